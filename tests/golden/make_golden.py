@@ -1,0 +1,304 @@
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE ITSELF (CPU fp32).
+
+Run only in the build container (needs /root/reference):
+    python tests/golden/make_golden.py [dit|vae|loop|ops|all]
+Outputs are small .npz files: seeded inputs, the reference's randomly initialised weights
+(state-dict key names unchanged) and the reference's outputs.  They are data only; no
+reference source is copied.  Same container + same torch => reproducible.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def npz_save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
+def sd_arrays(prefix, module):
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+TINY_DIT = dict(model_type="i2v", in_dim=64, dim=128, ffn_dim=512, num_heads=4, num_layers=2,
+                text_dim=64, text_len=32, freq_dim=256, out_dim=16, add_ref_conv=True,
+                use_dino_guidance=False, use_omnimae_guidance=False, cross_attn_norm=True)
+
+
+def load_recipe(module, keys_json, seed, prefix=""):
+    """Fill `module` from tests/golden/weights.py's recipe and record {key: shape} as a fixture
+    (the state-dict contract our own modules must reproduce)."""
+    import json
+    from weights import fill
+    shapes = {prefix + k: list(t.shape) for k, t in module.state_dict().items()}
+    if keys_json is not None:
+        with open(os.path.join(HERE, keys_json), "w") as fh:
+            json.dump(shapes, fh, indent=0, sort_keys=True)
+    sd = fill(shapes, seed)
+    module.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    return sd
+
+
+def randomize(model, gen_seed=4321, std=0.05):
+    """The reference zero-inits head.head.weight, biases, and guidance gates (:1378,1390,750-755):
+    give every zero-initialised tensor N(0, std) values so the fixture exercises them."""
+    g = torch.Generator().manual_seed(gen_seed)
+    for name, p in model.named_parameters():
+        if float(p.abs().sum()) == 0.0:
+            p.copy_(torch.randn(p.shape, generator=g) * std)
+        elif name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or \
+                name.endswith("norm_k_img.weight") or name.endswith("norm3.weight") or \
+                ".proj.0.weight" in name or ".proj.4.weight" in name:
+            p.add_(torch.randn(p.shape, generator=g) * 0.1)
+
+
+def make_dit_tiny(ref):
+    """Config 1 of SURVEY 8(d): tiny DiT, latent 1x32x32, with full_ref, seq_len padding."""
+    m = ref.dit.WanTransformer4DModel(**TINY_DIT).eval()
+    load_recipe(m, "dit_tiny_keys.json", seed=1234)
+    g = torch.Generator().manual_seed(7)
+    B = 2
+    x = torch.randn(B, 16, 2, 16, 16, generator=g)
+    y = torch.randn(B, 48, 2, 16, 16, generator=g)
+    full_ref = torch.randn(B, 16, 16, 16, generator=g)
+    ctx = [torch.randn(9, 64, generator=g), torch.randn(1, 64, generator=g)]
+    clip = torch.randn(B, 257, 1280, generator=g)
+    t = torch.tensor([500.0, 37.0])
+    L = 2 * 8 * 8
+    out_ref = m(x=x, t=t, context=ctx, seq_len=L + 5, clip_fea=clip, y=y, full_ref=full_ref)
+    out_noref = m(x=x, t=t, context=ctx, seq_len=L, clip_fea=clip, y=y, full_ref=None)
+    npz_save("dit_tiny.npz", x=x, y=y, full_ref=full_ref, ctx0=ctx[0], ctx1=ctx[1], clip=clip, t=t,
+             seq_len_pad=np.int64(L + 5), seq_len=np.int64(L), out_ref=out_ref, out_noref=out_noref)
+
+
+def make_dit_ops(ref):
+    """Per-op vectors: sinusoid, rope (incl. padded tail), rmsnorm, LN-modulate, SDPA,
+    self-attn, cross-attn, block (with and without spatial guidance), head."""
+    d = ref.dit
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    pos = torch.tensor([0.0, 1.0, 500.0, 999.0])
+    out["sin_pos"] = pos
+    out["sin_out"] = d.sinusoidal_embedding_1d(256, pos)
+    # rope: grid (2,3,4) = 24 tokens, 3 padded rows
+    hd = 128
+    freqs = torch.cat([d.rope_params(1024, hd - 4 * (hd // 6)), d.rope_params(1024, 2 * (hd // 6)),
+                       d.rope_params(1024, 2 * (hd // 6))], dim=1)
+    xq = torch.randn(1, 27, 2, hd, generator=g)
+    out["rope_x"] = xq
+    out["rope_out"] = d.rope_apply(xq, torch.tensor([[2, 3, 4]]), freqs)
+    # rmsnorm
+    rn = d.WanRMSNorm(256, eps=1e-6)
+    rn.weight.copy_(1 + 0.1 * torch.randn(256, generator=g))
+    xr = torch.randn(2, 5, 256, generator=g) * 3
+    out["rms_x"], out["rms_w"], out["rms_out"] = xr, rn.weight, rn(xr)
+    # sdpa
+    q = torch.randn(1, 64, 4, 128, generator=g)
+    k = torch.randn(1, 80, 4, 128, generator=g)
+    v = torch.randn(1, 80, 4, 128, generator=g)
+    out["att_q"], out["att_k"], out["att_v"] = q, k, v
+    out["att_out"] = d.attention(q, k, v)
+    npz_save("dit_ops.npz", **out)
+
+    # one block dim 256 / 2 heads (head_dim 128), with and without guidance
+    torch.manual_seed(99)
+    for guid in (False, True):
+        blk = d.WanAttentionBlock("i2v_cross_attn", 256, 1024, 2, (-1, -1), True, True, 1e-6,
+                                  use_spatial_guidance=guid).eval()
+        load_recipe(blk, "dit_block_guid_keys.json" if guid else "dit_block_keys.json", seed=99,
+                    prefix="blocks.0.")
+        grid = (2, 4, 5)
+        L = 40 + 3
+        x = torch.randn(2, L, 256, generator=g)
+        e0 = torch.randn(2, 6, 256, generator=g) * 0.3
+        ctx = torch.randn(2, 257 + 16, 256, generator=g)
+        freqs = torch.cat([d.rope_params(1024, 128 - 4 * (128 // 6)), d.rope_params(1024, 2 * (128 // 6)),
+                           d.rope_params(1024, 2 * (128 // 6))], dim=1)
+        feats = cls = None
+        if guid:
+            feats = torch.randn(2, 40, 768, generator=g)
+            cls = torch.randn(2, 1, 768, generator=g)
+        y = blk(x, e0, torch.tensor([L, L]), torch.tensor([list(grid)] * 2), freqs, ctx, None,
+                dtype=torch.float32, t=0, dino_features=(feats, cls), use_cls_token=False)
+        extra = dict(feats=feats, cls=cls) if guid else {}
+        npz_save("dit_block_guid.npz" if guid else "dit_block.npz", x=x, e0=e0, ctx=ctx,
+                 grid=np.array(grid), out=y, **extra)
+
+
+def make_block_14b_width(ref):
+    """One 14B-width block (dim 5120 / ffn 13824 / 40 heads) at small L=260, grid (5,4,13).
+    Weights are NOT stored (1.6 GB): they are regenerated from the seed by a recipe both this
+    script and the tests implement (tests/golden/weights.py); only input/output are stored."""
+    from weights import block_weights_14b
+    d = ref.dit
+    blk = d.WanAttentionBlock("i2v_cross_attn", 5120, 13824, 40, (-1, -1), True, True, 1e-6,
+                              use_spatial_guidance=False).eval()
+    sd = block_weights_14b(seed=0)
+    blk.load_state_dict({k[len("blocks.0."):]: v for k, v in sd.items()})
+    from weights import randn_named
+    grid = (5, 4, 13)
+    L = 260
+    x = randn_named("in.x", (1, L, 5120), 5)
+    e0 = randn_named("in.e0", (1, 6, 5120), 5, 0.2)
+    ctx = randn_named("in.ctx", (1, 257 + 512, 5120), 5)
+    freqs = torch.cat([d.rope_params(1024, 128 - 4 * (128 // 6)), d.rope_params(1024, 2 * (128 // 6)),
+                       d.rope_params(1024, 2 * (128 // 6))], dim=1)
+    y = blk(x, e0, torch.tensor([L]), torch.tensor([list(grid)]), freqs, ctx, None,
+            dtype=torch.float32, t=0, dino_features=None)
+    npz_save("dit_block_14b.npz", grid=np.array(grid), out=y)  # inputs: randn_named(..., seed 5)
+
+
+def make_loop(ref):
+    """50-step CFG Euler loop on the tiny DiT: hand-restated loop
+    around the imported reference DiT + the in-tree order-1 FlowDPMSolverMultistepScheduler."""
+    m = ref.dit.WanTransformer4DModel(**TINY_DIT).eval()
+    load_recipe(m, None, seed=1234)
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, 16, 1, 32, 32, generator=g)
+    y = torch.randn(1, 48, 1, 32, 32, generator=g)
+    full_ref = torch.randn(1, 16, 32, 32, generator=g)
+    ctx_c = torch.randn(9, 64, generator=g)
+    ctx_u = torch.randn(1, 64, generator=g)
+    clip = torch.randn(1, 257, 1280, generator=g)
+    steps, shift, gs = 50, 5.0, 6.0
+    sch = ref.fm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+    sig = ref.fm.get_sampling_sigmas(steps, shift)
+    # the pipeline passes pre-shifted sigmas through retrieve_timesteps -> set_timesteps(sigmas=...)
+    # which applies `shift` (config.shift=1.0 => identity) (fm_solvers.py:226-289)
+    sch.set_timesteps(sigmas=sig)
+    timesteps = sch.timesteps.clone()
+    sigmas = sch.sigmas.clone()
+    x = lat.clone()
+    seq_len = 16 * 16
+    for i, t in enumerate(timesteps):
+        inp = torch.cat([x, x])
+        tt = t.expand(2)
+        v = m(x=inp, t=tt, context=[ctx_u, ctx_c], seq_len=seq_len, clip_fea=torch.cat([clip, clip]),
+              y=torch.cat([y, y]), full_ref=torch.cat([full_ref, full_ref]))
+        vu, vc = v.chunk(2)
+        v = vu + gs * (vc - vu)
+        x = sch.step(v, t, x, return_dict=False)[0]
+    print("loop final abs-mean", float(x.abs().mean()), "sum", float(x.sum()))
+    npz_save("loop_tiny.npz", lat=lat, y=y, full_ref=full_ref, ctx_c=ctx_c, ctx_u=ctx_u, clip=clip,
+             timesteps=timesteps, sigmas=sigmas, final=x, steps=np.int64(steps), shift=np.float64(shift),
+             guidance=np.float64(gs))
+
+
+def make_vae(ref):
+    """AutoencoderKLWan encode/decode on [1,3,9,32,32] (3 chunks), per-op vectors for
+    CausalConv3d / RMS_norm / Resample (first vs later chunk) / ResidualBlock / AttentionBlock,
+    and the two trajectory adaptors."""
+    import json
+    from weights import fill
+    v = ref.vae
+    vae = v.AutoencoderKLWan().eval()
+    shapes = {k: list(t.shape) for k, t in vae.state_dict().items()}
+    with open(os.path.join(HERE, "vae_keys.json"), "w") as fh:
+        json.dump(shapes, fh, indent=0, sort_keys=True)
+    vae.load_state_dict(fill(shapes, seed=2024))  # 127 M params: regenerated by recipe, not stored
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 3, 9, 32, 32, generator=g) * 2 - 1
+    enc = vae._encode(x)  # [1,32,3,4,4] (mu normalised | logvar)
+    z = enc[:, :16]
+    dec = vae._decode(z).sample
+    npz_save("vae_roundtrip.npz", x=x, enc=enc, dec=dec)
+
+    # per-op fixtures with small channel counts (weights stored)
+    out = {}
+    conv = v.CausalConv3d(8, 12, 3, padding=1)
+    xx = torch.randn(1, 8, 3, 6, 7, generator=g)
+    cache = torch.randn(1, 8, 2, 6, 7, generator=g)
+    out.update(cc_w=conv.weight, cc_b=conv.bias, cc_x=xx, cc_cache=cache,
+               cc_out_nocache=conv(xx), cc_out_cache=conv(xx, cache),
+               cc_out_cache1=conv(xx, cache[:, :, -1:]))
+    rn = v.RMS_norm(8, images=False)
+    rn.gamma.add_(0.2 * torch.randn(rn.gamma.shape, generator=g))
+    out.update(rn_g=rn.gamma, rn_out=rn(xx))
+    npz_save("vae_ops.npz", **out)
+
+    # streaming sub-modules: run 3 chunks through each Resample mode / ResidualBlock with cache
+    for mode in ("upsample2d", "upsample3d", "downsample2d", "downsample3d"):
+        torch.manual_seed(5)
+        rs = v.Resample(8, mode).eval()
+        chunks = [torch.randn(1, 8, 1, 6, 8, generator=g), torch.randn(1, 8, 2, 6, 8, generator=g),
+                  torch.randn(1, 8, 2, 6, 8, generator=g)]
+        cache = [None]
+        outs = []
+        for c in chunks:
+            idx = [0]
+            outs.append(rs(c, cache, idx))
+        arrs = sd_arrays("sd.", rs)
+        npz_save(f"vae_resample_{mode}.npz", c0=chunks[0], c1=chunks[1], c2=chunks[2],
+                 o0=outs[0], o1=outs[1], o2=outs[2], **arrs)
+    torch.manual_seed(6)
+    rb = v.ResidualBlock(8, 12).eval()
+    chunks = [torch.randn(1, 8, 1, 6, 8, generator=g), torch.randn(1, 8, 4, 6, 8, generator=g),
+              torch.randn(1, 8, 1, 6, 8, generator=g)]
+    cache = [None, None]
+    outs = []
+    for c in chunks:
+        idx = [0]
+        outs.append(rb(c, cache, idx))
+    npz_save("vae_resblock.npz", c0=chunks[0], c1=chunks[1], c2=chunks[2], o0=outs[0], o1=outs[1],
+             o2=outs[2], **sd_arrays("sd.", rb))
+    torch.manual_seed(7)
+    ab = v.AttentionBlock(16).eval()
+    torch.nn.init.normal_(ab.proj.weight, std=0.1)
+    xa = torch.randn(1, 16, 2, 5, 6, generator=g)
+    npz_save("vae_attn.npz", x=xa, out=ab(xa), **sd_arrays("sd.", ab))
+
+    # adaptors
+    t = ref.traj
+    torch.manual_seed(8)
+    ea = t.VAEEncoderadaptor().eval()
+    da = t.VAEDecoderadaptor().eval()
+    for p in ea.conv_out.parameters():
+        p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    xt = torch.randn(1, 3, 2, 16, 24, generator=g) * 0.3
+    npz_save("adaptor_enc.npz", x=xt, out=ea(xt), **sd_arrays("sd.", ea))
+    npz_save("adaptor_dec.npz", x=xt, out=da(xt), **sd_arrays("sd.", da))
+
+
+def make_sched(ref):
+    """sigma/timestep tables of the in-tree order-1 solver and one step, 50 steps shift 5."""
+    sig = ref.fm.get_sampling_sigmas(50, 5.0)
+    sch = ref.fm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+    sch.set_timesteps(sigmas=sig)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 16, 2, 4, 4, generator=g)
+    v = torch.randn(1, 16, 2, 4, 4, generator=g)
+    x1 = sch.step(v, sch.timesteps[0], x, return_dict=False)[0]
+    x2 = sch.step(v, sch.timesteps[1], x1, return_dict=False)[0]
+    npz_save("sched.npz", sigmas=sch.sigmas, timesteps=sch.timesteps, x=x, v=v, x1=x1, x2=x2,
+             sampling_sigmas=sig)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    ref = _ref_import.load_reference()
+    if what in ("dit", "all"):
+        make_dit_tiny(ref)
+        make_dit_ops(ref)
+    if what in ("dit14b", "all"):
+        make_block_14b_width(ref)
+    if what in ("loop", "all"):
+        make_loop(ref)
+    if what in ("vae", "all"):
+        make_vae(ref)
+    if what in ("sched", "all"):
+        make_sched(ref)
