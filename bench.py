@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""bench.py — 4D-STraG denoise-steps/sec at 49x480x832, bf16, Wan2.1-14B-shaped DiT, on N MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input = the CFG pair of DiT forwards
+(batch 2, L = 21 840 tokens incl. the reference-image row) + classifier-free guidance + Euler update, with
+latents / control latents / embedded context resident in HBM before the timed region.  N > 1 shards the
+token (= frame-major, T) axis across ranks with an RCCL all-gather of K / V^T per layer (strong scaling:
+the N GPUs cooperate on the same sample).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     : the dominant kernel (bf16 MFMA GEMM), algorithmic FLOPs / HIP-event time over the timed region
+  cpu_baseline : the CPU oracle (oracle/dit.py, fp32, torch threads) on a bounded sample, N=1 rank 0 only.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG_14B = dict(model_type="i2v", patch_size=(1, 2, 2), text_len=512, in_dim=64, dim=5120, ffn_dim=13824, freq_dim=256,
+               text_dim=4096, out_dim=16, num_heads=40, num_layers=40, qk_norm=True, cross_attn_norm=True, eps=1e-6,
+               add_ref_conv=True, in_dim_ref_conv=16, use_dino_guidance=False, use_omnimae_guidance=False)
+MFMA_BF16_PEAK_TF = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(cfg, device, dtype):
+    """Random-init weights of the named architecture directly on the device (no checkpoint offline)."""
+    from more4d_amd.models import WanTransformer4DModel
+    with torch.device("meta"):
+        m = WanTransformer4DModel(**cfg)
+    m = m.to_empty(device=device)
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm_k_img.weight") \
+                    or name.endswith("norm3.weight") or ".proj.0.weight" in name or ".proj.4.weight" in name:
+                p.fill_(1.0)
+            elif name.endswith("bias"):
+                p.zero_()
+            elif name.endswith("modulation"):
+                p.copy_(torch.randn(p.shape, generator=g, device=device) / p.shape[-1] ** 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g, device=device) * 0.02)
+    m.disable_riflex()   # rebuild the host-side freqs table (it was created on the meta device)
+    return m.to(dtype).eval()
+
+
+def flops_per_forward(cfg, L, B):
+    d, ffn, nl = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
+    ctx = cfg["text_len"] + 257
+    gemm = nl * (12 * L * d * d + 4 * L * d * ffn) + 2 * L * (256 + 64) * d
+    attn = nl * (4 * L * L * d + 4 * L * ctx * d)
+    return B * gemm, B * attn
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are enqueued on (torch's current stream —
+    the one ops.py hands to the C ABI)."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def wrap(self, ops_mod, name, flops_fn):
+        orig = getattr(ops_mod, name)
+        timer = self
+
+        def timed(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig(*a, **k)
+            e.record()
+            timer.rec.setdefault(name, []).append((s, e, flops_fn(*a, **k)))
+            return out
+        setattr(ops_mod, name, timed)
+        return orig
+
+    def summary(self):
+        out = {}
+        for name, lst in self.rec.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in lst)
+            fl = sum(f for _, _, f in lst)
+            out[name] = dict(launches=len(lst), ms=ms, flops=fl, tflops=fl / ms / 1e9 if ms > 0 else 0.0)
+        return out
+
+
+def cpu_baseline(cfg, L, seconds_hint=30):
+    """oracle/dit.py block_forward (fp32) at full 14B width and full L on the host cores: one block,
+    extrapolated x num_layers x 2 (CFG) to a step.  Bounded sample: ~20-60 s of CPU work."""
+    from oracle import dit as odit
+
+    def block_shapes(dim, ffn):
+        s = {"blocks.0.modulation": (1, 6, dim), "blocks.0.norm3.weight": (dim,), "blocks.0.norm3.bias": (dim,),
+             "blocks.0.ffn.0.weight": (ffn, dim), "blocks.0.ffn.0.bias": (ffn,), "blocks.0.ffn.2.weight": (dim, ffn),
+             "blocks.0.ffn.2.bias": (dim,), "blocks.0.cross_attn.norm_k_img.weight": (dim,)}
+        for a in ("self_attn", "cross_attn"):
+            for n in ("q", "k", "v", "o") + (("k_img", "v_img") if a == "cross_attn" else ()):
+                s[f"blocks.0.{a}.{n}.weight"] = (dim, dim)
+                s[f"blocks.0.{a}.{n}.bias"] = (dim,)
+            s[f"blocks.0.{a}.norm_q.weight"] = (dim,)
+            s[f"blocks.0.{a}.norm_k.weight"] = (dim,)
+        return s
+    torch.manual_seed(0)
+    ocfg = odit.DiTConfig(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"], num_layers=1)
+    sd = {k: torch.randn(v) * (0.02 if len(v) > 1 else 0.0) + (1.0 if "norm" in k and k.endswith("weight") else 0.0)
+          for k, v in block_shapes(cfg["dim"], cfg["ffn_dim"]).items()}
+    h, w = 30, 52
+    f = L // (h * w)
+    Lc = f * h * w
+    x = torch.randn(1, Lc, cfg["dim"])
+    e0 = torch.randn(1, 6, cfg["dim"]) * 0.1
+    ctx = torch.randn(1, 257 + cfg["text_len"], cfg["dim"])
+    t0 = time.time()
+    with torch.no_grad():
+        odit.block_forward(sd, 0, ocfg, x, e0, (f, h, w), ctx)
+    dt = time.time() - t0
+    step_s = dt * cfg["num_layers"] * 2
+    return dict(value=1.0 / step_s, unit="denoise-steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"one 14B-width WanAttentionBlock (oracle/dit.py, fp32) at L={Lc}: {dt:.1f} s, "
+                       f"x{cfg['num_layers']} layers x2 CFG => {step_s:.0f} s/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=40, help="debug only: != 40 marks the result invalid")
+    ap.add_argument("--no-ref", action="store_true", help="drop the reference-image row (L=20280)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from more4d_amd import ops
+    from more4d_amd.pipeline import denoise_latents
+    from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+
+    cfg = dict(CFG_14B)
+    cfg["num_layers"] = args.layers
+    dtype = torch.bfloat16
+    model = build_model(cfg, dev, dtype)
+    if world > 1:
+        from more4d_amd.dist import init_sequence_parallel
+        init_sequence_parallel()
+        model.enable_multi_gpus_inference()
+
+    # synthetic 49x480x832 trajectory latents: [1,16,13,60,104] (+48 control channels, ref row, context)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    F_, H_, W_ = 13, 60, 104
+    lat = torch.randn(1, 16, F_, H_, W_, generator=g, device=dev)
+    y = torch.randn(1, 48, F_, H_, W_, generator=g, device=dev)
+    full_ref = None if args.no_ref else torch.randn(1, 16, H_, W_, generator=g, device=dev)
+    ctx = [torch.randn(512, 4096, generator=g, device=dev), torch.randn(77, 4096, generator=g, device=dev)]
+    clip = torch.randn(1, 257, 1280, generator=g, device=dev)
+    Lv = F_ * (H_ // 2) * (W_ // 2)
+    L = Lv + (0 if args.no_ref else (H_ // 2) * (W_ // 2))
+
+    sch = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+    total_steps = args.warmup + args.steps
+    ts, _ = retrieve_timesteps(sch, device=dev, sigmas=get_sampling_sigmas(50, 5.0))
+    with torch.no_grad():
+        cc = model.prepare_context(ctx, torch.cat([clip, clip]))   # step-invariant, resident before timing
+
+        def run(i0, n, x):
+            class _S:   # scheduler view starting at step i0
+                @staticmethod
+                def step_cfg_(lat_, v, gs, i, round_dtype=torch.float32):
+                    return sch.step_cfg_(lat_, v, gs, i0 + i, round_dtype)
+            return denoise_latents(model, _S, x, ts[i0:i0 + n], 6.0, cc, y=y, full_ref=full_ref, seq_len=Lv)
+
+        x = run(0, args.warmup, lat) if args.warmup else lat
+        kt = None
+        if not args.no_kernel_timers:
+            kt = KernelTimer()
+
+            def gemm_flops(a, w, *aa, **kk):
+                return 2 * (a.numel() // a.shape[-1]) * (w.numel() // w.shape[-1]) * a.shape[-1]
+
+            def attn_flops(q, segs, *aa, **kk):
+                klen = sum(max(0, s.len) for s in segs)
+                return 4 * kk["B"] * kk["Lq"] * klen * kk["heads"] * kk["head_dim"]
+            kt.wrap(ops, "gemm_bt", gemm_flops)
+            kt.wrap(ops, "attention", attn_flops)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x = run(args.warmup, args.steps, x)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    ok = bool(torch.isfinite(x).all())
+
+    if rank == 0:
+        gemm_fl, attn_fl = flops_per_forward(cfg, L, 2)
+        step_flops = gemm_fl + attn_fl
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "4D-STraG denoise-steps/sec, 49x480x832 bf16", "value": args.steps / dt, "unit": "denoise-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1] x CFG: Wan2.1-14B-shaped DiT (40 layers, d=5120, ffn=13824, 40 heads), "
+                                   f"latent 1x16x13x60x104 (49x480x832 px), L={L} tokens"
+                                   f"{'' if args.no_ref else ' incl. 1560 ref-row tokens'}, CFG batch 2, "
+                                   "guidance + Euler fused; random-init weights",
+                       "layers": args.layers, "tokens": L, "cfg_batch": 2,
+                       "parallelism": "single GPU" if world == 1 else f"sp{world} (token/T-sharded, RCCL all-gather K,V^T)"},
+            "finite": ok, "valid": args.layers == 40 and ok,
+            "step_tflop": step_flops / 1e12,
+            "mfma_frac_whole_step": step_flops / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TF * world),
+        }
+        if kt is not None:
+            ks = kt.summary()
+            gk = ks.get("gemm_bt", {})
+            out["roofline"] = {
+                "kernel": "gemm_bt_kernel<bf16> (all DiT projections / FFN; flops-weighted over its launches)",
+                "bound": "mfma", "achieved": gk.get("tflops", 0.0), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                "frac": gk.get("tflops", 0.0) / MFMA_BF16_PEAK_TF, "traffic": None,
+                "launches": gk.get("launches", 0), "avg_launch_ms": gk.get("ms", 0.0) / max(1, gk.get("launches", 1)),
+                "share_of_step_time": gk.get("ms", 0.0) / (dt * 1e3),
+            }
+            ak = ks.get("attention", {})
+            out["roofline_attention"] = {
+                "kernel": "attn_kernel<bf16,128>", "bound": "mfma", "achieved": ak.get("tflops", 0.0),
+                "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ak.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
+                "launches": ak.get("launches", 0), "share_of_step_time": ak.get("ms", 0.0) / (dt * 1e3),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, L)
+            except Exception as ex:  # the baseline must never sink the measurement
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/* more4d_hip.h — C ABI of libmore4d_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * 4D-STraG denoising hot path of MoRe4D (Wan2.1-DiT forward, Motion-Sensitive 3D-VAE, Euler/CFG loop).
+ *
+ * The reference has no FFI for this path: its boundary is the Python operator surface of
+ * MoRe4D/models/wan_transformer4d.py, wan_vae.py, trajectory_module.py and the loop in
+ * MoRe4D/pipeline/pipeline_wan_fun_control.py.  Each entry point below names the
+ * reference lines whose arithmetic it replaces.  Host code (more4d_amd/_lib.py) binds these with
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); the library never allocates,
+ *     frees or keeps them past the enqueued work;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); work is enqueued,
+ *     never synchronised;
+ *   - return 0 on success, <0 on error (-1 invalid argument, -2 unsupported shape, -3 launch
+ *     failure); m4d_last_error() returns a thread-local message; nothing throws across the ABI;
+ *   - dtype enums select the activation/weight element type `T`: M4D_BF16 is the production path
+ *     (bf16 operands, fp32 accumulation, casts placed where the reference's autocast puts them),
+ *     M4D_F32 is the parity path (exact-fp32 MFMA, checked against the CPU oracle to 1e-3).
+ */
+#ifndef MORE4D_HIP_H
+#define MORE4D_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { M4D_F32 = 0, M4D_BF16 = 1 } m4d_dtype;
+typedef void* m4d_stream;
+
+int m4d_version(void);
+const char* m4d_last_error(void);
+
+/* ---- GEMM epilogues (m4d_gemm_bt) ---- */
+typedef enum {
+    M4D_EPI_STORE = 0,      /* out[T]   = acc + bias                                   nn.Linear */
+    M4D_EPI_GELU_TANH = 1,  /* out[T]   = gelu_tanh(acc + bias)          wan_transformer4d.py:620-622, 900-902 */
+    M4D_EPI_GELU_ERF = 2,   /* out[T]   = gelu_erf(acc + bias)           MLPProj :729-732 */
+    M4D_EPI_SILU = 3,       /* out[T]   = silu(acc + bias)               time_embedding :904-906 */
+    M4D_EPI_RESID_GATE = 4, /* resid[f32] += round_T(acc + bias) * gate[sample(m), n]   :669, :674, :684 */
+    M4D_EPI_STORE_F32 = 5   /* out[f32] = round_T(acc + bias)            patch_embedding :1073, head :720 */
+} m4d_epilogue;
+
+/* C[M,N] = A[M,K] * W[N,K]^T (+ bias) with a fused epilogue.  Replaces every nn.Linear and the
+ * kernel==stride convs (patch_embedding :898-899, ref_conv :946) of the DiT, the 1x1(x1) convs of the
+ * VAE, and (through m4d_im2col_*) its 3x3(x3) convs.
+ *   A: T [M,K] row stride lda; W: T [N,K] row stride ldw (nn.Linear weight layout);
+ *   bias: T [N] (or T [M] when bias_on_m != 0), may be NULL;
+ *   out: T [M,N] (STORE/GELU/SILU) or float [M,N] (STORE_F32), row stride ldc;
+ *   resid: float [M,N] row stride ldc, updated in place (RESID_GATE); gate: float, element
+ *   [ (m / rows_per_sample) * gate_stride + n ], NULL => 1.
+ * Requirements: K*sizeof(T) % 16 == 0, N % 4 == 0, lda/ldw*sizeof(T) % 16 == 0, ldc % 4 == 0. */
+int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                const float* gate, int64_t gate_stride, int64_t rows_per_sample, m4d_stream stream);
+
+/* LayerNorm (no affine | affine) * (1 + scale) + shift, optional spatial guidance, cast to T.
+ * Replaces WanLayerNorm + modulation (:662, :677, :720), norm3 (:611-613, :674), the LayerNorms of
+ * MLPProj (:729-732) and SpatialGuidanceModule.forward (:757-783).
+ *   x: x_dt [rows, C] contiguous; out: out_dt [rows, C];
+ *   shift/scale: float, element [(row / rows_per_sample) * mod_stride + c], both NULL => no modulation;
+ *   ln_w/ln_b: float [C] or NULL;
+ *   guidance (all NULL/0 to disable): g_ss float [B, g_period, 2C] = (scale | shift) per spatial
+ *   position, g_gate float [C]; token l of a sample uses position l % g_period when l < g_len and
+ *   zero scale/shift otherwise (the reference zero-pads, :772-776).
+ * Requirements: C % 4 == 0, C <= 8192. */
+int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, void* out, int64_t rows, int C,
+                    int64_t rows_per_sample, const float* shift, const float* scale, int64_t mod_stride,
+                    const float* ln_w, const float* ln_b, float eps, const float* g_ss,
+                    const float* g_gate, int64_t g_period, int64_t g_len, m4d_stream stream);
+
+/* In-place WanRMSNorm over the full channel dim (:386-394) followed by 3-axis RoPE on adjacent pairs
+ * (:340-369) for up to two tensors (q and k) in one launch.
+ *   x0/x1: T [rows, C] row stride ld (x1 may be NULL); w0/w1: float [C];
+ *   cos/sin: float [table_rows, head_dim/2], per-token tables built by the host for the (f,h,w) grid
+ *   (NULL => no RoPE, cross-attention q/k); token l = row % rows_per_sample gets table row
+ *   pos_offset + l when l < rope_len, rows past rope_len are normalised but not rotated (:365). */
+int m4d_rmsnorm_rope(m4d_dtype dt, void* x0, void* x1, int64_t ld, const float* w0, const float* w1,
+                     int64_t rows, int C, int head_dim, float eps, const float* cos_t, const float* sin_t,
+                     int64_t rows_per_sample, int64_t rope_len, int64_t pos_offset, m4d_stream stream);
+
+/* Non-causal softmax(q k^T * scale) v, flash style (never materialises the score matrix).
+ * Replaces attention()/flash_attention() (:66-236) as used by WanSelfAttention (:455-461) and
+ * WanI2VCrossAttention (:533-552).  K/V may arrive as up to M4D_MAX_KV_SEGS segments (the T-sharded
+ * denoise loop hands over one segment per rank after the RCCL all-gather, no concat copy).
+ *   q:   T, element (b, l, h, d) at q + b*q_bs + l*q_ls + h*head_dim + d;  out likewise (o_bs, o_ls);
+ *   seg s: k_s element (b, j, h, d) at k[s] + b*k_bs[s] + j*k_ls[s] + h*head_dim + d;
+ *          V is supplied TRANSPOSED: vt_s element (b, h, d, j) at vt[s] + b*vt_bs[s] + (h*head_dim + d)*vt_ls[s] + j
+ *          (the projection GEMM writes V^T directly: m4d_gemm_bt(A = W_v, W = x));
+ *          len[s] keys are valid.
+ *   accumulate != 0: out = round_T(round_T(o) + out)   (x + img_x, :552).
+ * head_dim in {32, 64, 128}; all strides in elements, multiples of 8. */
+#define M4D_MAX_KV_SEGS 8
+typedef struct {
+    const void* k[M4D_MAX_KV_SEGS];
+    const void* vt[M4D_MAX_KV_SEGS];
+    int64_t k_bs[M4D_MAX_KV_SEGS], k_ls[M4D_MAX_KV_SEGS];
+    int64_t vt_bs[M4D_MAX_KV_SEGS], vt_ls[M4D_MAX_KV_SEGS];
+    int64_t len[M4D_MAX_KV_SEGS];
+    int32_t nseg;
+} m4d_kv_segs;
+
+int m4d_attention(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,
+                  int64_t o_bs, int64_t o_ls, int B, int64_t Lq, int heads, int head_dim, float scale,
+                  int accumulate, m4d_stream stream);
+
+/* Patch gather for the kernel==stride convs: out[b, (f,h,w), (c,pt,ph,pw)] = src[b, c, f*pt.., h*ph.., w*pw..]
+ * with channels taken from src0 (c0 channels) then src1 (c1 channels; NULL/0 allowed) — the
+ * torch.cat([x, y], dim=0 per sample) + Conv3d of :1069-1073, and ref_conv :1087 with F = 1. */
+int m4d_patchify(m4d_dtype src_dt, const void* src0, int c0, const void* src1, int c1, m4d_dtype out_dt,
+                 void* out, int B, int F, int H, int W, int pt, int ph, int pw, m4d_stream stream);
+
+/* unpatchify (:1343-1366): tok float [B, tok_bs rows.., (pt,ph,pw,c)] starting at row tok_row0 of each
+ * sample -> out out_dt [B, c, F*pt, H*ph, W*pw]. */
+int m4d_unpatchify(const float* tok, int64_t tok_bs, int64_t tok_row0, m4d_dtype out_dt, void* out, int B,
+                   int c, int F, int H, int W, int pt, int ph, int pw, m4d_stream stream);
+
+/* Classifier-free guidance + Euler step in one pass (pipeline_wan_fun_control.py:820-825,
+ * fm_solvers.py:415-483 order-1):  x <- x + dsigma * (v_u + g * (v_c - v_u)),  fp32 state.
+ *   v: v_dt [2, n] (uncond half first); round_dt: the model dtype the reference casts the sample back
+ *   to after the step (fm_solvers.py:789) — M4D_F32 keeps fp32. */
+int m4d_cfg_euler(float* x, m4d_dtype v_dt, const void* v, int64_t n, float guidance, float dsigma,
+                  m4d_dtype round_dt, m4d_stream stream);
+
+/* Elementwise helpers: out = act(x) with dtype conversion (act: 0 copy/cast, 1 silu, 2 gelu_tanh). */
+int m4d_unary(m4d_dtype in_dt, const void* x, m4d_dtype out_dt, void* out, int64_t n, int act,
+              m4d_stream stream);
+
+/* out[b, i] = a[b, i] + bias[i]  (float32; a: [B, n], bias: [n]) — `(self.modulation + e)` of
+ * WanAttentionBlock (:659) and Head (:718). */
+int m4d_add_bcast(const float* a, const float* bias, float* out, int64_t B, int64_t n, m4d_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MORE4D_HIP_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of libmore4d_hip.so (include/more4d_hip.h).  There is NO fallback: if the library
+is missing or a call fails the caller gets an exception — the HIP kernels are the product path."""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmore4d_hip.so")
+
+M4D_F32, M4D_BF16 = 0, 1
+EPI_STORE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_SILU, EPI_RESID_GATE, EPI_STORE_F32 = range(6)
+MAX_KV_SEGS = 8
+
+
+class KvSegs(Structure):
+    _fields_ = [("k", c_void_p * MAX_KV_SEGS), ("vt", c_void_p * MAX_KV_SEGS),
+                ("k_bs", c_int64 * MAX_KV_SEGS), ("k_ls", c_int64 * MAX_KV_SEGS),
+                ("vt_bs", c_int64 * MAX_KV_SEGS), ("vt_ls", c_int64 * MAX_KV_SEGS),
+                ("len", c_int64 * MAX_KV_SEGS), ("nseg", c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/more4d_hip.h one to one
+SIGNATURES = {
+    "m4d_version": (c_int, []),
+    "m4d_last_error": (c_char_p, []),
+    "m4d_gemm_bt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64,
+                            c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]),
+    "m4d_ln_modulate": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int64,
+                                c_void_p]),
+    "m4d_rmsnorm_rope": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                 c_float, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "m4d_attention": (c_int, [c_int, c_void_p, c_int64, c_int64, POINTER(KvSegs), c_void_p, c_int64, c_int64,
+                              c_int, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "m4d_patchify": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_int, c_void_p]),
+    "m4d_unpatchify": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, c_void_p]),
+    "m4d_cfg_euler": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
+    "m4d_unary": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
+    "m4d_add_bcast": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class More4DHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise More4DHipError(
+            f"{LIB_PATH} not found: build it with `python -m more4d_amd.build` "
+            "(the HIP extension is the only compute path; there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().m4d_last_error()
+        raise More4DHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,319 @@
+// m4d_attention: non-causal flash attention forward for gfx950 (wave64, MFMA 32x32).
+//
+// Formulation ("doubly swapped", so every softmax statistic is lane-local):
+//   S^T[key][q] = K · Q^T        A-operand = K tile rows (from LDS), B-operand = Q (registers)
+//   O^T[d][q]  += V^T · P^T      A-operand = V^T tile rows (from LDS), B-operand = P (registers)
+// Lane (q = l&31, hi = l>>5) of a wave owns query row q: its 16 S^T accumulator registers per 32-key
+// sub-tile are 16 of that row's 32 scores (the other 16 live in lane l^32), and its O^T registers are
+// 64 of the row's 128 outputs.  Row max needs one cross-half exchange per tile; the row sum is kept
+// per half and combined once in the epilogue.  K rows are fetched from LDS through the permutation
+// "swap index bits 2 and 3", which makes accumulator registers 8s..8s+7 hold 8 CONSECUTIVE keys
+// (16s + 8hi + [0,8)), i.e. exactly the B-operand fragment of the P·V MFMA and one 16-B read of a V^T row:
+// P never leaves registers and needs no cross-lane shuffle.
+// V arrives transposed (V^T[d][key]) — the projection GEMM writes it that way for free.
+//
+// Workgroup = 4 waves x 32 queries = 128 queries; KV tile = 64 keys (bf16) / 32 keys (fp32 parity
+// mode); one LDS stage (K tile + V^T tile, 32 KiB) with the next tile's global loads held in
+// registers while the current tile is computed (issue-early / write-late), two barriers per tile.
+// LDS images are XOR-swizzled per 16-B chunk so fragment reads (ds_read_b128) are conflict-free.
+#include "common.h"
+#include "more4d_hip.h"
+
+namespace {
+
+struct AttnArgs {
+    const void* q; void* out;
+    m4d_kv_segs kv;
+    int64_t q_bs, q_ls, o_bs, o_ls, Lq;
+    int B, heads, nq_tiles, accumulate;
+    float sc;  // softmax scale * log2(e)
+};
+
+template <int RB> M4D_DEV int swz_off(int row, int chunk) {
+    constexpr int CPR = RB / 16;
+    if constexpr (CPR >= 16) return row * RB + ((chunk ^ (row & 15)) << 4);
+    else return row * RB + ((chunk ^ ((row / (16 / CPR)) & (CPR - 1))) << 4);
+}
+
+M4D_DEV int perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+template <typename T> struct TileCfg;
+template <> struct TileCfg<bf16_t> { static constexpr int KVB = 64; };
+template <> struct TileCfg<float> { static constexpr int KVB = 32; };
+
+template <typename T> M4D_DEV typename Frag8<T>::type lds_frag(const char* base, int off0, int off1);
+template <> M4D_DEV bf16x8 lds_frag<bf16_t>(const char* base, int off0, int) {
+    return *reinterpret_cast<const bf16x8*>(base + off0);
+}
+template <> M4D_DEV f32x8 lds_frag<float>(const char* base, int off0, int off1) {
+    f32x4 lo = *reinterpret_cast<const f32x4*>(base + off0);
+    f32x4 hi = *reinterpret_cast<const f32x4*>(base + off1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <typename T> M4D_DEV typename Frag8<T>::type pack8(const f32x16& s, int base);
+template <> M4D_DEV bf16x8 pack8<bf16_t>(const f32x16& s, int base) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)s[base + j];
+    return r;
+}
+template <> M4D_DEV f32x8 pack8<float>(const f32x16& s, int base) {
+    f32x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = s[base + j];
+    return r;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_kernel(AttnArgs p) {
+    constexpr int ES = sizeof(T);
+    constexpr int KVB = TileCfg<T>::KVB;
+    constexpr int NSUB = KVB / 32;
+    constexpr int KRB = D * ES;      // bytes per K row
+    constexpr int VRB = KVB * ES;    // bytes per V^T row
+    constexpr int KCPR = KRB / 16, VCPR = VRB / 16;
+    constexpr int TILE_BYTES = KVB * D * ES;
+    constexpr int NLD = TILE_BYTES / 16 / 256;  // 16-B chunks per thread per operand
+    constexpr int EPC = 16 / ES;                 // elements per chunk
+    constexpr int NKK = D / 16, NDB = D / 32;
+    typedef typename Frag8<T>::type frag_t;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+    char* sK = smem;
+    char* sV = smem + TILE_BYTES;
+
+    // ---- block -> (q tile, head, batch); (b,h) groups pinned per XCD so K/V stay in that L2 ----
+    const int HB = p.heads * p.B;
+    int qt, hb;
+    if ((HB & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        hb = xcd * (HB >> 3) + idx / p.nq_tiles;
+        qt = idx % p.nq_tiles;
+    } else {
+        hb = blockIdx.x / p.nq_tiles;
+        qt = blockIdx.x % p.nq_tiles;
+    }
+    const int b = hb / p.heads, h = hb % p.heads;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, hi = lane >> 5;
+    const int64_t qrow = (int64_t)qt * 128 + wave * 32 + li;
+    const bool qvalid = qrow < p.Lq;
+
+    // ---- Q fragments (B operand of S^T = K Q^T) ----
+    frag_t qf[NKK];
+    {
+        const T* qp = (const T*)p.q + b * p.q_bs + qrow * p.q_ls + (int64_t)h * D + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            if (qvalid) qf[kk] = *reinterpret_cast<const frag_t*>(qp + kk * 16);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[kk][j] = (T)0.f;
+            }
+        }
+    }
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- KV tile iterator over segments ----
+    int seg = 0;
+    while (seg < p.kv.nseg && p.kv.len[seg] <= 0) ++seg;
+    int64_t key0 = 0;
+    uint4 rk[NLD], rv[NLD];
+
+    auto gload = [&](int s, int64_t k0) {
+        const int64_t len = p.kv.len[s];
+        const T* kp = (const T*)p.kv.k[s] + b * p.kv.k_bs[s] + (int64_t)h * D;
+        const T* vp = (const T*)p.kv.vt[s] + b * p.kv.vt_bs[s] + (int64_t)h * D * p.kv.vt_ls[s];
+        const int64_t kls = p.kv.k_ls[s], vls = p.kv.vt_ls[s];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = t + 256 * i;
+            {   // K: [KVB rows][KCPR chunks]
+                const int row = c / KCPR, ch = c % KCPR;
+                const int64_t key = k0 + row;
+                rk[i] = key < len ? *reinterpret_cast<const uint4*>(kp + key * kls + ch * EPC) : make_uint4(0, 0, 0, 0);
+            }
+            {   // V^T: [D rows][VCPR chunks]
+                const int row = c / VCPR, ch = c % VCPR;
+                const int64_t key = k0 + ch * EPC;
+                const T* src = vp + row * vls + key;
+                if (key + EPC <= len) rv[i] = *reinterpret_cast<const uint4*>(src);
+                else if (key >= len) rv[i] = make_uint4(0, 0, 0, 0);
+                else {  // ragged last chunk: element-wise, zero fill
+                    union { uint4 u; T e[EPC]; } tmp;
+                    tmp.u = make_uint4(0, 0, 0, 0);
+                    for (int j = 0; j < EPC; ++j)
+                        if (key + j < len) tmp.e[j] = src[j];
+                    rv[i] = tmp.u;
+                }
+            }
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = t + 256 * i;
+            *reinterpret_cast<uint4*>(sK + swz_off<KRB>(c / KCPR, c % KCPR)) = rk[i];
+            *reinterpret_cast<uint4*>(sV + swz_off<VRB>(c / VCPR, c % VCPR)) = rv[i];
+        }
+    };
+
+    if (seg < p.kv.nseg) gload(seg, key0);
+    while (seg < p.kv.nseg) {
+        swrite();
+        __syncthreads();
+        // current tile meta, then advance + prefetch
+        const int64_t cur_len = p.kv.len[seg], cur_k0 = key0;
+        int nseg_ = seg;
+        int64_t nk0 = key0 + KVB;
+        if (nk0 >= cur_len) {
+            nk0 = 0;
+            ++nseg_;
+            while (nseg_ < p.kv.nseg && p.kv.len[nseg_] <= 0) ++nseg_;
+        }
+        if (nseg_ < p.kv.nseg) gload(nseg_, nk0);
+
+        // ---- S^T = K Q^T ----
+        f32x16 s[NSUB];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+            const int krow = sub * 32 + perm23(li);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const int c0 = (kk * 16 + hi * 8) / EPC;
+                frag_t kf = lds_frag<T>(sK, swz_off<KRB>(krow, c0), swz_off<KRB>(krow, c0 + 1));
+                mma32(kf, qf[kk], s[sub]);
+            }
+        }
+        // ---- mask the ragged tail of a segment ----
+        if (cur_k0 + KVB > cur_len) {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t key = cur_k0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (key >= cur_len) s[sub][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (exp2 domain) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * p.sc);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(fmaf(s[sub][r], p.sc, -m_new));
+                s[sub][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                const frag_t pf = pack8<T>(s[sub], si * 8);
+                const int c0 = (sub * 32 + si * 16 + hi * 8) / EPC;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) {
+                    const int vrow = d * 32 + li;
+                    frag_t vf = lds_frag<T>(sV, swz_off<VRB>(vrow, c0), swz_off<VRB>(vrow, c0 + 1));
+                    mma32(vf, pf, o[d]);
+                }
+            }
+        __syncthreads();
+        seg = nseg_;
+        key0 = nk0;
+    }
+
+    // ---- epilogue: normalise, (accumulate), store 4 consecutive d per lane ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (qvalid) {
+        T* op = (T*)p.out + b * p.o_bs + qrow * p.o_ls + (int64_t)h * D + hi * 4;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][rq * 4 + e] * inv;
+                T* dst = op + d * 32 + rq * 8;
+                if (p.accumulate) {
+                    f32x4 prev = load4(dst);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]) + prev[e];
+                }
+                store4(dst, v);
+            }
+    }
+}
+
+template <typename T>
+int launch(const AttnArgs& p, int D, hipStream_t st) {
+    dim3 grid((unsigned)((int64_t)p.nq_tiles * p.heads * p.B)), block(256);
+    switch (D) {
+        case 32: hipLaunchKernelGGL((attn_kernel<T, 32>), grid, block, 0, st, p); break;
+        case 64: hipLaunchKernelGGL((attn_kernel<T, 64>), grid, block, 0, st, p); break;
+        case 128: hipLaunchKernelGGL((attn_kernel<T, 128>), grid, block, 0, st, p); break;
+        default: return -2;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int m4d_attention(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,
+                             int64_t o_bs, int64_t o_ls, int B, int64_t Lq, int heads, int head_dim, float scale,
+                             int accumulate, m4d_stream stream) {
+    M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "attention: bad dtype %d", (int)dt);
+    M4D_CHECK_ARG(q && kv && out, "attention: null pointer");
+    M4D_CHECK_ARG(B > 0 && Lq > 0 && heads > 0, "attention: empty problem");
+    M4D_CHECK_ARG(kv->nseg >= 1 && kv->nseg <= M4D_MAX_KV_SEGS, "attention: nseg=%d out of range", kv->nseg);
+    if (!(head_dim == 32 || head_dim == 64 || head_dim == 128)) {
+        m4d_set_error("attention: unsupported head_dim %d (32, 64, 128)", head_dim);
+        return -2;
+    }
+    int64_t total = 0;
+    for (int s = 0; s < kv->nseg; ++s) {
+        M4D_CHECK_ARG(kv->len[s] >= 0, "attention: negative segment length");
+        if (kv->len[s] == 0) continue;
+        M4D_CHECK_ARG(kv->k[s] && kv->vt[s], "attention: null K/V segment %d", s);
+        M4D_CHECK_ARG(kv->k_ls[s] % 8 == 0 && kv->vt_ls[s] % 8 == 0 && kv->k_bs[s] % 8 == 0 && kv->vt_bs[s] % 8 == 0,
+                      "attention: K/V strides must be multiples of 8 elements (segment %d)", s);
+        M4D_CHECK_ARG(((uintptr_t)kv->k[s] % 16) == 0 && ((uintptr_t)kv->vt[s] % 16) == 0, "attention: K/V must be 16-byte aligned");
+        total += kv->len[s];
+    }
+    M4D_CHECK_ARG(total > 0, "attention: no keys");
+    M4D_CHECK_ARG(q_ls % 8 == 0 && q_bs % 8 == 0 && o_ls % 8 == 0 && o_bs % 8 == 0, "attention: q/out strides must be multiples of 8 elements");
+    M4D_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)out % 16) == 0, "attention: q/out must be 16-byte aligned");
+    AttnArgs p;
+    p.q = q; p.out = out; p.kv = *kv;
+    p.q_bs = q_bs; p.q_ls = q_ls; p.o_bs = o_bs; p.o_ls = o_ls; p.Lq = Lq;
+    p.B = B; p.heads = heads; p.nq_tiles = (int)((Lq + 127) / 128); p.accumulate = accumulate;
+    p.sc = scale * 1.4426950408889634f;
+    int rc = dt == M4D_BF16 ? launch<bf16_t>(p, head_dim, (hipStream_t)stream) : launch<float>(p, head_dim, (hipStream_t)stream);
+    if (rc) { m4d_set_error("attention: unsupported configuration"); return rc; }
+    M4D_CHECK_LAUNCH("attention");
+    return 0;
+}

@@ -1,0 +1,373 @@
+// HBM-bound kernels of the DiT path: fused LayerNorm+modulate(+guidance), RMSNorm+RoPE, patch gather /
+// scatter, CFG+Euler, unary casts.  All are one-pass over their tensor: rows are held in registers
+// (16-B vector loads, wave64 shuffle reductions, one LDS hop across the 4 waves of a workgroup).
+#include "common.h"
+#include "more4d_hip.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 vectors per thread: C <= 256 * 4 * 8 = 8192
+
+template <int G> M4D_DEV float group_sum(float v, float* red) {
+    v = wave_sum(v);
+    if constexpr (G == 256) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        v = red[0] + red[1] + red[2] + red[3];
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ LayerNorm + modulate
+struct LnArgs {
+    const void* x; void* out;
+    const float *shift, *scale, *ln_w, *ln_b, *g_ss, *g_gate;
+    int64_t rows, rows_per_sample, mod_stride, g_period, g_len;
+    int C; float eps;
+};
+
+// G = threads cooperating on one row (64: one wave per row, 4 rows per workgroup; 256: one row per workgroup)
+template <typename TI, typename TO, int G>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int sub = G == 64 ? (tid >> 6) : 0;
+    const int lt = G == 64 ? (tid & 63) : tid;
+    const int64_t row = (int64_t)blockIdx.x * (256 / G) + sub;
+    const bool active = row < p.rows;   // G==64: whole wave uniform; G==256: always true
+    const int C = p.C, nv = C >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+    const TI* xr = (const TI*)p.x + (active ? row : 0) * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lt + i * G;
+        if (c4 < nv) {
+            v[i] = load4(xr + c4 * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = group_sum<G>(s, red) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lt + i * G;
+        if (c4 < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(group_sum<G>(q, red) / C + p.eps);
+    if (!active) return;
+    const int64_t sample = row / p.rows_per_sample, l = row % p.rows_per_sample;
+    const float* sh = p.shift ? p.shift + sample * p.mod_stride : nullptr;
+    const float* sc = p.scale ? p.scale + sample * p.mod_stride : nullptr;
+    const float* gs = nullptr;
+    if (p.g_ss && l < p.g_len) gs = p.g_ss + (sample * p.g_period + l % p.g_period) * 2 * C;
+    TO* orow = (TO*)p.out + row * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lt + i * G;
+        if (c4 < nv) {
+            const int c = c4 * 4;
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd;
+            if (p.ln_w) { y = y * load4(p.ln_w + c) + load4(p.ln_b + c); }
+            if (sc) { y = y * (1.f + load4(sc + c)) + load4(sh + c); }
+            if (gs) {   // x * (1 + scale*gate) + shift*gate  (wan_transformer4d.py:781)
+                const f32x4 g = load4(p.g_gate + c);
+                y = y * (1.f + load4(gs + c) * g) + load4(gs + C + c) * g;
+            }
+            store4(orow + c, y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RMSNorm (+ RoPE)
+struct RmsArgs {
+    void* x[2]; const float* w[2];
+    const float *cos_t, *sin_t;
+    int64_t ld, rows, rows_per_sample, rope_len, pos_offset;
+    int C, head_dim; float eps;
+};
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int sub = G == 64 ? (tid >> 6) : 0;
+    const int lt = G == 64 ? (tid & 63) : tid;
+    const int64_t row = (int64_t)blockIdx.x * (256 / G) + sub;
+    const bool active = row < p.rows;
+    const int which = blockIdx.y;
+    const int C = p.C, nv = C >> 2;
+    T* xr = (T*)p.x[which] + (active ? row : 0) * p.ld;
+    const float* w = p.w[which];
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lt + i * G;
+        if (c4 < nv) {
+            v[i] = load4(xr + c4 * 4);
+            s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    }
+    const float inv = rsqrtf(group_sum<G>(s, red) / C + p.eps);
+    if (!active) return;
+    const int64_t l = row % p.rows_per_sample;
+    const bool rot = p.cos_t && l < p.rope_len;
+    const int half = p.head_dim >> 1;
+    const float* ct = rot ? p.cos_t + (p.pos_offset + l) * half : nullptr;
+    const float* st = rot ? p.sin_t + (p.pos_offset + l) * half : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lt + i * G;
+        if (c4 < nv) {
+            const int c = c4 * 4;
+            f32x4 y;
+            const f32x4 wv = load4(w + c);
+            // reference: (x * rsqrt(..)).to(x.dtype) * weight  (wan_transformer4d.py:391-394)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = round_through<T>(v[i][e] * inv) * wv[e];
+            if (rot) {
+                const int pi = (c % p.head_dim) >> 1;  // pair index inside the head; c is even, pairs (c,c+1),(c+2,c+3)
+                const f32x2 cs = *reinterpret_cast<const f32x2*>(ct + pi);
+                const f32x2 sn = *reinterpret_cast<const f32x2*>(st + pi);
+                const float a0 = y[0], b0 = y[1], a1 = y[2], b1 = y[3];
+                y[0] = a0 * cs[0] - b0 * sn[0];
+                y[1] = a0 * sn[0] + b0 * cs[0];
+                y[2] = a1 * cs[1] - b1 * sn[1];
+                y[3] = a1 * sn[1] + b1 * cs[1];
+            }
+            store4(xr + c, y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ patchify / unpatchify
+struct PatchArgs {
+    const void* src0; const void* src1; void* out;
+    int c0, c1, B, F, H, W, pt, ph, pw;
+};
+
+// one thread per output element group of pw (contiguous in both source row and output K index)
+template <typename TS, typename TO>
+__global__ __launch_bounds__(256) void patchify_kernel(PatchArgs p) {
+    const int f = p.F / p.pt, h = p.H / p.ph, w = p.W / p.pw;
+    const int Ctot = p.c0 + p.c1;
+    const int Kdim = Ctot * p.pt * p.ph * p.pw;
+    const int64_t total = (int64_t)p.B * f * h * w * Kdim;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = idx;
+        const int kq = (int)(r % p.pw); r /= p.pw;
+        const int kp = (int)(r % p.ph); r /= p.ph;
+        const int kt = (int)(r % p.pt); r /= p.pt;
+        const int c = (int)(r % Ctot); r /= Ctot;
+        const int ww = (int)(r % w); r /= w;
+        const int hh = (int)(r % h); r /= h;
+        const int ff = (int)(r % f); r /= f;
+        const int b = (int)r;
+        const TS* src; int cc, cn;
+        if (c < p.c0) { src = (const TS*)p.src0; cc = c; cn = p.c0; }
+        else { src = (const TS*)p.src1; cc = c - p.c0; cn = p.c1; }
+        const int64_t si = ((((int64_t)b * cn + cc) * p.F + (ff * p.pt + kt)) * p.H + (hh * p.ph + kp)) * p.W + (ww * p.pw + kq);
+        ((TO*)p.out)[idx] = (TO)(float)src[si];
+    }
+}
+
+struct UnpatchArgs {
+    const float* tok; void* out;
+    int64_t tok_bs, tok_row0;
+    int B, c, F, H, W, pt, ph, pw;
+};
+
+template <typename TO>
+__global__ __launch_bounds__(256) void unpatchify_kernel(UnpatchArgs p) {
+    // out[b, ch, f*pt+kt, h*ph+kp, w*pw+kq] = tok[b, row0 + (f,h,w), ((kt*ph+kp)*pw+kq)*c + ch]
+    const int Fo = p.F * p.pt, Ho = p.H * p.ph, Wo = p.W * p.pw;
+    const int64_t total = (int64_t)p.B * p.c * Fo * Ho * Wo;
+    const int vec = p.pt * p.ph * p.pw * p.c;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = idx;
+        const int x = (int)(r % Wo); r /= Wo;
+        const int y = (int)(r % Ho); r /= Ho;
+        const int z = (int)(r % Fo); r /= Fo;
+        const int ch = (int)(r % p.c); r /= p.c;
+        const int b = (int)r;
+        const int f = z / p.pt, kt = z % p.pt, h = y / p.ph, kp = y % p.ph, w = x / p.pw, kq = x % p.pw;
+        const int64_t trow = p.tok_row0 + ((int64_t)f * p.H + h) * p.W + w;
+        const float v = p.tok[b * p.tok_bs + trow * vec + ((kt * p.ph + kp) * p.pw + kq) * p.c + ch];
+        ((TO*)p.out)[idx] = (TO)v;
+    }
+}
+
+// ------------------------------------------------------------------ CFG + Euler
+template <typename TV, typename TR>
+__global__ __launch_bounds__(256) void cfg_euler_kernel(float* x, const TV* v, int64_t n, float g, float ds) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 vu = load4(v + i * 4), vc = load4(v + n + i * 4);
+        f32x4 xv = load4(x + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // noise_pred computed in the model dtype (pipeline :820-822), step in fp32 (:760), cast back (:789)
+            const float np_ = round_through<TV>(vu[e] + g * (vc[e] - vu[e]));
+            xv[e] = round_through<TR>(xv[e] + ds * np_);
+        }
+        store4(x + i * 4, xv);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void unary_kernel(const TI* x, TO* out, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = (float)x[i];
+        if (act == 1) v = silu_f(v);
+        else if (act == 2) v = gelu_tanh_f(v);
+        out[i] = (TO)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_bcast_kernel(const float* a, const float* bias, float* out, int64_t total, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + bias[i % n];
+}
+
+inline unsigned grid_for(int64_t n, int per_block = 256) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > 2048 * 4) g = 2048 * 4;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, void* out, int64_t rows, int C,
+                               int64_t rows_per_sample, const float* shift, const float* scale, int64_t mod_stride,
+                               const float* ln_w, const float* ln_b, float eps, const float* g_ss,
+                               const float* g_gate, int64_t g_period, int64_t g_len, m4d_stream stream) {
+    M4D_CHECK_ARG(x && out && rows > 0, "ln_modulate: null/empty");
+    M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 256 * 4 * MAXV, "ln_modulate: C=%d must be a multiple of 4 and <= 8192", C);
+    M4D_CHECK_ARG((shift == nullptr) == (scale == nullptr), "ln_modulate: shift and scale must both be set or both NULL");
+    M4D_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "ln_modulate: ln_w and ln_b must both be set or both NULL");
+    M4D_CHECK_ARG(g_ss == nullptr || (g_gate && g_period > 0), "ln_modulate: guidance needs gate and period");
+    LnArgs p;
+    p.x = x; p.out = out; p.shift = shift; p.scale = scale; p.ln_w = ln_w; p.ln_b = ln_b; p.g_ss = g_ss; p.g_gate = g_gate;
+    p.rows = rows; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows; p.mod_stride = mod_stride;
+    p.g_period = g_period > 0 ? g_period : 1; p.g_len = g_len; p.C = C; p.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = C <= 64 * 4 * MAXV;  // one wave per row
+    dim3 block(256), grid((unsigned)(small ? (rows + 3) / 4 : rows));
+#define LN_LAUNCH(TI, TO)                                                                             \
+    do {                                                                                              \
+        if (small) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 64>), grid, block, 0, st, p);       \
+        else hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 256>), grid, block, 0, st, p);            \
+    } while (0)
+    if (x_dt == M4D_F32 && out_dt == M4D_F32) LN_LAUNCH(float, float);
+    else if (x_dt == M4D_F32 && out_dt == M4D_BF16) LN_LAUNCH(float, bf16_t);
+    else if (x_dt == M4D_BF16 && out_dt == M4D_BF16) LN_LAUNCH(bf16_t, bf16_t);
+    else if (x_dt == M4D_BF16 && out_dt == M4D_F32) LN_LAUNCH(bf16_t, float);
+    else { m4d_set_error("ln_modulate: bad dtypes"); return -1; }
+#undef LN_LAUNCH
+    M4D_CHECK_LAUNCH("ln_modulate");
+    return 0;
+}
+
+extern "C" int m4d_rmsnorm_rope(m4d_dtype dt, void* x0, void* x1, int64_t ld, const float* w0, const float* w1,
+                                int64_t rows, int C, int head_dim, float eps, const float* cos_t, const float* sin_t,
+                                int64_t rows_per_sample, int64_t rope_len, int64_t pos_offset, m4d_stream stream) {
+    M4D_CHECK_ARG(x0 && w0 && rows > 0, "rmsnorm_rope: null/empty");
+    M4D_CHECK_ARG(x1 == nullptr || w1 != nullptr, "rmsnorm_rope: x1 without w1");
+    M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 256 * 4 * MAXV, "rmsnorm_rope: C=%d must be a multiple of 4 and <= 8192", C);
+    M4D_CHECK_ARG(head_dim > 0 && head_dim % 4 == 0 && C % head_dim == 0, "rmsnorm_rope: head_dim=%d must divide C and be a multiple of 4", head_dim);
+    M4D_CHECK_ARG((cos_t == nullptr) == (sin_t == nullptr), "rmsnorm_rope: cos and sin must both be set or both NULL");
+    M4D_CHECK_ARG(ld % 4 == 0 && ld >= C, "rmsnorm_rope: bad ld");
+    RmsArgs p;
+    p.x[0] = x0; p.x[1] = x1; p.w[0] = w0; p.w[1] = w1; p.cos_t = cos_t; p.sin_t = sin_t;
+    p.ld = ld; p.rows = rows; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows;
+    p.rope_len = rope_len; p.pos_offset = pos_offset; p.C = C; p.head_dim = head_dim; p.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = C <= 64 * 4 * MAXV;
+    dim3 block(256), grid((unsigned)(small ? (rows + 3) / 4 : rows), x1 ? 2 : 1);
+    if (dt == M4D_BF16) {
+        if (small) hipLaunchKernelGGL((rmsnorm_rope_kernel<bf16_t, 64>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((rmsnorm_rope_kernel<bf16_t, 256>), grid, block, 0, st, p);
+    } else if (dt == M4D_F32) {
+        if (small) hipLaunchKernelGGL((rmsnorm_rope_kernel<float, 64>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((rmsnorm_rope_kernel<float, 256>), grid, block, 0, st, p);
+    } else { m4d_set_error("rmsnorm_rope: bad dtype"); return -1; }
+    M4D_CHECK_LAUNCH("rmsnorm_rope");
+    return 0;
+}
+
+extern "C" int m4d_patchify(m4d_dtype src_dt, const void* src0, int c0, const void* src1, int c1, m4d_dtype out_dt,
+                            void* out, int B, int F, int H, int W, int pt, int ph, int pw, m4d_stream stream) {
+    M4D_CHECK_ARG(src0 && out && c0 > 0 && c1 >= 0 && (c1 == 0 || src1), "patchify: null/empty");
+    M4D_CHECK_ARG(pt > 0 && ph > 0 && pw > 0 && F % pt == 0 && H % ph == 0 && W % pw == 0, "patchify: grid %dx%dx%d not divisible by patch %dx%dx%d", F, H, W, pt, ph, pw);
+    PatchArgs p{src0, src1, out, c0, c1, B, F, H, W, pt, ph, pw};
+    const int64_t total = (int64_t)B * F * H * W * (c0 + c1);
+    dim3 block(256), grid(grid_for(total));
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dt == M4D_F32 && out_dt == M4D_F32) hipLaunchKernelGGL((patchify_kernel<float, float>), grid, block, 0, st, p);
+    else if (src_dt == M4D_F32 && out_dt == M4D_BF16) hipLaunchKernelGGL((patchify_kernel<float, bf16_t>), grid, block, 0, st, p);
+    else if (src_dt == M4D_BF16 && out_dt == M4D_BF16) hipLaunchKernelGGL((patchify_kernel<bf16_t, bf16_t>), grid, block, 0, st, p);
+    else if (src_dt == M4D_BF16 && out_dt == M4D_F32) hipLaunchKernelGGL((patchify_kernel<bf16_t, float>), grid, block, 0, st, p);
+    else { m4d_set_error("patchify: bad dtypes"); return -1; }
+    M4D_CHECK_LAUNCH("patchify");
+    return 0;
+}
+
+extern "C" int m4d_unpatchify(const float* tok, int64_t tok_bs, int64_t tok_row0, m4d_dtype out_dt, void* out, int B,
+                              int c, int F, int H, int W, int pt, int ph, int pw, m4d_stream stream) {
+    M4D_CHECK_ARG(tok && out && B > 0 && c > 0 && F > 0 && H > 0 && W > 0, "unpatchify: null/empty");
+    UnpatchArgs p{tok, out, tok_bs, tok_row0, B, c, F, H, W, pt, ph, pw};
+    const int64_t total = (int64_t)B * c * F * pt * H * ph * W * pw;
+    dim3 block(256), grid(grid_for(total));
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dt == M4D_F32) hipLaunchKernelGGL((unpatchify_kernel<float>), grid, block, 0, st, p);
+    else if (out_dt == M4D_BF16) hipLaunchKernelGGL((unpatchify_kernel<bf16_t>), grid, block, 0, st, p);
+    else { m4d_set_error("unpatchify: bad dtype"); return -1; }
+    M4D_CHECK_LAUNCH("unpatchify");
+    return 0;
+}
+
+extern "C" int m4d_cfg_euler(float* x, m4d_dtype v_dt, const void* v, int64_t n, float guidance, float dsigma,
+                             m4d_dtype round_dt, m4d_stream stream) {
+    M4D_CHECK_ARG(x && v && n > 0 && n % 4 == 0, "cfg_euler: n must be a positive multiple of 4");
+    dim3 block(256), grid(grid_for(n / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (v_dt == M4D_F32 && round_dt == M4D_F32) hipLaunchKernelGGL((cfg_euler_kernel<float, float>), grid, block, 0, st, x, (const float*)v, n, guidance, dsigma);
+    else if (v_dt == M4D_BF16 && round_dt == M4D_BF16) hipLaunchKernelGGL((cfg_euler_kernel<bf16_t, bf16_t>), grid, block, 0, st, x, (const bf16_t*)v, n, guidance, dsigma);
+    else if (v_dt == M4D_BF16 && round_dt == M4D_F32) hipLaunchKernelGGL((cfg_euler_kernel<bf16_t, float>), grid, block, 0, st, x, (const bf16_t*)v, n, guidance, dsigma);
+    else if (v_dt == M4D_F32 && round_dt == M4D_BF16) hipLaunchKernelGGL((cfg_euler_kernel<float, bf16_t>), grid, block, 0, st, x, (const float*)v, n, guidance, dsigma);
+    else { m4d_set_error("cfg_euler: bad dtypes"); return -1; }
+    M4D_CHECK_LAUNCH("cfg_euler");
+    return 0;
+}
+
+extern "C" int m4d_unary(m4d_dtype in_dt, const void* x, m4d_dtype out_dt, void* out, int64_t n, int act,
+                         m4d_stream stream) {
+    M4D_CHECK_ARG(x && out && n > 0, "unary: null/empty");
+    M4D_CHECK_ARG(act >= 0 && act <= 2, "unary: bad act %d", act);
+    dim3 block(256), grid(grid_for(n));
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dt == M4D_F32 && out_dt == M4D_F32) hipLaunchKernelGGL((unary_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)out, n, act);
+    else if (in_dt == M4D_F32 && out_dt == M4D_BF16) hipLaunchKernelGGL((unary_kernel<float, bf16_t>), grid, block, 0, st, (const float*)x, (bf16_t*)out, n, act);
+    else if (in_dt == M4D_BF16 && out_dt == M4D_BF16) hipLaunchKernelGGL((unary_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)out, n, act);
+    else if (in_dt == M4D_BF16 && out_dt == M4D_F32) hipLaunchKernelGGL((unary_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, (float*)out, n, act);
+    else { m4d_set_error("unary: bad dtypes"); return -1; }
+    M4D_CHECK_LAUNCH("unary");
+    return 0;
+}
+
+extern "C" int m4d_add_bcast(const float* a, const float* bias, float* out, int64_t B, int64_t n, m4d_stream stream) {
+    M4D_CHECK_ARG(a && bias && out && B > 0 && n > 0, "add_bcast: null/empty");
+    dim3 block(256), grid(grid_for(B * n));
+    hipLaunchKernelGGL(add_bcast_kernel, grid, block, 0, (hipStream_t)stream, a, bias, out, B * n, n);
+    M4D_CHECK_LAUNCH("add_bcast");
+    return 0;
+}

@@ -1,0 +1,66 @@
+"""Sequence-parallel ("T-sharded") group for the denoise loop — built from scratch: the reference imports
+`MoRe4D.dist` (get_sequence_parallel_rank/world_size, get_sp_group, usp_attn_forward,
+xFuserLongContextAttention; wan_transformer4d.py:23-25) but ships no such package.
+
+Design for MI355X: one process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI).  Tokens are
+f-major, so a contiguous split of the token axis is a split along T (reference intent, :1187-1198).  Every
+op but self-attention is token-local; per layer each rank all-gathers K [B, Ls, C] and V^T [C, B*Ls] and hands
+the attention kernel one K/V *segment per rank* (no concat copy).  The final head output is all-gathered
+along tokens (:1320-1321).
+"""
+import torch
+import torch.distributed as dist
+
+from ..ops import KV
+
+_SP_GROUP = None
+
+
+class SequenceParallelGroup:
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_gather(self, x, dim=1):
+        """Concatenate equal-sized shards along `dim` (reference get_sp_group().all_gather, :1321)."""
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(self.world_size)]
+        dist.all_gather(parts, x, group=self.group)
+        return torch.cat(parts, dim=dim)
+
+    def gather_kv(self, k, vt, B, Ls, C, key_len):
+        """k: T [B*Ls, C] (this rank's keys after RMSNorm+RoPE), vt: T [C, B*Ls].  Returns one KV segment per
+        rank; segment r covers global tokens [r*Ls, (r+1)*Ls) of each sample, of which
+        clamp(key_len - r*Ls, 0, Ls) are valid keys."""
+        W = self.world_size
+        kg = torch.empty((W,) + tuple(k.shape), device=k.device, dtype=k.dtype)
+        vg = torch.empty((W,) + tuple(vt.shape), device=vt.device, dtype=vt.dtype)
+        dist.all_gather(list(kg.unbind(0)), k.contiguous(), group=self.group)
+        dist.all_gather(list(vg.unbind(0)), vt.contiguous(), group=self.group)
+        segs = []
+        for r in range(W):
+            n = max(0, min(Ls, key_len - r * Ls))
+            segs.append(KV(kg[r].view(-1), vg[r], Ls * C, C, Ls, B * Ls, n))
+        return segs
+
+
+def init_sequence_parallel(group=None):
+    """Make `group` (default: WORLD) the sequence-parallel group.  torch.distributed must be initialised."""
+    global _SP_GROUP
+    _SP_GROUP = SequenceParallelGroup(group)
+    return _SP_GROUP
+
+
+def get_sp_group():
+    if _SP_GROUP is None:
+        raise RuntimeError("sequence parallelism is not initialised: call more4d_amd.dist.init_sequence_parallel()")
+    return _SP_GROUP
+
+
+def get_sequence_parallel_world_size():
+    return 1 if _SP_GROUP is None else _SP_GROUP.world_size
+
+
+def get_sequence_parallel_rank():
+    return 0 if _SP_GROUP is None else _SP_GROUP.rank

@@ -1,0 +1,741 @@
+"""Wan2.1-DiT with MoRe4D spatial guidance — MI355X-native host side.
+
+Drop-in for the reference's `MoRe4D/models/wan_transformer4d.py` (same class names, ctor kwargs,
+forward kwargs, parameter names/shapes — SURVEY.md §8b, Appendix A), but every arithmetic op is a
+hand-written gfx950 kernel reached through the C ABI (`more4d_amd.ops` -> libmore4d_hip.so).  The
+nn.Linear / nn.Conv3d / nn.LayerNorm objects below are parameter CONTAINERS only (so checkpoints,
+`named_parameters()`, `.to(dtype)`, optimizers keep working); their torch forward is never called.
+
+Compute dtype T = the parameters' dtype: bfloat16 is the production path (bf16 MFMA operands, fp32
+accumulation, fp32 residual stream, casts where the reference's autocast places them — SURVEY.md
+Appendix C); float32 is the parity path (exact-fp32 MFMA), checked against the CPU oracle to 1e-3.
+
+Internal layout: tokens are rows of [B, Lp, C] buffers with Lp = seq_len rounded up to 8 (16-byte
+rows for V^T); rows >= seq_len are never used as keys.  V is produced TRANSPOSED by its projection
+GEMM (V^T [C, B*Lp]) because the attention kernel consumes V^T tiles (csrc/attention.hip).
+"""
+import math
+import types
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import EPI_GELU_ERF, EPI_GELU_TANH, EPI_RESID_GATE, EPI_SILU, EPI_STORE, EPI_STORE_F32, KV
+from ..utils.cfg_optimization import cfg_skip
+from .cache_utils import TeaCache
+
+__all__ = ["WanTransformer4DModel", "WanAttentionBlock", "WanSelfAttention", "WanI2VCrossAttention",
+           "WanT2VCrossAttention", "WanRMSNorm", "WanLayerNorm", "Head", "MLPProj", "SpatialGuidanceModule",
+           "sinusoidal_embedding_1d", "rope_params", "ContextCache"]
+
+
+def _round8(n):
+    return (n + 7) // 8 * 8
+
+
+def sinusoidal_embedding_1d(dim, position):
+    """float64 cat(cos, sin) table, computed on the host side of the boundary (reference :239-249)."""
+    assert dim % 2 == 0
+    half = dim // 2
+    pos = position.to(torch.float64)
+    inv = torch.pow(10000, -torch.arange(half, dtype=torch.float64, device=pos.device).div(half))
+    s = torch.outer(pos, inv)
+    return torch.cat([torch.cos(s), torch.sin(s)], dim=1)
+
+
+def rope_params(max_seq_len, dim, theta=10000):
+    """complex128 unit phasors [max_seq_len, dim/2] (reference :252-260)."""
+    assert dim % 2 == 0
+    ang = torch.outer(torch.arange(max_seq_len, dtype=torch.float64),
+                      1.0 / torch.pow(theta, torch.arange(0, dim, 2, dtype=torch.float64).div(dim)))
+    return torch.polar(torch.ones_like(ang), ang)
+
+
+def build_rope_tables(freqs, grid, head_dim, device):
+    """Per-token cos/sin float32 [f*h*w, head_dim/2] from the complex128 `freqs` attribute: the first
+    c-2(c//3) pairs rotate with the frame index, the next c//3 with the row, the last c//3 with the column
+    (reference rope_apply :346-361).  Built in float64 on the host, cast once."""
+    f, h, w = grid
+    c = head_dim // 2
+    fr = freqs.cpu().split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    z = torch.cat([fr[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1),
+                   fr[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                   fr[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, -1)
+    return (z.real.to(torch.float32).contiguous().to(device), z.imag.to(torch.float32).contiguous().to(device))
+
+
+def _f32(p, cache):
+    """float32 view/copy of a (possibly bf16) parameter, cached per (storage, version)."""
+    if p.dtype == torch.float32:
+        return p.detach()
+    key = (p.data_ptr(), p._version, tuple(p.shape))
+    hit = cache.get(id(p))
+    if hit is None or hit[0] != key:
+        hit = (key, p.detach().float().contiguous())
+        cache[id(p)] = hit
+    return hit[1]
+
+
+class WanRMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class WanLayerNorm(nn.LayerNorm):
+    def __init__(self, dim, eps=1e-6, elementwise_affine=False):
+        super().__init__(dim, elementwise_affine=elementwise_affine, eps=eps)
+
+
+class _Ctx:
+    """Per-forward shared state handed to the blocks: shapes, rope tables, guidance tables, SP group."""
+
+    def __init__(self, B, L, Lp, grid, cos, sin, rope_len, f32cache, key_len, sp=None, pos_offset=0):
+        self.B, self.L, self.Lp, self.grid = B, L, Lp, grid
+        self.cos, self.sin, self.rope_len = cos, sin, rope_len
+        self.f32cache = f32cache
+        self.key_len = key_len          # valid keys in the full (unsharded) sequence
+        self.sp = sp                    # sequence-parallel group wrapper or None
+        self.pos_offset = pos_offset    # first global token index of this rank's shard
+        self.guid = None                # (g_ss_self[layer], g_ss_ffn[layer], period, len) when guidance is on
+
+
+class WanSelfAttention(nn.Module):
+    def __init__(self, dim, num_heads, window_size=(-1, -1), qk_norm=True, eps=1e-6):
+        assert dim % num_heads == 0
+        super().__init__()
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.window_size, self.qk_norm, self.eps = window_size, qk_norm, eps
+        self.q = nn.Linear(dim, dim)
+        self.k = nn.Linear(dim, dim)
+        self.v = nn.Linear(dim, dim)
+        self.o = nn.Linear(dim, dim)
+        self.norm_q = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
+        self.norm_k = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
+
+    def _ones(self, ref):
+        return torch.ones(self.dim, device=ref.device, dtype=torch.float32)
+
+    def run(self, xn, xres, gate, gate_stride, c: _Ctx):
+        """xn: T [B, Lp, C] modulated input; accumulates o-proj * gate into xres (float32) in place."""
+        B, Lp, C = xn.shape
+        n, d = self.num_heads, self.head_dim
+        q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
+        k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
+        vt = ops.gemm_bt(self.v.weight, xn, self.v.bias, bias_on_m=True)          # V^T [C, B*Lp]
+        if self.qk_norm:
+            wq, wk = _f32(self.norm_q.weight, c.f32cache), _f32(self.norm_k.weight, c.f32cache)
+            ops.rmsnorm_rope(q, wq, k, wk, head_dim=d, eps=self.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp,
+                             rope_len=c.rope_len, pos_offset=c.pos_offset)
+        else:  # no norm configured: rope only is not a reference configuration for Wan checkpoints
+            raise NotImplementedError("qk_norm=False is not supported by the fused rmsnorm+rope kernel")
+        if c.sp is None or c.sp.world_size == 1:
+            segs = [KV(k, vt, Lp * C, C, Lp, B * Lp, c.key_len)]
+        else:
+            segs = c.sp.gather_kv(k, vt, B, Lp, C, c.key_len)
+        o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
+        ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=gate,
+                    gate_stride=gate_stride, rows_per_sample=Lp)
+        return xres
+
+
+class ContextCache:
+    """Step-invariant tensors of one (prompt, CLIP) pair: embedded context and per-layer cross-attention
+    K / V^T (reference recomputes them in every block of every step, :528-531, :1175-1184)."""
+
+    def __init__(self):
+        self.txt = None      # T [B, Tp, C]
+        self.img = None      # T [B, Ip, C] or None
+        self.txt_len = 0
+        self.img_len = 0
+        self.layers = {}     # layer idx -> {"txt": KV, "img": KV}
+
+    def slice_batch(self, start):
+        """View of the samples [start:] (cfg_skip runs only the conditional half)."""
+        cc = ContextCache()
+        cc.txt = self.txt[start:]
+        cc.img = None if self.img is None else self.img[start:]
+        cc.txt_len, cc.img_len = self.txt_len, self.img_len
+        for layer, d in self.layers.items():
+            cc.layers[layer] = {
+                name: KV(kv.k[start * kv.k_bs:], kv.vt[:, start * kv.vt_bs:], kv.k_bs, kv.k_ls, kv.vt_bs, kv.vt_ls,
+                         kv.len) for name, kv in d.items()}
+        return cc
+
+
+class WanT2VCrossAttention(WanSelfAttention):
+    has_img = False
+
+    def _kv(self, c: _Ctx, cc: ContextCache, layer):
+        hit = cc.layers.get(layer)
+        if hit is not None:
+            return hit
+        d, C = self.head_dim, self.dim
+        out = {}
+
+        def project(src, valid, kl, vl, nw):
+            Bc, Sp, _ = src.shape
+            k = ops.gemm_bt(src, kl.weight, kl.bias)                      # [Bc*Sp, C]
+            if self.qk_norm:
+                ops.rmsnorm_rope(k, _f32(nw.weight, c.f32cache), head_dim=d, eps=self.eps)
+            vt = ops.gemm_bt(vl.weight, src, vl.bias, bias_on_m=True)     # V^T [C, Bc*Sp]
+            # k is stored flat ([rows, C]) so that slice_batch can offset rows; strides are explicit
+            return KV(k.view(-1), vt, Sp * C, C, Sp, Bc * Sp, valid)
+
+        out["txt"] = project(cc.txt, cc.txt_len, self.k, self.v, self.norm_k)
+        if self.has_img and cc.img is not None:
+            out["img"] = project(cc.img, cc.img_len, self.k_img, self.v_img, self.norm_k_img)
+        cc.layers[layer] = out
+        return out
+
+    def run(self, xn, xres, c: _Ctx, cc: ContextCache, layer):
+        B, Lp, C = xn.shape
+        n, d = self.num_heads, self.head_dim
+        kv = self._kv(c, cc, layer)
+        q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
+        if self.qk_norm:
+            ops.rmsnorm_rope(q, _f32(self.norm_q.weight, c.f32cache), head_dim=d, eps=self.eps)
+        o = ops.attention(q, [kv["txt"]], B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
+        if "img" in kv:  # x + img_x (:552)
+            ops.attention(q, [kv["img"]], B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C, out=o,
+                          accumulate=True)
+        ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=None,
+                    rows_per_sample=Lp)
+        return xres
+
+
+class WanI2VCrossAttention(WanT2VCrossAttention):
+    has_img = True
+
+    def __init__(self, dim, num_heads, window_size=(-1, -1), qk_norm=True, eps=1e-6):
+        super().__init__(dim, num_heads, window_size, qk_norm, eps)
+        self.k_img = nn.Linear(dim, dim)
+        self.v_img = nn.Linear(dim, dim)
+        self.norm_k_img = WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()
+
+
+class WanCrossAttention(WanT2VCrossAttention):
+    pass
+
+
+WAN_CROSSATTENTION_CLASSES = {
+    't2v_cross_attn': WanT2VCrossAttention,
+    'i2v_cross_attn': WanI2VCrossAttention,
+    'cross_attn': WanCrossAttention,
+}
+
+
+class SpatialGuidanceModule(nn.Module):
+    """Parameter container for the MoRe4D spatial guidance (reference :739-783).  The scale/shift table is
+    computed once per forward for one frame (the feature map is T-periodic, :1153) by `table()`; the
+    modulation itself is fused into the LayerNorm+modulate kernel."""
+
+    def __init__(self, dim, dino_feature_dim=768):
+        super().__init__()
+        self.dim = dim
+        self.spatial_guide = nn.Sequential(nn.SiLU(), nn.Linear(dino_feature_dim, dim * 2))
+        nn.init.zeros_(self.spatial_guide[-1].weight)
+        nn.init.zeros_(self.spatial_guide[-1].bias)
+        self.gate = nn.Parameter(torch.zeros(dim))
+
+    def table(self, feats_silu, f32cache):
+        """feats_silu: T [B, P, 768] (SiLU already applied) -> float32 [B, P, 2*dim] = (scale | shift)."""
+        lin = self.spatial_guide[1]
+        return ops.gemm_bt(feats_silu, lin.weight, lin.bias, epilogue=EPI_STORE_F32)
+
+
+class WanAttentionBlock(nn.Module):
+    def __init__(self, cross_attn_type, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True,
+                 cross_attn_norm=False, eps=1e-6, use_spatial_guidance=True):
+        super().__init__()
+        self.dim, self.ffn_dim, self.num_heads = dim, ffn_dim, num_heads
+        self.window_size, self.qk_norm, self.cross_attn_norm, self.eps = window_size, qk_norm, cross_attn_norm, eps
+        self.use_spatial_guidance = use_spatial_guidance
+        self.norm1 = WanLayerNorm(dim, eps)
+        self.self_attn = WanSelfAttention(dim, num_heads, window_size, qk_norm, eps)
+        self.norm3 = WanLayerNorm(dim, eps, elementwise_affine=True) if cross_attn_norm else nn.Identity()
+        self.cross_attn = WAN_CROSSATTENTION_CLASSES[cross_attn_type](dim, num_heads, (-1, -1), qk_norm, eps)
+        self.norm2 = WanLayerNorm(dim, eps)
+        self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate='tanh'), nn.Linear(ffn_dim, dim))
+        self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+        if use_spatial_guidance:
+            self.spatial_guidance_self = SpatialGuidanceModule(dim)
+            self.spatial_guidance_ffn = SpatialGuidanceModule(dim)
+        else:
+            self.spatial_guidance_self = None
+            self.spatial_guidance_ffn = None
+
+    def run(self, xres, e0, c: _Ctx, cc: ContextCache, layer, guid=None):
+        """xres: float32 [B, Lp, C] residual stream (updated in place); e0: float32 [B, 6, C]."""
+        B, Lp, C = xres.shape
+        T = self.ffn[0].weight.dtype
+        # e = modulation + e0 (:659): a [B,6,C] table, rows = shift1, scale1, gate1, shift2, scale2, gate2
+        e = ops.add_bcast(e0, _f32(self.modulation, c.f32cache))
+        st = 6 * C
+        g1 = dict(g_ss=None)
+        g2 = dict(g_ss=None)
+        if guid is not None and self.spatial_guidance_self is not None:
+            feats_silu, period, glen = guid
+            g1 = dict(g_ss=self.spatial_guidance_self.table(feats_silu, c.f32cache),
+                      g_gate=_f32(self.spatial_guidance_self.gate, c.f32cache), g_period=period, g_len=glen)
+            g2 = dict(g_ss=self.spatial_guidance_ffn.table(feats_silu, c.f32cache),
+                      g_gate=_f32(self.spatial_guidance_ffn.gate, c.f32cache), g_period=period, g_len=glen)
+        # self-attention (:662-669)
+        xn = ops.ln_modulate(xres, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=Lp, eps=self.eps,
+                             **g1)
+        self.self_attn.run(xn, xres, e[:, 2], st, c)
+        # cross-attention (:674)
+        if self.cross_attn_norm:
+            xn = ops.ln_modulate(xres, T, ln_w=_f32(self.norm3.weight, c.f32cache),
+                                 ln_b=_f32(self.norm3.bias, c.f32cache), eps=self.eps, out=xn)
+        else:
+            xn = ops.unary(xres, T, out=xn)
+        self.cross_attn.run(xn, xres, c, cc, layer)
+        # ffn (:677-684)
+        xn = ops.ln_modulate(xres, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=Lp, eps=self.eps,
+                             out=xn, **g2)
+        h = ops.gemm_bt(xn, self.ffn[0].weight, self.ffn[0].bias, epilogue=EPI_GELU_TANH)
+        ops.gemm_bt(h, self.ffn[2].weight, self.ffn[2].bias, out=xres, epilogue=EPI_RESID_GATE, gate=e[:, 5],
+                    gate_stride=st, rows_per_sample=Lp)
+        return xres
+
+
+    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, dtype=torch.float32, t=0,
+                dino_features=None, use_cls_token=False):
+        """Reference signature (:633-646) for callers that drive one block: x [B, L, C], e [B, 6, C],
+        grid_sizes [B, 3] (all samples share one grid), freqs complex [1024, d/2], context [B, 257+T, C]
+        (already embedded; i2v layout: 257 CLIP tokens first, :522-523).  Returns float32 [B, L, C]."""
+        B, L, C = x.shape
+        dev = self.modulation.device
+        T = self.ffn[0].weight.dtype
+        grid = tuple(int(v) for v in (grid_sizes[0].tolist() if hasattr(grid_sizes, "tolist") else grid_sizes[0]))
+        Lp = _round8(L)
+        xres = torch.zeros((B, Lp, C), device=dev, dtype=torch.float32)
+        xres[:, :L] = x.to(dev)
+        cos, sin = build_rope_tables(freqs, grid, self.self_attn.head_dim, dev)
+        f32cache = self.__dict__.setdefault("_f32cache", {})
+        c = _Ctx(B, L, Lp, grid, cos, sin, min(L, grid[0] * grid[1] * grid[2]), f32cache, L)
+        cc = ContextCache()
+        context = context.to(dev)
+        n_img = 257 if isinstance(self.cross_attn, WanI2VCrossAttention) else 0
+
+        def padded(src):
+            S = src.shape[1]
+            out = torch.zeros((B, _round8(S), C), device=dev, dtype=T)
+            out[:, :S] = src
+            return out, S
+
+        if n_img:
+            cc.img, cc.img_len = padded(context[:, :n_img])
+        cc.txt, cc.txt_len = padded(context[:, n_img:])
+        guid = None
+        if dino_features is not None and dino_features[0] is not None and self.spatial_guidance_self is not None:
+            feats, cls = dino_features
+            src = cls.expand(-1, feats.shape[1], -1) if (use_cls_token and cls is not None) else feats
+            # the reference applies guidance per token over feats.shape[1] tokens (zero beyond, :772-776)
+            guid = (ops.unary(src.to(dev).contiguous(), T, act=1), feats.shape[1], feats.shape[1])
+        self.run(xres, e.to(device=dev, dtype=torch.float32).contiguous(), c, cc, 0, guid)
+        return xres[:, :L]
+
+
+class Head(nn.Module):
+    def __init__(self, dim, out_dim, patch_size, eps=1e-6):
+        super().__init__()
+        self.dim, self.out_dim, self.patch_size, self.eps = dim, out_dim, patch_size, eps
+        out_dim = math.prod(patch_size) * out_dim
+        self.norm = WanLayerNorm(dim, eps)
+        self.head = nn.Linear(dim, out_dim)
+        self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
+
+    def run(self, xres, e, f32cache):
+        """xres float32 [B, Lp, C], e float32 [B, C] -> float32 [B, Lp, prod(patch)*out_dim] (:708-721)."""
+        B, Lp, C = xres.shape
+        T = self.head.weight.dtype
+        m = ops.add_bcast(e.view(B, 1, C).expand(B, 2, C).contiguous(), _f32(self.modulation, f32cache))
+        xn = ops.ln_modulate(xres, T, shift=m[:, 0], scale=m[:, 1], mod_stride=2 * C, rows_per_sample=Lp, eps=self.eps)
+        out = ops.gemm_bt(xn, self.head.weight, self.head.bias, epilogue=EPI_STORE_F32)
+        return out.view(B, Lp, -1)
+
+
+class MLPProj(nn.Module):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.proj = nn.Sequential(nn.LayerNorm(in_dim), nn.Linear(in_dim, in_dim), nn.GELU(),
+                                  nn.Linear(in_dim, out_dim), nn.LayerNorm(out_dim))
+
+    def run(self, clip_fea, T, f32cache):
+        """clip_fea [B, 257, in_dim] -> T [B, 264, out_dim] (rows 257.. are padding)."""
+        B, n, cin = clip_fea.shape
+        Ip = _round8(n)
+        src = torch.zeros((B, Ip, cin), device=clip_fea.device, dtype=T)
+        src[:, :n] = clip_fea
+        p = self.proj
+        x = ops.ln_modulate(src, T, ln_w=_f32(p[0].weight, f32cache), ln_b=_f32(p[0].bias, f32cache), eps=p[0].eps)
+        x = ops.gemm_bt(x, p[1].weight, p[1].bias, epilogue=EPI_GELU_ERF)
+        x = ops.gemm_bt(x, p[3].weight, p[3].bias)
+        x = ops.ln_modulate(x, T, ln_w=_f32(p[4].weight, f32cache), ln_b=_f32(p[4].bias, f32cache), eps=p[4].eps)
+        return x.view(B, Ip, -1), n
+
+
+class _Config(dict):
+    """`transformer.config.patch_size`, `.config.get("add_ref_conv")` (pipeline_wan_fun_control.py:703, 737)."""
+    __getattr__ = dict.__getitem__
+
+
+class WanTransformer4DModel(nn.Module):
+    r"""Wan diffusion backbone (t2v / i2v) with MoRe4D guidance hooks; MI355X-native forward."""
+
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, model_type='t2v', patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, window_size=(-1, -1),
+                 qk_norm=True, cross_attn_norm=True, eps=1e-6, in_channels=16, hidden_size=2048,
+                 add_control_adapter=False, in_dim_control_adapter=24, add_ref_conv=False, in_dim_ref_conv=16,
+                 cross_attn_type=None, use_dino_guidance=True, use_omnimae_guidance=False,
+                 use_depth_guidance=False, use_cls_token=False):
+        super().__init__()
+        self.config = _Config(
+            model_type=model_type, patch_size=patch_size, text_len=text_len, in_dim=in_dim, dim=dim, ffn_dim=ffn_dim,
+            freq_dim=freq_dim, text_dim=text_dim, out_dim=out_dim, num_heads=num_heads, num_layers=num_layers,
+            window_size=window_size, qk_norm=qk_norm, cross_attn_norm=cross_attn_norm, eps=eps,
+            in_channels=in_channels, hidden_size=hidden_size, add_control_adapter=add_control_adapter,
+            in_dim_control_adapter=in_dim_control_adapter, add_ref_conv=add_ref_conv,
+            in_dim_ref_conv=in_dim_ref_conv, cross_attn_type=cross_attn_type, use_dino_guidance=use_dino_guidance,
+            use_omnimae_guidance=use_omnimae_guidance, use_depth_guidance=use_depth_guidance,
+            use_cls_token=use_cls_token)
+        assert model_type in ['t2v', 'i2v', 'ti2v']
+        self.model_type = model_type
+        self.use_dino_guidance = use_dino_guidance
+        self.use_omnimae_guidance = use_omnimae_guidance
+        self.patch_size = tuple(patch_size)
+        self.text_len = text_len
+        self.in_dim = 48  # reference quirk: hard-coded (:866); the conv below uses the ctor value
+        self.use_cls_token = use_cls_token
+        self.dim, self.ffn_dim, self.freq_dim, self.text_dim = dim, ffn_dim, freq_dim, text_dim
+        self.out_dim, self.num_heads, self.num_layers = out_dim, num_heads, num_layers
+        self.window_size, self.qk_norm, self.cross_attn_norm, self.eps = window_size, qk_norm, cross_attn_norm, eps
+
+        if use_dino_guidance:
+            raise NotImplementedError("DINO guidance is not implemented")  # as in the reference (:881)
+        self.dino_dim = 768
+        if use_omnimae_guidance:
+            # The OmniMAE ViT-B extractor itself is outside the hot path: callers
+            # hand its [B,196,768] patch features in through `first_frame_features`; the adapter convs stay here
+            # so released checkpoints load.
+            self.feature_adapter = nn.Sequential(nn.Conv2d(self.dino_dim, self.dino_dim, 3, padding=1), nn.SiLU(),
+                                                 nn.Conv2d(self.dino_dim, self.dino_dim, 3, padding=1))
+        self.dino_extractor = None
+
+        self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=self.patch_size, stride=self.patch_size)
+        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate='tanh'), nn.Linear(dim, dim))
+        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
+        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
+
+        if cross_attn_type is None:
+            cross_attn_type = 't2v_cross_attn' if model_type == 't2v' else 'i2v_cross_attn'
+        self.blocks = nn.ModuleList([
+            WanAttentionBlock(cross_attn_type, dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps,
+                              use_spatial_guidance=(use_dino_guidance or use_omnimae_guidance))
+            for _ in range(num_layers)])
+        for layer_idx, block in enumerate(self.blocks):
+            block.self_attn.layer_idx = layer_idx
+            block.self_attn.num_layers = self.num_layers
+        self.head = Head(dim, out_dim, self.patch_size, eps)
+
+        assert (dim % num_heads) == 0 and (dim // num_heads) % 2 == 0
+        d = dim // num_heads
+        self.d = d
+        # plain attribute, not a buffer, as in the reference (:923-935)
+        with torch.device("cpu"):   # host-side table even when the module is built under a meta/device context
+            self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                                    rope_params(1024, 2 * (d // 6))], dim=1)
+        if model_type == 'i2v':
+            self.img_emb = MLPProj(1280, dim)
+        if add_control_adapter:
+            raise NotImplementedError("add_control_adapter: SimpleAdapter is undefined in the reference too (:941)")
+        self.control_adapter = None
+        self.ref_conv = nn.Conv2d(in_dim_ref_conv, dim, kernel_size=self.patch_size[1:],
+                                  stride=self.patch_size[1:]) if add_ref_conv else None
+
+        self.teacache = None
+        self.cfg_skip_ratio = None
+        self.current_steps = 0
+        self.num_inference_steps = None
+        self.gradient_checkpointing = False
+        self.sp_world_size = 1
+        self.sp_world_rank = 0
+        self._sp = None
+        self.mask_padding_keys = False   # False = the reference's SDPA branch (k_lens ignored, :222-226)
+        self._f32cache = {}
+        self._rope_cache = {}
+        self.init_weights()
+
+    # ------------------------------------------------------------------ reference API surface
+    @property
+    def dtype(self):
+        return self.patch_embedding.weight.dtype
+
+    @property
+    def device(self):
+        return self.patch_embedding.weight.device
+
+    def _set_gradient_checkpointing(self, *args, **kwargs):
+        if "value" in kwargs:
+            self.gradient_checkpointing = kwargs["value"]
+        elif "enable" in kwargs:
+            self.gradient_checkpointing = kwargs["enable"]
+        else:
+            raise ValueError("Invalid set gradient checkpointing")
+
+    def enable_gradient_checkpointing(self):
+        self.gradient_checkpointing = True
+
+    def enable_teacache(self, coefficients, num_steps: int, rel_l1_thresh: float, num_skip_start_steps: int = 0,
+                        offload: bool = True):
+        self.teacache = TeaCache(coefficients, num_steps, rel_l1_thresh=rel_l1_thresh,
+                                 num_skip_start_steps=num_skip_start_steps, offload=offload)
+
+    def share_teacache(self, transformer=None):
+        self.teacache = transformer.teacache
+
+    def disable_teacache(self):
+        self.teacache = None
+
+    def enable_cfg_skip(self, cfg_skip_ratio, num_steps):
+        if cfg_skip_ratio != 0:
+            self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = cfg_skip_ratio, 0, num_steps
+        else:
+            self.disable_cfg_skip()
+
+    def share_cfg_skip(self, transformer=None):
+        self.cfg_skip_ratio = transformer.cfg_skip_ratio
+        self.current_steps = transformer.current_steps
+        self.num_inference_steps = transformer.num_inference_steps
+
+    def disable_cfg_skip(self):
+        self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = None, 0, None
+
+    def enable_riflex(self, k=6, L_test=66, L_test_scale=4.886):
+        d = self.d
+        da = d - 4 * (d // 6)
+        inv = 1.0 / torch.pow(10000.0, torch.arange(0, da, 2, dtype=torch.float64).div(da))
+        inv[k - 1] = 0.9 * 2 * torch.pi / L_test          # RIFLEx intrinsic-frequency edit (reference :306-310)
+        if L_test_scale is not None:
+            inv[k - 1] = inv[k - 1] / L_test_scale
+        ang = torch.outer(torch.arange(1024, dtype=torch.float64), inv)
+        self.freqs = torch.cat([torch.polar(torch.ones_like(ang), ang), rope_params(1024, 2 * (d // 6)),
+                                rope_params(1024, 2 * (d // 6))], dim=1)
+        self._rope_cache.clear()
+
+    def disable_riflex(self):
+        d = self.d
+        self.freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                                rope_params(1024, 2 * (d // 6))], dim=1)
+        self._rope_cache.clear()
+
+    def enable_multi_gpus_inference(self):
+        """T-(token-)sharded denoising across the ranks of the sequence-parallel group (more4d_amd.dist)."""
+        from ..dist import get_sequence_parallel_rank, get_sequence_parallel_world_size, get_sp_group
+        self.sp_world_size = get_sequence_parallel_world_size()
+        self.sp_world_rank = get_sequence_parallel_rank()
+        self._sp = get_sp_group()
+        self.all_gather = self._sp.all_gather
+
+    # ------------------------------------------------------------------ host-side tables
+    def _rope_tables(self, grid, device):
+        key = (tuple(grid), str(device))
+        hit = self._rope_cache.get(key)
+        if hit is None:
+            hit = build_rope_tables(self.freqs, grid, self.d, device)
+            self._rope_cache[key] = hit
+        return hit
+
+    # ------------------------------------------------------------------ embeddings (step-invariant part)
+    def prepare_context(self, context, clip_fea=None) -> ContextCache:
+        """text_embedding / img_emb once per prompt (:1174-1184); per-layer K,V^T are filled lazily."""
+        T, dev = self.dtype, self.device
+        B = len(context)
+        cc = ContextCache()
+        Tp = _round8(self.text_len)
+        txt = torch.zeros((B, Tp, self.text_dim), device=dev, dtype=T)
+        for i, u in enumerate(context):
+            txt[i, :u.size(0)] = u.to(device=dev, dtype=T)
+        h = ops.gemm_bt(txt, self.text_embedding[0].weight, self.text_embedding[0].bias, epilogue=EPI_GELU_TANH)
+        cc.txt = ops.gemm_bt(h, self.text_embedding[2].weight, self.text_embedding[2].bias).view(B, Tp, self.dim)
+        cc.txt_len = self.text_len
+        if clip_fea is not None and self.model_type == 'i2v':
+            cc.img, cc.img_len = self.img_emb.run(clip_fea.to(device=dev), T, self._f32cache)
+        return cc
+
+    def _time_embed(self, t):
+        """e [B, C], e0 [B, 6, C] float32 (:1160-1171): fp32 GEMMs regardless of T."""
+        dev = self.device
+        s = sinusoidal_embedding_1d(self.freq_dim, t.to(dev)).float().contiguous()
+        fc = self._f32cache
+        te0, te2, tp = self.time_embedding[0], self.time_embedding[2], self.time_projection[1]
+        h = ops.gemm_bt(s, _f32(te0.weight, fc), _f32(te0.bias, fc), epilogue=EPI_SILU)
+        e = ops.gemm_bt(h, _f32(te2.weight, fc), _f32(te2.bias, fc))
+        e0 = ops.gemm_bt(ops.unary(e, torch.float32, act=1), _f32(tp.weight, fc), _f32(tp.bias, fc))
+        return e, e0.view(-1, 6, self.dim)
+
+    # ------------------------------------------------------------------ forward
+    @cfg_skip()
+    def forward(self, x, t, context, seq_len, clip_fea=None, y=None, y_camera=None, full_ref=None, subject_ref=None,
+                cond_flag=True, first_frame=None, first_frame_features=None):
+        """Same contract as the reference forward (:1047-1340).
+
+        x [B,16,F,H,W]; t [B]; context: list of [Li, text_dim] tensors OR a ContextCache from
+        `prepare_context`; clip_fea [B,257,1280]; y [B,48,F,H,W]; full_ref [B,16,H,W].
+        first_frame_features: optional (patch_feats [B,196,768], cls [B,768]) OmniMAE outputs for spatial
+        guidance (the ViT itself is out of scope; see ctor note).  Returns [B, out_dim, F, H, W] in T.
+        """
+        if y_camera is not None or subject_ref is not None:
+            raise NotImplementedError("y_camera / subject_ref are not part of the 4D-STraG path")
+        if t.dim() != 1:
+            raise NotImplementedError("per-token timesteps (ti2v) are not part of the 4D-STraG path")
+        if self.teacache is not None:
+            raise NotImplementedError("TeaCache step skipping is a 'next' row (SURVEY §8f rank 1), not built yet")
+        if first_frame is not None and self.use_omnimae_guidance and first_frame_features is None:
+            raise NotImplementedError("pass OmniMAE outputs via first_frame_features=(patch_feats, cls); the ViT-B "
+                                      "extractor is outside the hot path (SURVEY §8f rank 3)")
+        T, dev = self.dtype, self.device
+        B = x.shape[0]
+        x = x.to(dev)
+        if y is not None:
+            y = y.to(device=dev, dtype=x.dtype)
+        pt, ph, pw = self.patch_size
+        f, h, w = x.shape[2] // pt, x.shape[3] // ph, x.shape[4] // pw
+        Lv = f * h * w
+        n_ref = 0
+        grid = (f, h, w)
+        if self.ref_conv is not None and full_ref is not None:
+            n_ref = h * w
+            grid = (f + 1, h, w)
+            seq_len = seq_len + n_ref
+        L = Lv + n_ref
+        sp = self._sp if self.sp_world_size > 1 else None
+        # keys: the reference's SDPA branch attends the zero rows up to seq_len (:222-226); rows added only to
+        # make the sequence divisible by the SP world (:1100-1101) are masked so N ranks == 1 rank.
+        key_len = L if self.mask_padding_keys else seq_len
+        if sp is not None:
+            seq_len = int(math.ceil(seq_len / self.sp_world_size)) * self.sp_world_size
+        assert L <= seq_len, f"sequence of {L} tokens exceeds seq_len={seq_len}"
+        # ---- tokens: patch gather + GEMM straight into the fp32 residual stream
+        Lp = _round8(seq_len) if sp is None else _round8(seq_len // self.sp_world_size) * self.sp_world_size
+        xres = torch.zeros((B, Lp, self.dim), device=dev, dtype=torch.float32)
+        tok = ops.patchify(x, y, self.patch_size, T)
+        wpe = self.patch_embedding.weight.view(self.dim, -1)
+        for b in range(B):
+            ops.gemm_bt(tok[b], wpe, self.patch_embedding.bias, out=xres[b, n_ref:n_ref + Lv], epilogue=EPI_STORE_F32)
+        if n_ref:
+            rt = ops.patchify(full_ref.to(dev).unsqueeze(2), None, (1, ph, pw), T)
+            wr = self.ref_conv.weight.view(self.dim, -1)
+            for b in range(B):
+                ops.gemm_bt(rt[b], wr, self.ref_conv.bias, out=xres[b, :n_ref], epilogue=EPI_STORE_F32)
+        # ---- conditioning
+        e, e0 = self._time_embed(t)
+        cc = context if isinstance(context, ContextCache) else self.prepare_context(context, clip_fea)
+        cos, sin = self._rope_tables(grid, dev)
+        guid = None
+        if self.use_omnimae_guidance and first_frame_features is not None:
+            guid = self._guidance_tables(first_frame_features, (h, w), x.shape[2] // pt)
+        # ---- shard for sequence parallelism (token axis == f-major == T axis, reference :1187-1198)
+        pos_offset = 0
+        if sp is not None:
+            Ls = Lp // self.sp_world_size
+            pos_offset = self.sp_world_rank * Ls
+            xres = xres[:, pos_offset:pos_offset + Ls].contiguous()
+            c = _Ctx(B, L, Ls, grid, cos, sin, max(0, min(Ls, L - pos_offset)), self._f32cache, key_len, sp, pos_offset)
+        else:
+            c = _Ctx(B, L, Lp, grid, cos, sin, L, self._f32cache, key_len)
+        if guid is not None and sp is not None:
+            raise NotImplementedError("spatial guidance with sequence parallelism")
+        for i, block in enumerate(self.blocks):
+            block.run(xres, e0, c, cc, i, guid)
+        out = self.head.run(xres, e, self._f32cache)          # float32 [B, Lp or Ls, 64]
+        if sp is not None:
+            out = sp.all_gather(out, dim=1)
+        res = ops.unpatchify(out.contiguous(), n_ref, (f, h, w), self.patch_size, self.out_dim, T)
+        return res
+
+    def _guidance_tables(self, feats, hw, latent_T):
+        """OmniMAE patch features -> SiLU'd, adapter-convolved, resized [B, h*w, 768] table (reference
+        :1149-1156).  The 3x3 adapter convs + bilinear resize run once per forward on a 14x14 map; they are
+        built with the VAE conv kernels in a later round — until then guidance inference needs the caller to
+        pass features already adapted to (h, w)."""
+        patch, cls = feats
+        T = self.dtype
+        h, w = hw
+        if patch.dim() != 3 or patch.shape[1] != h * w or patch.shape[2] != self.dino_dim:
+            raise NotImplementedError("first_frame_features must be adapter outputs resized to [B, h*w, 768]")
+        src = cls.view(cls.shape[0], 1, -1).expand(-1, h * w, -1) if self.use_cls_token else patch
+        return ops.unary(src.to(self.device).contiguous(), T, act=1), h * w, latent_T * h * w
+
+    def unpatchify(self, x, grid_sizes):
+        """Reference-compatible helper (:1343-1366) for callers that hold head outputs: x list of [L, 64]."""
+        outs = []
+        for u, v in zip(x, grid_sizes.tolist() if hasattr(grid_sizes, "tolist") else grid_sizes):
+            tok = u[:math.prod(v)].float().contiguous().unsqueeze(0)
+            outs.append(ops.unpatchify(tok, 0, tuple(v), self.patch_size, self.out_dim, u.dtype)[0])
+        return outs
+
+    def init_weights(self):
+        """Same initialisation scheme as the reference (:1368-1390)."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        nn.init.xavier_uniform_(self.patch_embedding.weight.flatten(1))
+        for m in self.text_embedding.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=.02)
+        for m in self.time_embedding.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=.02)
+        nn.init.zeros_(self.head.head.weight)
+        for b in self.blocks:
+            for g in (b.spatial_guidance_self, b.spatial_guidance_ffn):
+                if g is not None:
+                    nn.init.zeros_(g.spatial_guide[-1].weight)
+                    nn.init.zeros_(g.spatial_guide[-1].bias)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={},
+                        low_cpu_mem_usage=False, torch_dtype=torch.bfloat16):
+        """Load a Wan / VideoX-Fun / MoRe4D checkpoint directory: config.json + *.safetensors shards
+        (reference :1392-1523).  Size-mismatched keys are skipped, like the reference does."""
+        import glob
+        import json
+        import os
+        if subfolder is not None:
+            pretrained_model_path = os.path.join(pretrained_model_path, subfolder)
+        config_file = os.path.join(pretrained_model_path, 'config.json')
+        if not os.path.isfile(config_file):
+            raise RuntimeError(f"{config_file} does not exist")
+        with open(config_file, "r") as fh:
+            config = json.load(fh)
+        import inspect
+        valid = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        kwargs = {k: v for k, v in {**config, **transformer_additional_kwargs}.items() if k in valid}
+        model = cls(**kwargs)
+        files = sorted(glob.glob(os.path.join(pretrained_model_path, "*.safetensors")))
+        state = {}
+        if files:
+            from safetensors.torch import load_file
+            for fpath in files:
+                state.update(load_file(fpath))
+        else:
+            bin_file = os.path.join(pretrained_model_path, "diffusion_pytorch_model.bin")
+            if not os.path.exists(bin_file):
+                raise RuntimeError(f"no weights found under {pretrained_model_path}")
+            state = torch.load(bin_file, map_location="cpu", weights_only=True)
+        own = model.state_dict()
+        filtered = {k: v for k, v in state.items() if k in own and own[k].shape == v.shape}
+        skipped = [k for k in state if k not in filtered]
+        m, u = model.load_state_dict(filtered, strict=False)
+        print(f"### missing keys: {len(m)}; ### unexpected/size-mismatched keys skipped: {len(skipped)}")
+        return model.to(torch_dtype)

@@ -1,0 +1,241 @@
+"""Tensor-level wrappers over the C ABI (include/more4d_hip.h).  torch supplies device memory and the
+current HIP stream; every arithmetic op below runs in a hand-written gfx950 kernel.  No fallback."""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_GELU_ERF, EPI_GELU_TANH, EPI_RESID_GATE, EPI_SILU, EPI_STORE, EPI_STORE_F32,  # noqa: F401
+                   KvSegs, check)
+
+_DT = {torch.float32: _lib.M4D_F32, torch.bfloat16: _lib.M4D_BF16}
+
+
+def dt_code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"more4d_amd kernels support float32 and bfloat16, got {dtype}") from None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.More4DHipError("more4d_amd kernels need tensors on the HIP device (got a CPU tensor); "
+                                      "there is no CPU path")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _rows2d(t):
+    """(rows, row stride) of a tensor viewed as [rows, last]; last dim must be contiguous."""
+    if t.stride(-1) != 1:
+        raise ValueError("last dimension must be contiguous")
+    if t.dim() == 1:
+        return 1, t.shape[0]
+    if t.dim() == 2:
+        return t.shape[0], t.stride(0)
+    # leading dims must collapse onto the row stride
+    ld = t.stride(-2)
+    rows = t.shape[-2]
+    for d in range(t.dim() - 3, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != rows * ld:
+            raise ValueError(f"tensor of shape {tuple(t.shape)} / strides {t.stride()} is not a strided 2-D matrix")
+        rows *= t.shape[d]
+    return rows, ld
+
+
+def gemm_bt(a, w, bias=None, *, out=None, epilogue=EPI_STORE, gate=None, gate_stride=0, rows_per_sample=0,
+            bias_on_m=False, out_rows_ld=None):
+    """out = epilogue(a @ w^T + bias).  a [M,K] (row-strided), w [N,K] (row-strided).
+    EPI_RESID_GATE / EPI_STORE_F32 write float32 `out`; others write a.dtype."""
+    _dev(a, w, bias, out, gate)
+    if a.dtype != w.dtype:
+        raise TypeError(f"gemm_bt: A {a.dtype} vs W {w.dtype}")
+    M, lda = _rows2d(a)
+    N, ldw = _rows2d(w)
+    K = a.shape[-1]
+    if w.shape[-1] != K:
+        raise ValueError(f"gemm_bt: K mismatch {K} vs {w.shape[-1]}")
+    f32_out = epilogue in (EPI_RESID_GATE, EPI_STORE_F32)
+    if out is None:
+        if epilogue == EPI_RESID_GATE:
+            raise ValueError("gemm_bt: EPI_RESID_GATE needs the residual tensor as `out`")
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if f32_out else a.dtype)
+    want = torch.float32 if f32_out else a.dtype
+    if out.dtype != want:
+        raise TypeError(f"gemm_bt: out dtype {out.dtype}, expected {want}")
+    om, ldc = _rows2d(out)
+    if om != M or out.shape[-1] != N:
+        raise ValueError(f"gemm_bt: out shape {tuple(out.shape)} vs M={M} N={N}")
+    if bias is not None and (bias.dtype != a.dtype or bias.numel() != (M if bias_on_m else N)):
+        raise ValueError("gemm_bt: bias must have A's dtype and N (or M) elements")
+    if gate is not None and gate.dtype != torch.float32:
+        raise TypeError("gemm_bt: gate must be float32")
+    lib = _lib.load()
+    check(lib.m4d_gemm_bt(dt_code(a.dtype), _ptr(a), lda, _ptr(w), ldw, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
+                          M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _stream()), "m4d_gemm_bt")
+    return out
+
+
+def ln_modulate(x, out_dtype, *, shift=None, scale=None, mod_stride=0, rows_per_sample=0, ln_w=None, ln_b=None,
+                eps=1e-6, g_ss=None, g_gate=None, g_period=0, g_len=0, out=None):
+    """LayerNorm over the last dim (+affine) (+modulate) (+spatial guidance) -> out_dtype, same shape."""
+    _dev(x, shift, scale, ln_w, ln_b, g_ss, g_gate, out)
+    if not x.is_contiguous():
+        raise ValueError("ln_modulate: x must be contiguous")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    for t in (shift, scale, ln_w, ln_b, g_ss, g_gate):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("ln_modulate: modulation / affine / guidance tensors must be float32")
+    lib = _lib.load()
+    check(lib.m4d_ln_modulate(dt_code(x.dtype), _ptr(x), dt_code(out.dtype), _ptr(out), rows, C, rows_per_sample,
+                              _ptr(shift), _ptr(scale), mod_stride, _ptr(ln_w), _ptr(ln_b), eps, _ptr(g_ss),
+                              _ptr(g_gate), g_period, g_len, _stream()), "m4d_ln_modulate")
+    return out
+
+
+def rmsnorm_rope(x0, w0, x1=None, w1=None, *, head_dim, eps=1e-6, cos=None, sin=None, rows_per_sample=0,
+                 rope_len=0, pos_offset=0):
+    """In-place RMSNorm over the last dim (+RoPE) on x0 (and x1)."""
+    _dev(x0, x1, w0, w1, cos, sin)
+    rows, ld = _rows2d(x0)
+    C = x0.shape[-1]
+    if x1 is not None:
+        r1, ld1 = _rows2d(x1)
+        if r1 != rows or ld1 != ld or x1.dtype != x0.dtype or x1.shape[-1] != C:
+            raise ValueError("rmsnorm_rope: x0/x1 layout mismatch")
+    for t in (w0, w1, cos, sin):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise TypeError("rmsnorm_rope: weights and rope tables must be contiguous float32")
+    if cos is not None and cos.shape[-1] != head_dim // 2:
+        raise ValueError("rmsnorm_rope: rope table must have head_dim/2 columns")
+    if cos is not None and pos_offset + min(rope_len, rows_per_sample or rows) > cos.shape[0]:
+        raise ValueError("rmsnorm_rope: rope table too short")
+    lib = _lib.load()
+    check(lib.m4d_rmsnorm_rope(dt_code(x0.dtype), _ptr(x0), _ptr(x1), ld, _ptr(w0), _ptr(w1), rows, C, head_dim, eps,
+                               _ptr(cos), _ptr(sin), rows_per_sample, rope_len, pos_offset, _stream()),
+          "m4d_rmsnorm_rope")
+    return x0, x1
+
+
+class KV:
+    """One K/V segment for `attention`: k [B, Lk, C] (token rows strided), vt = V^T [C, >=...] with the keys of
+    batch b starting at column b*vt_bs."""
+    __slots__ = ("k", "vt", "k_bs", "k_ls", "vt_bs", "vt_ls", "len")
+
+    def __init__(self, k, vt, k_bs, k_ls, vt_bs, vt_ls, length):
+        self.k, self.vt, self.k_bs, self.k_ls, self.vt_bs, self.vt_ls, self.len = k, vt, k_bs, k_ls, vt_bs, vt_ls, length
+
+
+def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None):
+    """softmax(q k^T * scale) v over the concatenation of `segs` (list of KV).  q/out: [B, Lq, heads*head_dim]."""
+    _dev(q, out, *[s.k for s in segs], *[s.vt for s in segs])
+    C = heads * head_dim
+    if q_ls is None:
+        q_ls = q.stride(-2)
+    if q_bs is None:
+        q_bs = q.stride(0) if q.dim() == 3 else Lq * q_ls
+    if out is None:
+        out = torch.empty((B, Lq, C), device=q.device, dtype=q.dtype)
+    if not 1 <= len(segs) <= _lib.MAX_KV_SEGS:
+        raise ValueError(f"attention: 1..{_lib.MAX_KV_SEGS} KV segments, got {len(segs)}")
+    kv = KvSegs()
+    kv.nseg = len(segs)
+    for i, s in enumerate(segs):
+        if s.k.dtype != q.dtype or s.vt.dtype != q.dtype:
+            raise TypeError("attention: q/k/v dtype mismatch")
+        kv.k[i], kv.vt[i] = s.k.data_ptr(), s.vt.data_ptr()
+        kv.k_bs[i], kv.k_ls[i], kv.vt_bs[i], kv.vt_ls[i], kv.len[i] = s.k_bs, s.k_ls, s.vt_bs, s.vt_ls, s.len
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    lib = _lib.load()
+    check(lib.m4d_attention(dt_code(q.dtype), _ptr(q), q_bs, q_ls, kv, _ptr(out), out.stride(0), out.stride(1), B, Lq,
+                            heads, head_dim, scale, int(accumulate), _stream()), "m4d_attention")
+    return out
+
+
+def patchify(src0, src1, patch, out_dtype):
+    """[B,c0,F,H,W] (+ [B,c1,F,H,W]) -> [B, f*h*w, (c0+c1)*pt*ph*pw]."""
+    _dev(src0, src1)
+    src0 = src0.contiguous()
+    B, c0, F, H, W = src0.shape
+    c1 = 0
+    if src1 is not None:
+        src1 = src1.contiguous()
+        if src1.dtype != src0.dtype or src1.shape[0] != B or tuple(src1.shape[2:]) != (F, H, W):
+            raise ValueError("patchify: src1 must match src0's dtype, batch and grid")
+        c1 = src1.shape[1]
+    pt, ph, pw = patch
+    out = torch.empty((B, (F // pt) * (H // ph) * (W // pw), (c0 + c1) * pt * ph * pw), device=src0.device,
+                      dtype=out_dtype)
+    lib = _lib.load()
+    check(lib.m4d_patchify(dt_code(src0.dtype), _ptr(src0), c0, _ptr(src1), c1, dt_code(out_dtype), _ptr(out), B, F, H,
+                           W, pt, ph, pw, _stream()), "m4d_patchify")
+    return out
+
+
+def unpatchify(tok, row0, grid, patch, c, out_dtype):
+    """tok float32 [B, L, pt*ph*pw*c]; rows row0.. hold the (f,h,w) grid -> [B, c, f*pt, h*ph, w*pw]."""
+    _dev(tok)
+    if tok.dtype != torch.float32 or not tok.is_contiguous():
+        raise TypeError("unpatchify: tok must be contiguous float32")
+    B = tok.shape[0]
+    f, h, w = grid
+    pt, ph, pw = patch
+    out = torch.empty((B, c, f * pt, h * ph, w * pw), device=tok.device, dtype=out_dtype)
+    lib = _lib.load()
+    check(lib.m4d_unpatchify(_ptr(tok), tok.stride(0), row0, dt_code(out_dtype), _ptr(out), B, c, f, h, w, pt, ph, pw,
+                             _stream()), "m4d_unpatchify")
+    return out
+
+
+def cfg_euler_(x, v, guidance, dsigma, round_dtype=torch.float32):
+    """x (float32, in place) += dsigma * (v[0] + guidance * (v[1] - v[0])); v: [2, ...] uncond first."""
+    _dev(x, v)
+    if x.dtype != torch.float32 or not x.is_contiguous() or not v.is_contiguous():
+        raise TypeError("cfg_euler_: x must be contiguous float32, v contiguous")
+    n = x.numel()
+    if v.numel() != 2 * n:
+        raise ValueError("cfg_euler_: v must hold the uncond and cond halves")
+    lib = _lib.load()
+    check(lib.m4d_cfg_euler(_ptr(x), dt_code(v.dtype), _ptr(v), n, float(guidance), float(dsigma),
+                            dt_code(round_dtype), _stream()), "m4d_cfg_euler")
+    return x
+
+
+def unary(x, out_dtype, act=0, out=None):
+    """act: 0 cast, 1 silu, 2 gelu(tanh)."""
+    _dev(x, out)
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    lib = _lib.load()
+    check(lib.m4d_unary(dt_code(x.dtype), _ptr(x), dt_code(out.dtype), _ptr(out), x.numel(), act, _stream()),
+          "m4d_unary")
+    return out
+
+
+def add_bcast(a, bias):
+    """float32 a [B, ...] + bias [...] broadcast over the leading dim (modulation + e)."""
+    _dev(a, bias)
+    if a.dtype != torch.float32 or bias.dtype != torch.float32:
+        raise TypeError("add_bcast: float32 only")
+    a = a.contiguous()
+    bias = bias.contiguous()
+    n = bias.numel()
+    if a.numel() % n:
+        raise ValueError("add_bcast: shape mismatch")
+    out = torch.empty_like(a)
+    lib = _lib.load()
+    check(lib.m4d_add_bcast(_ptr(a), _ptr(bias), _ptr(out), a.numel() // n, n, _stream()), "m4d_add_bcast")
+    return out

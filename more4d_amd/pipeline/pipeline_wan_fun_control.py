@@ -1,0 +1,183 @@
+"""4D-STraG sampler (mirror of MoRe4D/pipeline/pipeline_wan_fun_control.py: __call__ :477-858).
+
+The hot loop (:741-840) runs entirely on the device: the CFG batch, the 48-channel control input `y`
+and the embedded context / cross-attention K,V (ContextCache) are built ONCE before the loop (the
+reference re-concatenates and re-embeds them every step, :751-789, :1175-1184); each step is one batched DiT
+forward followed by ONE kernel that does classifier-free guidance + the Euler update on an fp32 latent.
+
+Text/CLIP encoders are outside the hot path: pass them in as callables exactly
+like the reference does, or pass `prompt_embeds` / `negative_prompt_embeds` / `clip_context` directly.
+"""
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Union
+
+import torch
+
+from ..models.wan_transformer4d import ContextCache
+from ..utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+
+
+@dataclass
+class WanPipelineOutput:
+    videos: torch.Tensor
+
+
+def denoise_latents(transformer, scheduler, latents, timesteps, guidance_scale, context, clip_fea=None, y=None,
+                    full_ref=None, seq_len=None, first_frame_features=None, callback=None):
+    """The 4D-STraG denoise loop on device.
+
+    latents [B,16,F,H,W] (any float dtype; state is kept in fp32 as the reference's scheduler does, :760);
+    context: list of 2B prompt embeddings ordered uncond..., cond... (:571) or a ContextCache for 2B samples;
+    y [B,48,F,H,W], full_ref [B,16,H,W], clip_fea [B,257,1280] are per-sample and duplicated for the CFG pair.
+    Returns fp32 latents.
+    """
+    dev = transformer.device
+    T = transformer.dtype
+    do_cfg = guidance_scale > 1.0
+    x = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
+    B = x.shape[0]
+    rep = 2 if do_cfg else 1
+
+    def dup(t):
+        if t is None:
+            return None
+        t = t.to(device=dev, dtype=T)
+        return torch.cat([t] * rep).contiguous()
+
+    y2, ref2 = dup(y), dup(full_ref)
+    if isinstance(context, ContextCache):
+        cc = context
+    else:
+        clip2 = dup(clip_fea)
+        cc = transformer.prepare_context(context, clip2)
+    if seq_len is None:
+        p = transformer.config.patch_size
+        seq_len = math.ceil((x.shape[3] * x.shape[4]) / (p[1] * p[2]) * x.shape[2])
+    transformer.num_inference_steps = len(timesteps)
+    ffeat = None
+    if first_frame_features is not None:
+        ffeat = tuple(torch.cat([u] * rep) for u in first_frame_features)
+    for i, t in enumerate(timesteps):
+        transformer.current_steps = i
+        xin = torch.cat([x] * rep) if do_cfg else x
+        tt = t.to(dev).expand(xin.shape[0])
+        v = transformer(x=xin.to(T) if T != torch.float32 else xin, t=tt, context=cc, seq_len=seq_len, y=y2,
+                        full_ref=ref2, first_frame_features=ffeat)
+        if do_cfg:
+            scheduler.step_cfg_(x, v.contiguous(), guidance_scale, i, round_dtype=T)
+        else:
+            scheduler.step_cfg_(x, torch.cat([v, v]).contiguous(), 1.0, i, round_dtype=T)
+        if callback is not None:
+            callback(i, t, x)
+    return x
+
+
+class WanFunControlPipeline:
+    """Constructor and call signature of the reference pipeline (:170-189, :477-510)."""
+
+    def __init__(self, tokenizer=None, text_encoder=None, vae=None, transformer=None, clip_image_encoder=None,
+                 scheduler=None):
+        self.tokenizer, self.text_encoder, self.vae = tokenizer, text_encoder, vae
+        self.transformer, self.clip_image_encoder = transformer, clip_image_encoder
+        self.scheduler = scheduler if scheduler is not None else FlowDPMSolverMultistepScheduler(solver_order=1)
+        self._guidance_scale = 6.0
+        self._interrupt = False
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def _execution_device(self):
+        return self.transformer.device
+
+    # -- conditioning prologue -------------------------------------------------------------------------
+    def encode_prompt(self, prompt, negative_prompt, do_cfg, prompt_embeds=None, negative_prompt_embeds=None,
+                      max_sequence_length=512, device=None):
+        if prompt_embeds is None:
+            if self.text_encoder is None or self.tokenizer is None:
+                raise ValueError("pass prompt_embeds/negative_prompt_embeds or a tokenizer + text_encoder")
+            prompt_embeds = self._t5(prompt, max_sequence_length, device)
+        if do_cfg and negative_prompt_embeds is None:
+            negative_prompt_embeds = self._t5(negative_prompt if negative_prompt is not None else "",
+                                              max_sequence_length, device)
+        return prompt_embeds, negative_prompt_embeds
+
+    def _t5(self, prompt, max_len, device):
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        tok = self.tokenizer(prompt, padding="max_length", max_length=max_len, truncation=True,
+                             add_special_tokens=True, return_tensors="pt")
+        ids, mask = tok.input_ids.to(device), tok.attention_mask.to(device)
+        lens = mask.gt(0).sum(dim=1).long()
+        emb = self.text_encoder(ids, attention_mask=mask)[0]
+        return [u[:v] for u, v in zip(emb, lens)]
+
+    def prepare_latents(self, batch, channels, num_frames, height, width, dtype, device, generator, latents=None):
+        if latents is not None:
+            return latents.to(device)
+        shape = (batch, channels, (num_frames - 1) // self.vae.temporal_compression_ratio + 1,
+                 height // self.vae.spatial_compression_ratio, width // self.vae.spatial_compression_ratio)
+        return torch.randn(shape, generator=generator, dtype=torch.float32,
+                           device=generator.device if generator is not None else "cpu").to(device)
+
+    def _encode_control(self, video, device):
+        """vae.encode(x)[0].mode() (reference prepare_control_latents :343-374)."""
+        return self.vae.encode(video.to(device))[0].mode()
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, negative_prompt=None, height: int = 480, width: int = 720, control_video=None,
+                 control_camera_video=None, start_image=None, ref_image=None, num_frames: int = 49,
+                 num_inference_steps: int = 50, timesteps: Optional[List[int]] = None, guidance_scale: float = 6,
+                 num_videos_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None,
+                 prompt_embeds=None, negative_prompt_embeds=None, output_type: str = "numpy",
+                 return_dict: bool = False, callback_on_step_end=None, attention_kwargs=None,
+                 callback_on_step_end_tensor_inputs=("latents",), clip_image=None, max_sequence_length: int = 512,
+                 comfyui_progressbar: bool = False, shift: int = 5, first_frame=None, depth_image=None,
+                 clip_context=None, first_frame_features=None) -> Union[WanPipelineOutput, tuple]:
+        if control_camera_video is not None or start_image is not None:
+            raise NotImplementedError("camera-control / start-image inputs are not part of the 4D-STraG path")
+        self._guidance_scale = guidance_scale
+        device = self._execution_device
+        T = self.transformer.dtype
+        do_cfg = guidance_scale > 1.0
+        pe, ne = self.encode_prompt(prompt, negative_prompt, do_cfg, prompt_embeds, negative_prompt_embeds,
+                                    max_sequence_length, device)
+        in_prompt_embeds = (ne + pe) if do_cfg else pe      # uncond first (:571)
+        B = len(pe)
+        sig = get_sampling_sigmas(num_inference_steps, shift)
+        ts, _ = retrieve_timesteps(self.scheduler, device=device, sigmas=sig)
+        lat = self.prepare_latents(B, self.vae.config.latent_channels, num_frames, height, width, T, device,
+                                   generator, latents)
+        # control latents: [control video | start image (zeros) | depth] = 48 channels (:762-777)
+        if control_video is not None:
+            ctrl = self._encode_control(control_video.float(), device)
+        else:
+            ctrl = torch.zeros_like(lat)
+        parts = [ctrl, torch.zeros_like(lat)]
+        if depth_image is not None:
+            parts.append(self._encode_control(depth_image.repeat(1, 1, control_video.shape[2], 1, 1).float(), device))
+        y = torch.cat([p.to(device=device, dtype=torch.float32) for p in parts], dim=1)
+        full_ref = None
+        if self.transformer.config.get("add_ref_conv", False):
+            full_ref = self._encode_control(ref_image.float(), device)[:, :, 0] if ref_image is not None \
+                else torch.zeros_like(lat)[:, :, 0]
+        elif ref_image is not None:
+            raise ValueError("The add_ref_conv is False, but ref_image is not None")
+        if clip_context is None:
+            if clip_image is not None and self.clip_image_encoder is not None:
+                clip_context = self.clip_image_encoder([clip_image[:, None, :, :]]).to(device, T)
+            else:
+                clip_context = torch.zeros((B, 257, 1280), device=device, dtype=T)   # (:698-701)
+        rep = 2 if do_cfg else 1
+        cc = self.transformer.prepare_context(in_prompt_embeds, torch.cat([clip_context] * rep))
+        lat = denoise_latents(self.transformer, self.scheduler, lat, ts, guidance_scale, cc, y=y, full_ref=full_ref,
+                              first_frame_features=first_frame_features)
+        if output_type == "latent":
+            video = lat
+        elif output_type == "no_normalize":
+            video = self.vae.decode(lat.to(self.vae.dtype)).sample.float().cpu()     # (:382-386)
+        else:
+            video = self.vae.decode(lat.to(self.vae.dtype)).sample
+            video = (video / 2 + 0.5).clamp(0, 1).float().cpu()                      # decode_latents (:376-381)
+        return WanPipelineOutput(videos=video)

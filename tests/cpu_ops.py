@@ -1,0 +1,187 @@
+"""TEST-ONLY stand-in for `more4d_amd.ops` on machines without a GPU.
+
+The product never falls back to this: tests monkeypatch `more4d_amd.ops` functions with these so that the
+HOST LOGIC (token sharding, RoPE offsets, K/V segment bookkeeping, all-gather plumbing, caches, cfg-skip,
+the pipeline loop) can be exercised in this container and under `gloo` with world_size 2.  Arithmetic here
+is plain fp32 torch / the oracle; it says nothing about the kernels (those are tested with -m gpu)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from more4d_amd.ops import (EPI_GELU_ERF, EPI_GELU_TANH, EPI_RESID_GATE, EPI_SILU, EPI_STORE,  # noqa: F401
+                            EPI_STORE_F32, KV, _rows2d)
+
+NAMES = ["gemm_bt", "ln_modulate", "rmsnorm_rope", "attention", "patchify", "unpatchify", "cfg_euler_", "unary",
+         "add_bcast"]
+
+
+def install(monkeypatch):
+    import more4d_amd.ops as real
+    import sys
+    me = sys.modules[__name__]
+    for n in NAMES:
+        monkeypatch.setattr(real, n, getattr(me, n))
+
+
+def gemm_bt(a, w, bias=None, *, out=None, epilogue=EPI_STORE, gate=None, gate_stride=0, rows_per_sample=0,
+            bias_on_m=False, out_rows_ld=None):
+    M, _ = _rows2d(a)
+    N, _ = _rows2d(w)
+    a2 = a.reshape(M, a.shape[-1]).float()
+    y = a2 @ w.reshape(N, w.shape[-1]).float().t()
+    if bias is not None:
+        y = y + (bias.float()[:, None] if bias_on_m else bias.float())
+    if epilogue == EPI_GELU_TANH:
+        y = F.gelu(y, approximate="tanh")
+    elif epilogue == EPI_GELU_ERF:
+        y = F.gelu(y)
+    elif epilogue == EPI_SILU:
+        y = F.silu(y)
+    if epilogue == EPI_RESID_GATE:
+        o2 = out.view(M, N)
+        if gate is not None:
+            rps = rows_per_sample or M
+            B = M // rps
+            # gate is a view into a [B, k, N] table: element (b, n) at gate.data + b*gate_stride + n
+            g = torch.stack([torch.as_strided(gate, (N,), (1,), gate.storage_offset() + b * gate_stride)
+                             for b in range(B)])
+            y = y.to(a.dtype).float() * g.repeat_interleave(rps, dim=0)
+        else:
+            y = y.to(a.dtype).float()
+        o2 += y
+        return out
+    if epilogue == EPI_STORE_F32:
+        y = y.to(a.dtype).float()
+        if out is None:
+            return y
+        out.copy_(y.view(out.shape))
+        return out
+    y = y.to(a.dtype)
+    if out is None:
+        return y
+    out.copy_(y.view(out.shape))
+    return out
+
+
+def _strided_rows(t, B, stride, C):
+    return torch.stack([torch.as_strided(t, (C,), (1,), t.storage_offset() + b * stride) for b in range(B)])
+
+
+def ln_modulate(x, out_dtype, *, shift=None, scale=None, mod_stride=0, rows_per_sample=0, ln_w=None, ln_b=None,
+                eps=1e-6, g_ss=None, g_gate=None, g_period=0, g_len=0, out=None):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    rps = rows_per_sample or rows
+    B = rows // rps
+    xf = x.reshape(B, rps, C).float()
+    mu = xf.mean(-1, keepdim=True)
+    y = (xf - mu) * torch.rsqrt((xf - mu).pow(2).mean(-1, keepdim=True) + eps)
+    if ln_w is not None:
+        y = y * ln_w + ln_b
+    if scale is not None:
+        y = y * (1 + _strided_rows(scale, B, mod_stride, C)[:, None]) + _strided_rows(shift, B, mod_stride, C)[:, None]
+    if g_ss is not None:
+        sc = torch.zeros(B, rps, C)
+        sh = torch.zeros(B, rps, C)
+        n = min(g_len, rps)
+        idx = torch.arange(n) % g_period
+        sc[:, :n] = g_ss[:, idx, :C]
+        sh[:, :n] = g_ss[:, idx, C:]
+        y = y * (1 + sc * g_gate) + sh * g_gate
+    y = y.reshape(x.shape).to(out_dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def rmsnorm_rope(x0, w0, x1=None, w1=None, *, head_dim, eps=1e-6, cos=None, sin=None, rows_per_sample=0,
+                 rope_len=0, pos_offset=0):
+    for x, w in ((x0, w0), (x1, w1)):
+        if x is None:
+            continue
+        C = x.shape[-1]
+        rows = x.numel() // C
+        rps = rows_per_sample or rows
+        xf = x.reshape(rows, C).float()
+        y = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype).float() * w
+        if cos is not None:
+            y = y.view(rows // rps, rps, C // head_dim, head_dim // 2, 2)
+            n = min(rope_len, rps)
+            c = cos[pos_offset:pos_offset + n].view(1, n, 1, -1)
+            s = sin[pos_offset:pos_offset + n].view(1, n, 1, -1)
+            a, b = y[:, :n, :, :, 0].clone(), y[:, :n, :, :, 1].clone()
+            y[:, :n, :, :, 0] = a * c - b * s
+            y[:, :n, :, :, 1] = a * s + b * c
+        x.copy_(y.reshape(x.shape).to(x.dtype))
+    return x0, x1
+
+
+def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None):
+    C = heads * head_dim
+    if q_ls is None:
+        q_ls = C
+    if q_bs is None:
+        q_bs = Lq * q_ls
+    qf = torch.as_strided(q, (B, Lq, C), (q_bs, q_ls, 1), q.storage_offset()).float().view(B, Lq, heads, head_dim)
+    ks, vs = [], []
+    for s in segs:
+        if s.len <= 0:
+            continue
+        k = torch.as_strided(s.k, (B, s.len, C), (s.k_bs, s.k_ls, 1), s.k.storage_offset()).float()
+        vt = torch.as_strided(s.vt, (B, C, s.len), (s.vt_bs, s.vt_ls, 1), s.vt.storage_offset()).float()
+        ks.append(k)
+        vs.append(vt.transpose(1, 2))
+    k = torch.cat(ks, 1).view(B, -1, heads, head_dim)
+    v = torch.cat(vs, 1).view(B, -1, heads, head_dim)
+    sc = scale if scale is not None else 1.0 / math.sqrt(head_dim)
+    s_ = torch.einsum("bqhd,bkhd->bhqk", qf, k) * sc
+    o = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s_, -1), v).reshape(B, Lq, C).to(q.dtype)
+    if out is None:
+        return o
+    if accumulate:
+        out.copy_((out.float() + o.float()).to(out.dtype))
+    else:
+        out.copy_(o)
+    return out
+
+
+def patchify(src0, src1, patch, out_dtype):
+    x = src0 if src1 is None else torch.cat([src0, src1], 1)
+    B, C, Fr, H, W = x.shape
+    pt, ph, pw = patch
+    u = x.reshape(B, C, Fr // pt, pt, H // ph, ph, W // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    return u.reshape(B, -1, C * pt * ph * pw).to(out_dtype)
+
+
+def unpatchify(tok, row0, grid, patch, c, out_dtype):
+    f, h, w = grid
+    pt, ph, pw = patch
+    B = tok.shape[0]
+    u = tok[:, row0:row0 + f * h * w].reshape(B, f, h, w, pt, ph, pw, c).permute(0, 7, 1, 4, 2, 5, 3, 6)
+    return u.reshape(B, c, f * pt, h * ph, w * pw).to(out_dtype)
+
+
+def cfg_euler_(x, v, guidance, dsigma, round_dtype=torch.float32):
+    vu, vc = v.float().reshape(2, -1)
+    npred = (vu + guidance * (vc - vu)).to(v.dtype).float()
+    x.copy_((x.reshape(-1) + dsigma * npred).to(round_dtype).float().view(x.shape))
+    return x
+
+
+def unary(x, out_dtype, act=0, out=None):
+    y = x.float()
+    if act == 1:
+        y = F.silu(y)
+    elif act == 2:
+        y = F.gelu(y, approximate="tanh")
+    y = y.to(out_dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def add_bcast(a, bias):
+    return a + bias.reshape(a.shape[1:])

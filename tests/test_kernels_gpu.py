@@ -1,0 +1,301 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point (through more4d_amd.ops) against the CPU oracle /
+plain fp32 torch on the same seeded inputs.  fp32 mode must meet the path's 1e-3 bar with a wide margin
+(1e-4 here: exact-fp32 MFMA, only the summation order differs); bf16 mode is held to a bf16 budget."""
+import math
+
+import pytest
+import torch
+
+from util import load_npz, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+F32_TOL = 1e-4
+BF16_TOL = 2.5e-2
+
+
+def ops():
+    from more4d_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(x, dt):
+    """round to the compute dtype and back (inputs the kernel really sees)."""
+    return x.to(dt).float()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 192, 264), (2, 64, 256), (1000, 520, 72), (130, 4, 8)])
+def test_gemm_store_and_activations(dt, M, N, K):
+    o = ops()
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = q(a, dt) @ q(w, dt).t() + q(b, dt)
+    tol = F32_TOL if dt == torch.float32 else BF16_TOL
+    ad, wd, bd = a.to(DEV, dt), w.to(DEV, dt), b.to(DEV, dt)
+    out = o.gemm_bt(ad, wd, bd)
+    assert rel_err(out.float().cpu(), ref) < tol
+    out = o.gemm_bt(ad, wd, None)
+    assert rel_err(out.float().cpu(), ref - q(b, dt)) < tol
+    for epi, fn in ((o.EPI_GELU_TANH, lambda x: torch.nn.functional.gelu(x, approximate="tanh")),
+                    (o.EPI_GELU_ERF, torch.nn.functional.gelu), (o.EPI_SILU, torch.nn.functional.silu)):
+        out = o.gemm_bt(ad, wd, bd, epilogue=epi)
+        assert rel_err(out.float().cpu(), fn(ref)) < tol
+    out = o.gemm_bt(ad, wd, bd, epilogue=o.EPI_STORE_F32)
+    assert out.dtype == torch.float32
+    assert rel_err(out.cpu(), ref) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gemm_resid_gate_and_bias_on_m(dt):
+    o = ops()
+    B, L, N, K = 2, 77, 136, 96
+    M = B * L
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    gate = rnd(B, 6, N, seed=4)
+    resid = rnd(M, N, seed=5)
+    y = (q(a, dt) @ q(w, dt).t() + q(b, dt)).to(dt).float()
+    ref = resid + y * gate[:, 2].repeat_interleave(L, dim=0)
+    tol = F32_TOL if dt == torch.float32 else BF16_TOL
+    r = resid.to(DEV).clone()
+    gd = gate.to(DEV)
+    o.gemm_bt(a.to(DEV, dt), w.to(DEV, dt), b.to(DEV, dt), out=r, epilogue=o.EPI_RESID_GATE, gate=gd[:, 2],
+              gate_stride=6 * N, rows_per_sample=L)
+    assert rel_err(r.cpu(), ref) < tol
+    r = resid.to(DEV).clone()
+    o.gemm_bt(a.to(DEV, dt), w.to(DEV, dt), b.to(DEV, dt), out=r, epilogue=o.EPI_RESID_GATE, gate=None)
+    assert rel_err(r.cpu(), resid + y) < tol
+    # transposed product with a per-row bias: V^T = W_v x^T + b[:, None]
+    bm = rnd(M, seed=6)
+    out = o.gemm_bt(a.to(DEV, dt), w.to(DEV, dt)[:N // 8 * 8], bm.to(DEV, dt), bias_on_m=True)
+    ref2 = q(a, dt) @ q(w, dt)[:N // 8 * 8].t() + q(bm, dt)[:, None]
+    assert rel_err(out.float().cpu(), ref2) < tol
+    # strided output rows (writing into a slice of a wider buffer)
+    wide = torch.zeros(M, N + 24, device=DEV, dtype=dt)
+    o.gemm_bt(a.to(DEV, dt), w.to(DEV, dt), b.to(DEV, dt), out=wide[:, 8:8 + N])
+    assert rel_err(wide[:, 8:8 + N].float().cpu(), q(a, dt) @ q(w, dt).t() + q(b, dt)) < tol
+    assert float(wide[:, :8].abs().sum()) == 0 and float(wide[:, 8 + N:].abs().sum()) == 0
+
+
+def test_gemm_large_k_accumulation():
+    """K = 13824 (the FFN down projection) in bf16: fp32 accumulation must hold."""
+    o = ops()
+    M, N, K = 256, 256, 13824
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    ref = q(a, torch.bfloat16).double() @ q(w, torch.bfloat16).double().t()
+    out = o.gemm_bt(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), None, epilogue=o.EPI_STORE_F32)
+    assert rel_err(out.cpu(), ref.float()) < 1.5e-2   # bf16 rounding of the result only
+
+
+def test_gemm_rejects_bad_args():
+    o = ops()
+    from more4d_amd._lib import More4DHipError
+    a = torch.zeros(8, 12, device=DEV, dtype=torch.bfloat16)     # K*2 = 24 bytes: not a multiple of 16
+    with pytest.raises(More4DHipError):
+        o.gemm_bt(a, a, None)
+    with pytest.raises(More4DHipError):
+        o.gemm_bt(torch.zeros(4, 8), torch.zeros(4, 8))          # CPU tensors
+
+
+@pytest.mark.parametrize("C", [128, 1536, 5120])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_ln_modulate(C, odt):
+    o = ops()
+    B, L = 2, 37
+    x = rnd(B, L, C, seed=1, scale=2.0) + 0.5
+    e = rnd(B, 6, C, seed=2, scale=0.3)
+    xf = x.float()
+    mu = xf.mean(-1, keepdim=True)
+    ln = (xf - mu) * torch.rsqrt((xf - mu).pow(2).mean(-1, keepdim=True) + 1e-6)
+    ref = ln * (1 + e[:, 1:2]) + e[:, 0:1]
+    tol = 1e-5 if odt == torch.float32 else 8e-3
+    ed = e.to(DEV)
+    out = o.ln_modulate(x.to(DEV), odt, shift=ed[:, 0], scale=ed[:, 1], mod_stride=6 * C, rows_per_sample=L, eps=1e-6)
+    assert rel_err(out.float().cpu(), ref) < tol
+    w, b = rnd(C, seed=3) * 0.1 + 1, rnd(C, seed=4) * 0.1
+    out = o.ln_modulate(x.to(DEV), odt, ln_w=w.to(DEV), ln_b=b.to(DEV), eps=1e-6)
+    assert rel_err(out.float().cpu(), ln * w + b) < tol
+    # spatial guidance: periodic table over P positions, zero past g_len
+    P, glen = 5, 30
+    gss = rnd(B, P, 2 * C, seed=5, scale=0.2)
+    gate = rnd(C, seed=6, scale=0.5)
+    sc = torch.zeros(B, L, C)
+    sh = torch.zeros(B, L, C)
+    for l in range(glen):
+        sc[:, l] = gss[:, l % P, :C]
+        sh[:, l] = gss[:, l % P, C:]
+    refg = ref * (1 + sc * gate) + sh * gate
+    out = o.ln_modulate(x.to(DEV), odt, shift=ed[:, 0], scale=ed[:, 1], mod_stride=6 * C, rows_per_sample=L, eps=1e-6,
+                        g_ss=gss.to(DEV), g_gate=gate.to(DEV), g_period=P, g_len=glen)
+    assert rel_err(out.float().cpu(), refg) < tol
+    # bf16 input (MLPProj's second LayerNorm)
+    xb = x.to(torch.bfloat16)
+    xbf = xb.float()
+    mu = xbf.mean(-1, keepdim=True)
+    lnb = (xbf - mu) * torch.rsqrt((xbf - mu).pow(2).mean(-1, keepdim=True) + 1e-5)
+    out = o.ln_modulate(xb.to(DEV), odt, ln_w=w.to(DEV), ln_b=b.to(DEV), eps=1e-5)
+    assert rel_err(out.float().cpu(), lnb * w + b) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,hd", [(256, 128), (5120, 128), (128, 32)])
+def test_rmsnorm_rope(dt, C, hd):
+    from oracle import dit as odit
+    o = ops()
+    B, grid, pad = 2, (2, 3, 4), 3
+    S = grid[0] * grid[1] * grid[2]
+    L = S + pad
+    xq, xk = rnd(B, L, C, seed=1, scale=2.0), rnd(B, L, C, seed=2)
+    wq, wk = rnd(C, seed=3) * 0.1 + 1, rnd(C, seed=4) * 0.1 + 1
+    n = C // hd
+
+    def ref(x, w):
+        xr = q(x, dt)
+        y = odit.rms_norm(xr, w, 1e-6)
+        if dt == torch.bfloat16:   # (x*rsqrt).to(bf16) * w
+            inv = torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)
+            y = (xr * inv).to(dt).float() * w
+        return odit.rope_apply(y.view(B, L, n, hd), grid).reshape(B, L, C)
+
+    cos, sin = odit.rope_token_table(hd, grid)
+    cos, sin = cos.float().contiguous().to(DEV), sin.float().contiguous().to(DEV)
+    dq, dk = xq.to(DEV, dt).clone(), xk.to(DEV, dt).clone()
+    o.rmsnorm_rope(dq, wq.to(DEV), dk, wk.to(DEV), head_dim=hd, eps=1e-6, cos=cos, sin=sin, rows_per_sample=L,
+                   rope_len=S)
+    tol = 2e-5 if dt == torch.float32 else 1e-2
+    assert rel_err(dq.float().cpu(), ref(xq, wq)) < tol
+    assert rel_err(dk.float().cpu(), ref(xk, wk)) < tol
+    # norm only (cross-attention), single tensor, strided rows
+    wide = torch.zeros(B * L, C + 16, device=DEV, dtype=dt)
+    wide[:, :C] = xq.view(B * L, C).to(DEV, dt)
+    o.rmsnorm_rope(wide[:, :C], wq.to(DEV), head_dim=hd, eps=1e-6)
+    xr = q(xq, dt)
+    inv = torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)
+    refn = (xr * inv).to(dt).float() * wq
+    assert rel_err(wide[:, :C].float().cpu().view(B, L, C), refn) < tol
+    # shard semantics: rows [4, 4+8) of the sequence with pos_offset
+    sub = xq[:, 4:12].contiguous().to(DEV, dt)
+    o.rmsnorm_rope(sub, wq.to(DEV), head_dim=hd, eps=1e-6, cos=cos, sin=sin, rows_per_sample=8, rope_len=8,
+                   pos_offset=4)
+    assert rel_err(sub.float().cpu(), ref(xq, wq)[:, 4:12]) < tol
+
+
+def _attn_ref(qq, kk, vv, klen=None):
+    from oracle import dit as odit
+    return odit.sdpa(qq, kk, vv, klen)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("Lq,Lk", [(64, 80), (200, 257), (128, 64), (5, 9)])
+def test_attention(dt, D, Lq, Lk):
+    o = ops()
+    B, n = 2, 3
+    C = n * D
+    qq, kk, vv = rnd(B, Lq, n, D, seed=1), rnd(B, Lk, n, D, seed=2), rnd(B, Lk, n, D, seed=3)
+    ref = _attn_ref(q(qq, dt), q(kk, dt), q(vv, dt)).reshape(B, Lq, C)
+    Lkp = (Lk + 7) // 8 * 8
+    kd = torch.zeros(B, Lkp, C, dtype=dt)
+    kd[:, :Lk] = kk.reshape(B, Lk, C).to(dt)
+    vt = torch.full((C, B * Lkp), float("nan"), dtype=dt)     # padding columns poisoned: must never be read into the sum
+    for b in range(B):
+        vt[:, b * Lkp:b * Lkp + Lk] = vv[b].reshape(Lk, C).t().to(dt)
+    kd, vt = kd.to(DEV), vt.to(DEV)
+    seg = o.KV(kd, vt, Lkp * C, C, Lkp, B * Lkp, Lk)
+    out = o.attention(qq.reshape(B, Lq, C).to(DEV, dt).contiguous(), [seg], B=B, Lq=Lq, heads=n, head_dim=D)
+    tol = F32_TOL if dt == torch.float32 else BF16_TOL
+    assert rel_err(out.float().cpu(), ref) < tol
+    # accumulate: out += second attention (x + img_x)
+    out2 = o.attention(qq.reshape(B, Lq, C).to(DEV, dt).contiguous(), [seg], B=B, Lq=Lq, heads=n, head_dim=D,
+                       out=out.clone(), accumulate=True)
+    assert rel_err(out2.float().cpu(), 2 * ref) < 2 * tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_segments_equal_concat(dt):
+    """K/V handed over as 3 ragged segments (what the T-sharded loop does) == one concatenated K/V."""
+    o = ops()
+    B, n, D, Lq = 2, 2, 128, 70
+    C = n * D
+    lens = [40, 24, 33]
+    qq = rnd(B, Lq, n, D, seed=1)
+    ks = [rnd(B, l, n, D, seed=10 + i) for i, l in enumerate(lens)]
+    vs = [rnd(B, l, n, D, seed=20 + i) for i, l in enumerate(lens)]
+    ref = _attn_ref(q(qq, dt), q(torch.cat(ks, 1), dt), q(torch.cat(vs, 1), dt)).reshape(B, Lq, C)
+    segs = []
+    for k_, v_ in zip(ks, vs):
+        l = k_.shape[1]
+        lp = 48   # every shard buffer is 48 rows, only `l` valid (padding rows hold garbage)
+        kd = torch.full((B, lp, C), 7.0, dtype=dt)
+        kd[:, :l] = k_.reshape(B, l, C).to(dt)
+        vt = torch.full((C, B * lp), -3.0, dtype=dt)
+        for b in range(B):
+            vt[:, b * lp:b * lp + l] = v_[b].reshape(l, C).t().to(dt)
+        segs.append(o.KV(kd.to(DEV), vt.to(DEV), lp * C, C, lp, B * lp, l))
+    out = o.attention(qq.reshape(B, Lq, C).to(DEV, dt).contiguous(), segs, B=B, Lq=Lq, heads=n, head_dim=D)
+    assert rel_err(out.float().cpu(), ref) < (F32_TOL if dt == torch.float32 else BF16_TOL)
+
+
+def test_attention_online_softmax_rescale():
+    """Force the running-max rescale: one key far above the rest in a late tile (cdna guide §5.4 rule 26)."""
+    o = ops()
+    B, n, D, Lq, Lk = 1, 1, 128, 32, 256
+    qq, kk, vv = rnd(B, Lq, n, D, seed=1), rnd(B, Lk, n, D, seed=2), rnd(B, Lk, n, D, seed=3)
+    kk[0, 200] = qq[0, 7] * 3.0          # spike: q7 . k200 >> everything else, arrives in the 4th tile
+    kk[0, 3] = qq[0, 20] * 2.0           # and an early spike for another row
+    ref = _attn_ref(qq, kk, vv).reshape(B, Lq, D)
+    kd = kk.reshape(B, Lk, D).to(DEV)
+    vt = vv[0].reshape(Lk, D).t().contiguous().to(DEV)
+    out = o.attention(qq.reshape(B, Lq, D).to(DEV), [o.KV(kd, vt, Lk * D, D, Lk, Lk, Lk)], B=B, Lq=Lq, heads=n,
+                      head_dim=D)
+    assert rel_err(out.cpu(), ref) < F32_TOL
+
+
+def test_golden_sdpa_fixture():
+    o = ops()
+    z = load_npz("dit_ops.npz")
+    qq, kk, vv = z["att_q"], z["att_k"], z["att_v"]
+    B, Lq, n, D = qq.shape
+    Lk = kk.shape[1]
+    C = n * D
+    vt = vv[0].reshape(Lk, C).t().contiguous().to(DEV)
+    out = o.attention(qq.reshape(B, Lq, C).to(DEV), [o.KV(kk.reshape(B, Lk, C).to(DEV), vt, Lk * C, C, Lk, Lk, Lk)],
+                      B=B, Lq=Lq, heads=n, head_dim=D)
+    assert rel_err(out.cpu().view(B, Lq, n, D), z["att_out"]) < F32_TOL
+
+
+@pytest.mark.parametrize("sdt,odt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                     (torch.float32, torch.bfloat16)])
+def test_patchify_unpatchify(sdt, odt):
+    from oracle import dit as odit
+    o = ops()
+    B, F, H, W = 2, 3, 8, 12
+    x, y = rnd(B, 16, F, H, W, seed=1), rnd(B, 48, F, H, W, seed=2)
+    out = o.patchify(x.to(DEV, sdt), y.to(DEV, sdt), (1, 2, 2), odt)
+    xc = torch.cat([x, y], 1).to(sdt).float()
+    ref = xc.view(B, 64, F, 1, H // 2, 2, W // 2, 2).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, -1, 256)
+    assert torch.equal(out.float().cpu(), ref.to(odt).float())
+    tok = rnd(B, 5 + F * (H // 2) * (W // 2), 64, seed=3)
+    res = o.unpatchify(tok.to(DEV), 5, (F, H // 2, W // 2), (1, 2, 2), 16, odt)
+    refu = odit.unpatchify(tok[:, 5:], (F, H // 2, W // 2), (1, 2, 2), 16)
+    assert torch.equal(res.float().cpu(), refu.to(odt).float())
+
+
+def test_cfg_euler_unary_add_bcast():
+    from oracle import sched
+    o = ops()
+    x, v = rnd(1, 16, 3, 8, 8, seed=1), rnd(2, 16, 3, 8, 8, seed=2)
+    ref = sched.euler_step(x, sched.cfg_combine(v[0:1], v[1:2], 6.0), 0.9, 0.85)
+    xd = x.to(DEV).clone()
+    o.cfg_euler_(xd, v.to(DEV), 6.0, 0.85 - 0.9)
+    assert rel_err(xd.cpu(), ref) < 1e-6
+    a = rnd(1000, seed=3)
+    assert rel_err(o.unary(a.to(DEV), torch.float32, act=1).cpu(), torch.nn.functional.silu(a)) < 1e-6
+    assert torch.equal(o.unary(a.to(DEV), torch.bfloat16).cpu(), a.to(torch.bfloat16))
+    e0, m = rnd(2, 6, 128, seed=4), rnd(1, 6, 128, seed=5)
+    assert torch.equal(o.add_bcast(e0.to(DEV), m.to(DEV)).cpu(), e0 + m)
