@@ -1,16 +1,26 @@
-// m4d_gemm_bt: C[M,N] = A[M,K] * W[N,K]^T with fused epilogues, gfx950 MFMA.
+// m4d_gemm_bt: C[M,N] = A[M,K] * W[N,K]^T with fused epilogues, gfx950 MFMA (32x32x16 bf16 / 32x32x2 f32).
 //
-// Structure (v1): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave as
-// 2x2 MFMA 32x32 tiles), K-tile of 128 BYTES per row (64 bf16 / 32 fp32), two LDS stages (64 KiB ->
-// 2 workgroups per CU), register-staged global->LDS copies issued one tile ahead, one barrier per
-// K-tile.  LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 so that the
-// ds_read_b128 of an MFMA fragment column is bank-conflict free (cdna guide §6 G4).
+// Two kernels share the fragment convention, LDS image and epilogue:
+//  * gemm_bt256_kernel (bf16, K % 64 == 0): the production kernel.  256x256 output tile per 512-thread
+//    workgroup (8 waves as 2(M) x 4(N), 128x64 per wave = 4x2 MFMA 32x32 tiles, 128 accumulator VGPRs),
+//    K-tile 64, two LDS stages of 64 KiB filled by direct global->LDS DMA (global_load_lds_dwordx4: no
+//    VGPR round trip, no ds_write), next tile in flight during the current tile's 32 MFMAs per wave,
+//    ONE barrier per K-tile.  The DMA writes LDS lane-linearly, so the bank swizzle is applied on the
+//    per-lane SOURCE address and again on the fragment read (both-sides-or-neither, cdna guide rule 21).
+//  * gemm_bt_kernel<T> (bf16 / fp32, any K with 16-byte rows): 128x128 tile, 4 waves, register-staged
+//    copies with zero fill — ragged K, small problems and the exact-fp32 parity mode.
+// LDS rows are 128 B; 16-B chunk c of row r lives at chunk (c ^ ((r >> 1) & 7)): the ds_read_b128 of an
+// MFMA fragment column is bank-conflict free (guide §6 G4 / T2).
 // The MFMA is issued with W as the "A" operand and A as the "B" operand, so every lane ends up with
 // 4 CONSECUTIVE n for one m: epilogue loads/stores are 8-16 B per lane and bias/gate are vector loads.
-// Tiles are ordered XCD-aware (block b runs on XCD b%8): each XCD walks a contiguous band of tiles so
-// that neighbouring tiles share A/W panels in that XCD's L2.
+// Tiles are ordered XCD-aware (block b runs on XCD b % 8): each XCD walks a contiguous range of tiles in
+// bands of 8 tile-rows, so concurrently resident tiles share A / W panels in that XCD's L2 (guide T1).
+#include <stdlib.h>
 #include "common.h"
 #include "more4d_hip.h"
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
 
 namespace {
 
@@ -20,12 +30,81 @@ struct GemmArgs {
     int64_t lda, ldw, ldc, M, N, K, gate_stride, rows_per_sample;
     int epilogue, bias_on_m;
     int tiles_m, tiles_n;
+    int abl;   // timing ablations (tools only; results wrong when != 0): 1 no DMA, 2 frags once, 4 no barriers, 8 no MFMA
 };
 
-constexpr int BM = 128, BN = 128, ROWB = 128;          // tile rows, bytes of K per LDS row
-constexpr int STAGE_BYTES = (BM + BN) * ROWB;          // 32 KiB
+constexpr int ROWB = 128;  // bytes of K per LDS row
 
 M4D_DEV int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// XCD-aware, banded tile order -> (tm, tn)
+M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GM = 8;
+    const int band = bid / (GM * p.tiles_n);
+    const int band_rows = min(GM, p.tiles_m - band * GM);
+    const int in_band = bid - band * GM * p.tiles_n;
+    tm = band * GM + in_band % band_rows;
+    tn = in_band / band_rows;
+    if (p.abl & 16) { tm = 0; tn = 0; }          // ablation: every workgroup reads the same panels (all L2 hits)
+    if (p.abl & 32) { tm = blockIdx.x % p.tiles_m; tn = blockIdx.x / p.tiles_m; }   // ablation: naive order
+}
+
+// Epilogue for one 32(n) x 32(m) accumulator tile: this lane holds column m, rows nb0 + 8*rq + 4*hi + [0,4).
+template <typename T>
+M4D_DEV void epilogue_tile(const GemmArgs& p, const f32x16& acc, int64_t m, int64_t nb0, int hi, float bias_m,
+                           const float* grow) {
+    const T* bias = (const T*)p.bias;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const int64_t nb = nb0 + rq * 8 + hi * 4;
+        if (nb >= p.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[rq * 4 + e];
+        if (bias) {
+            if (p.bias_on_m) { v += bias_m; }
+            else { v += load4(bias + nb); }
+        }
+        switch (p.epilogue) {
+            case M4D_EPI_GELU_TANH:
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                break;
+            case M4D_EPI_GELU_ERF:
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                break;
+            case M4D_EPI_SILU:
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                break;
+            default: break;
+        }
+        if (p.epilogue == M4D_EPI_RESID_GATE) {
+            float* r = (float*)p.out + m * p.ldc + nb;
+            f32x4 x = load4(r);
+            f32x4 g = {1.f, 1.f, 1.f, 1.f};
+            if (grow) g = load4(grow + nb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] += round_through<T>(v[e]) * g[e];
+            store4(r, x);
+        } else if (p.epilogue == M4D_EPI_STORE_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
+            store4((float*)p.out + m * p.ldc + nb, v);
+        } else {
+            store4((T*)p.out + m * p.ldc + nb, v);
+        }
+    }
+}
+
+// ============================================================================ 128x128, register staged
+constexpr int BM = 128, BN = 128;
+constexpr int STAGE_BYTES = (BM + BN) * ROWB;  // 32 KiB
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(GemmArgs p) {
@@ -35,19 +114,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(GemmArgs p) {
     constexpr int KSTEPS = KT / 16;      // MFMA K=16 steps per tile
     typedef typename Frag8<T>::type frag_t;
 
-    // ---- XCD-aware tile order ----
-    const int nwg = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    constexpr int GM = 8;  // tiles_m band height: 8 x tiles_n tiles share 8 A panels
-    const int band = bid / (GM * p.tiles_n);
-    const int band_rows = min(GM, p.tiles_m - band * GM);
-    const int in_band = bid - band * GM * p.tiles_n;
-    const int tm = band * GM + in_band % band_rows;
-    const int tn = in_band / band_rows;
+    int tm, tn;
+    tile_coords(p, tm, tn);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -137,61 +205,235 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds n = nb + [0..4), m fixed, per (ni, mi, rq) ----
     const T* bias = (const T*)p.bias;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int64_t m = m0 + wm * 64 + mi * 32 + li;
         if (m >= p.M) continue;
-        float bm = 0.f;
-        if (bias && p.bias_on_m) bm = (float)bias[m];
-        const float* grow = nullptr;
-        if (p.epilogue == M4D_EPI_RESID_GATE && p.gate) grow = p.gate + (m / p.rows_per_sample) * p.gate_stride;
+        const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;
+        const float* grow = (p.epilogue == M4D_EPI_RESID_GATE && p.gate) ? p.gate + (m / p.rows_per_sample) * p.gate_stride : nullptr;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < 2; ++ni) epilogue_tile<T>(p, acc[ni][mi], m, n0 + wn * 64 + ni * 32, hi, bm, grow);
+    }
+}
+
+// ============================================================================ 256x256, direct-to-LDS DMA
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int STAGE2_BYTES = (BM2 + BN2) * ROWB;  // 64 KiB
+extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+
+__global__ __launch_bounds__(512, 2) void gemm_bt256_kernel(GemmArgs p) {
+    typedef bf16_t T;
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, wave tile 128(m) x 64(n)
+
+    // ---- DMA addressing: one wave instruction = 8 rows x 128 B = 1 KiB, lane -> (row, physical chunk) ----
+    // row block rb = i*8 + wave (i = 0..3) covers rows rb*8 .. rb*8+7 of the 256-row operand tile.
+    const int lrow = lane >> 3, pc = lane & 7;
+    const T* ga[4];
+    const T* gw[4];
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int64_t nb = n0 + wn * 64 + ni * 32 + rq * 8 + hi * 4;
-                if (nb >= p.N) continue;
-                f32x4 v;
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + wave) * 8 + lrow;
+        const int lc = pc ^ ((row >> 1) & 7);          // logical chunk that must land in physical chunk pc
+        const int64_t ra_ = min(m0 + row, p.M - 1);    // clamp: rows past the edge are computed, never stored
+        const int64_t rw_ = min(n0 + row, p.N - 1);
+        ga[i] = (const T*)p.A + ra_ * p.lda + lc * 8;
+        gw[i] = (const T*)p.W + rw_ * p.ldw + lc * 8;
+    }
+    auto issue = [&](int stage, int kt) {
+        char* sA = dyn_smem + stage * STAGE2_BYTES;
+        char* sW = sA + BM2 * ROWB;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][rq * 4 + e];
-                if (bias) {
-                    if (p.bias_on_m) { v += bm; }
-                    else { v += load4(bias + nb); }
-                }
-                switch (p.epilogue) {
-                    case M4D_EPI_GELU_TANH:
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                        break;
-                    case M4D_EPI_GELU_ERF:
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
-                        break;
-                    case M4D_EPI_SILU:
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                        break;
-                    default: break;
-                }
-                if (p.epilogue == M4D_EPI_RESID_GATE) {
-                    float* r = (float*)p.out + m * p.ldc + nb;
-                    f32x4 x = load4(r);
-                    f32x4 g = {1.f, 1.f, 1.f, 1.f};
-                    if (grow) g = load4(grow + nb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] += round_through<T>(v[e]) * g[e];
-                    store4(r, x);
-                } else if (p.epilogue == M4D_EPI_STORE_F32) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
-                    store4((float*)p.out + m * p.ldc + nb, v);
-                } else {
-                    store4((T*)p.out + m * p.ldc + nb, v);
-                }
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int rb = i * 8 + wave;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(ga[i] + kt * 64), (LDS_AS void*)(sA + rb * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(gw[i] + kt * 64), (LDS_AS void*)(sW + rb * 1024), 16, 0, 0);
         }
+    };
+
+    f32x16 acc[2][4];  // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // per-lane LDS byte offsets of the first fragment row of each K=16 step (the XOR swizzle is not additive in kk);
+    // further fragments of the same operand are +32 rows = +4096 B (the swizzle only depends on row & 15)
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)dyn_smem;
+    unsigned aoff[4], woff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        aoff[kk] = lds_off(wm * 128 + li, kk * 2 + hi);
+        woff[kk] = BM2 * ROWB + lds_off(wn * 64 + li, kk * 2 + hi);
+    }
+
+    const int nk = (int)(p.K / 64);
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        // my DMA for tile kt has landed; after the barrier everyone's has, and everyone is done reading stage^1
+        if (p.abl & 64) {   // ablation: DMA stream with two batches in flight, no consumer
+            if (kt + 1 < nk) issue(stage ^ 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (!(p.abl & 4)) __builtin_amdgcn_s_barrier();
+            continue;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk && !(p.abl & 1)) issue(stage ^ 1, kt + 1);
+        if (p.abl & 8) continue;
+        // Fragment double buffer.  hipcc's waitcnt pass drains lgkmcnt to 0 in front of every MFMA group here, so the
+        // reads are issued from inline asm (invisible to that pass) and waited for with COUNTED lgkmcnt: the 6 reads
+        // of step kk+1 are in flight while the 8 MFMAs of step kk run (cdna guide §5.7: own your waits).
+        const unsigned sbase = lds_base + stage * STAGE2_BYTES;
+        bf16x8 fa[2][4], fw[2][2];
+#define M4D_LDFRAG(buf, kk)                                                                                          \
+        do {                                                                                                         \
+            const unsigned aw_ = sbase + woff[kk], aa_ = sbase + aoff[kk];                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fw[buf][0]) : "v"(aw_));                                       \
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fw[buf][1]) : "v"(aw_));                          \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[buf][0]) : "v"(aa_));                                       \
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[buf][1]) : "v"(aa_));                          \
+            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fa[buf][2]) : "v"(aa_));                          \
+            asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fa[buf][3]) : "v"(aa_));                         \
+        } while (0)
+        M4D_LDFRAG(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk == 0) { M4D_LDFRAG(1, 1); }
+            else if (kk == 1) { M4D_LDFRAG(0, 2); }
+            else if (kk == 2) { M4D_LDFRAG(1, 3); }
+            if (kk < 3) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma32(fw[kk & 1][ni], fa[kk & 1][mi], acc[ni][mi]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef M4D_LDFRAG
+    }
+
+    const T* bias = (const T*)p.bias;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 128 + mi * 32 + li;
+        if (m >= p.M) continue;
+        const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;
+        const float* grow = (p.epilogue == M4D_EPI_RESID_GATE && p.gate) ? p.gate + (m / p.rows_per_sample) * p.gate_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) epilogue_tile<T>(p, acc[ni][mi], m, n0 + wn * 64 + ni * 32, hi, bm, grow);
+    }
+}
+
+// ============================================================================ 256x256, ping-pong wave groups
+// Same tile and wave layout, but the K loop is cut into K=32 slices held in a 4-slot LDS ring (4 x 32 KiB) and the
+// two wave groups (waves 0-3 = upper 128 rows, waves 4-7 = lower 128 rows; one wave of each group per SIMD) run ONE
+// INTERVAL APART: while a group issues its 16 MFMAs on slice s, the other group is in its load phase (12 ds_read_b128
+// for its next slice + 4 DMA instructions for the slice three ahead).  Every SIMD therefore always has one wave feeding
+// the matrix pipe and one wave doing memory work (cdna guide T3/T5: role-split schedule, s_setprio on the MFMA
+// cluster pays).  One s_barrier per interval; DMA is waited for with a COUNTED vmcnt(8) (two slices stay in flight
+// across barriers) and a staged slice is first read one barrier after the wait that retired it.
+constexpr int SLOT_BYTES = 512 * 64;   // (256 A rows + 256 W rows) x 64 B
+
+M4D_DEV int lds_off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+__global__ __launch_bounds__(512, 2) void gemm_bt256pp_kernel(GemmArgs p) {
+    const int ABL = p.abl;   // timing ablations (tools/abl.sh): results are wrong when != 0
+    typedef bf16_t T;
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ns = (int)(p.K / 32);
+
+    // DMA share of this wave: 4 x (16 rows x 64 B) of every slice; waves 0-3 carry A, waves 4-7 carry W
+    const T* gp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = (wave * 4 + i) * 16 + (lane >> 2);
+        const int lc = (lane & 3) ^ ((R >> 2) & 3);
+        if (R < 256) gp[i] = (const T*)p.A + min(m0 + R, p.M - 1) * p.lda + lc * 8;
+        else gp[i] = (const T*)p.W + min(n0 + (R - 256), p.N - 1) * p.ldw + lc * 8;
+    }
+    auto issue = [&](int s) {
+        const int sc = min(s, ns - 1);   // past the end: harmless re-load into a free slot keeps the vmcnt arithmetic uniform
+        char* slot = dyn_smem + (s & 3) * SLOT_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(gp[i] + sc * 32), (LDS_AS void*)(slot + i * 1024), 16, 0, 0);
+    };
+    int ao[2], wo[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        ao[kk] = lds_off64(wm * 128 + li, kk * 2 + hi);
+        wo[kk] = 256 * 64 + lds_off64(wn * 64 + li, kk * 2 + hi);
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // lower group starts one interval late
+    bf16x8 fa[2][4], fw[2][2];
+    for (int s = 0; s < ns; ++s) {
+        // ---- load phase: DMA three slices ahead, fragments of slice s
+        if (!(ABL & 1)) issue(s + 3);
+        const char* slot = dyn_smem + (s & 3) * SLOT_BYTES;
+        if (!(ABL & 2) || s == 0)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fw[kk][i] = *reinterpret_cast<const bf16x8*>(slot + wo[kk] + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[kk][i] = *reinterpret_cast<const bf16x8*>(slot + ao[kk] + i * 2048);
+        }
+        if (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // my share of slice s+1 has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of slice s are complete (slot may be refilled)
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        // ---- compute phase
+        __builtin_amdgcn_s_setprio(1);
+        if (!(p.abl & 8))
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma32(fw[kk][ni], fa[kk][mi], acc[ni][mi]);
+        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();   // match the lower group's barrier count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const T* bias = (const T*)p.bias;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 128 + mi * 32 + li;
+        if (m >= p.M) continue;
+        const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;
+        const float* grow = (p.epilogue == M4D_EPI_RESID_GATE && p.gate) ? p.gate + (m / p.rows_per_sample) * p.gate_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) epilogue_tile<T>(p, acc[ni][mi], m, n0 + wn * 64 + ni * 32, hi, bm, grow);
     }
 }
 
@@ -215,12 +457,35 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.gate_stride = gate_stride; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : M;
     p.epilogue = epilogue; p.bias_on_m = bias_on_m;
-    p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
-    const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-    M4D_CHECK_ARG(nwg < (1ll << 31), "gemm_bt: too many tiles");
-    dim3 grid((unsigned)nwg), block(256);
-    if (dt == M4D_BF16) hipLaunchKernelGGL(gemm_bt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_bt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+    static int abl_env = -1;
+    if (abl_env < 0) { const char* v = getenv("M4D_GEMM_ABL"); abl_env = v ? atoi(v) : 0; }
+    p.abl = abl_env;
+    hipStream_t st = (hipStream_t)stream;
+    // production kernel: big bf16 problems with K a multiple of the 64-wide K-tile
+    const bool big = dt == M4D_BF16 && K % 64 == 0 && M >= 512 && N >= 512;
+    if (big) {
+        static int variant = -1;   // M4D_GEMM_VARIANT=2 selects the ping-pong kernel (A/B measurements); default: 2-stage kernel
+        if (variant < 0) {
+            const char* v = getenv("M4D_GEMM_VARIANT");
+            variant = v ? atoi(v) : 1;
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)gemm_bt256pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
+            if (e != hipSuccess) { variant = -1; m4d_set_error("gemm_bt: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -3; }
+        }
+        p.tiles_m = (int)((M + BM2 - 1) / BM2); p.tiles_n = (int)((N + BN2 - 1) / BN2);
+        const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+        M4D_CHECK_ARG(nwg < (1ll << 31), "gemm_bt: too many tiles");
+        if (variant == 1) hipLaunchKernelGGL(gemm_bt256_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE2_BYTES, st, p);
+        else hipLaunchKernelGGL(gemm_bt256pp_kernel, dim3((unsigned)nwg), dim3(512), 4 * SLOT_BYTES, st, p);
+    } else {
+        p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+        const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+        M4D_CHECK_ARG(nwg < (1ll << 31), "gemm_bt: too many tiles");
+        dim3 grid((unsigned)nwg), block(256);
+        if (dt == M4D_BF16) hipLaunchKernelGGL(gemm_bt_kernel<bf16_t>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(gemm_bt_kernel<float>, grid, block, 0, st, p);
+    }
     M4D_CHECK_LAUNCH("gemm_bt");
     return 0;
 }

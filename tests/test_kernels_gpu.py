@@ -31,7 +31,8 @@ def q(x, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 192, 264), (2, 64, 256), (1000, 520, 72), (130, 4, 8)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 192, 264), (2, 64, 256), (1000, 520, 72), (130, 4, 8),
+                                   (1000, 520, 192), (515, 1028, 64), (768, 512, 320)])  # last three: 256x256 DMA kernel
 def test_gemm_store_and_activations(dt, M, N, K):
     o = ops()
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
@@ -54,7 +55,7 @@ def test_gemm_store_and_activations(dt, M, N, K):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gemm_resid_gate_and_bias_on_m(dt):
     o = ops()
-    B, L, N, K = 2, 77, 136, 96
+    B, L, N, K = (2, 77, 136, 96) if dt == torch.float32 else (2, 300, 520, 128)   # bf16: 256x256 DMA kernel
     M = B * L
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     gate = rnd(B, 6, N, seed=4)
