@@ -16,6 +16,7 @@
 // mode); one LDS stage (K tile + V^T tile, 32 KiB) with the next tile's global loads held in
 // registers while the current tile is computed (issue-early / write-late), two barriers per tile.
 // LDS images are XOR-swizzled per 16-B chunk so fragment reads (ds_read_b128) are conflict-free.
+#include <stdlib.h>
 #include "common.h"
 #include "more4d_hip.h"
 
@@ -269,9 +270,247 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_kernel(Att
     }
 }
 
+// ============================================================================ production kernel: bf16, D = 128
+// Same math and register layout as attn_kernel<bf16,128>, restructured around the measured bottlenecks
+// (profiles/r01: VALU:MFMA = 15:1, 46 % of wave cycles parked on waits):
+//  * K / V^T tiles arrive by direct global->LDS DMA (global_load_lds_dwordx4) into two LDS stages — no staging VGPRs,
+//    no ds_write pass, next tile in flight during the whole current tile, ONE barrier per tile.  The XOR bank swizzle
+//    is applied on the per-lane source address (DMA writes LDS lane-linearly) and on the fragment reads.
+//  * the ragged last tile of a segment is staged through registers with zero fill (the DMA cannot mask), once per segment;
+//  * VALU diet: LDS fragment offsets are per-lane constants + immediates, exp2 is the raw v_exp_f32, the O / l rescale is
+//    skipped when no row's running max moved (wave-uniform branch), the cross-half max uses v_permlane32_swap.
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+__global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
+    typedef bf16_t T;
+    constexpr int D = 128, KVB = 64, STAGE = 32768, VOFF = 16384;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int HB = p.heads * p.B;
+    int qt, hb;
+    if ((HB & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        hb = xcd * (HB >> 3) + idx / p.nq_tiles;
+        qt = idx % p.nq_tiles;
+    } else {
+        hb = blockIdx.x / p.nq_tiles;
+        qt = blockIdx.x % p.nq_tiles;
+    }
+    const int b = hb / p.heads, h = hb % p.heads;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, hi = lane >> 5;
+    const int64_t qrow = (int64_t)qt * 128 + wave * 32 + li;
+    const bool qvalid = qrow < p.Lq;
+
+    bf16x8 qf[8];
+    {
+        const T* qp = (const T*)p.q + b * p.q_bs + qrow * p.q_ls + (int64_t)h * D + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (qvalid) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[kk][j] = (T)0.f;
+            }
+        }
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // per-lane LDS offsets (bytes inside a stage); sub-tile / d-block steps are immediates
+    int koff[8], voff[4];
+    {
+        const int kr = perm23(li);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) koff[kk] = kr * 256 + (((kk * 2 + hi) ^ (kr & 15)) << 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) voff[c] = VOFF + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
+    }
+    // DMA lane roles: K instr = 4 rows x 256 B, V^T instr = 8 rows x 128 B; wave w issues instr w*4 .. w*4+3 of each
+    const int k_r = lane >> 4, k_lc0 = lane & 15;     // row within the 4-row group, physical chunk
+    const int v_r = lane >> 3, v_pc = lane & 7;
+
+    int seg = 0;
+    while (seg < p.kv.nseg && p.kv.len[seg] <= 0) ++seg;
+    int64_t key0 = 0;
+
+    auto dma_tile = [&](int stage, int s, int64_t k0) {
+        const T* kp = (const T*)p.kv.k[s] + b * p.kv.k_bs[s] + (int64_t)h * D + k0 * p.kv.k_ls[s];
+        const T* vp = (const T*)p.kv.vt[s] + b * p.kv.vt_bs[s] + (int64_t)h * D * p.kv.vt_ls[s] + k0;
+        const int64_t kls = p.kv.k_ls[s], vls = p.kv.vt_ls[s];
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int blk = wave * 4 + i;
+            const int krow = blk * 4 + k_r;                       // 0..63
+            const int klc = k_lc0 ^ (krow & 15);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(kp + krow * kls + klc * 8),
+                                             (LDS_AS void*)(base + blk * 1024), 16, 0, 0);
+            const int vrow = blk * 8 + v_r;                       // 0..127 (d)
+            const int vlc = v_pc ^ ((vrow >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(vp + vrow * vls + vlc * 8),
+                                             (LDS_AS void*)(base + VOFF + blk * 1024), 16, 0, 0);
+        }
+    };
+    auto reg_tile = [&](int stage, int s, int64_t k0) {   // ragged tile: zero-filled, synchronous
+        const int64_t len = p.kv.len[s];
+        const T* kp = (const T*)p.kv.k[s] + b * p.kv.k_bs[s] + (int64_t)h * D;
+        const T* vp = (const T*)p.kv.vt[s] + b * p.kv.vt_bs[s] + (int64_t)h * D * p.kv.vt_ls[s];
+        const int64_t kls = p.kv.k_ls[s], vls = p.kv.vt_ls[s];
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + 256 * i;
+            {
+                const int row = c >> 4, ch = c & 15;
+                const int64_t key = k0 + row;
+                const uint4 v = key < len ? *reinterpret_cast<const uint4*>(kp + key * kls + ch * 8) : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(base + swz_off<256>(row, ch)) = v;
+            }
+            {
+                const int row = c >> 3, ch = c & 7;
+                const int64_t key = k0 + ch * 8;
+                const T* src = vp + row * vls + key;
+                union { uint4 u; T e[8]; } tmp;
+                tmp.u = make_uint4(0, 0, 0, 0);
+                if (key + 8 <= len) tmp.u = *reinterpret_cast<const uint4*>(src);
+                else if (key < len) {
+                    for (int j = 0; j < 8; ++j)
+                        if (key + j < len) tmp.e[j] = src[j];
+                }
+                *reinterpret_cast<uint4*>(base + VOFF + swz_off<128>(row, ch)) = tmp.u;
+            }
+        }
+    };
+
+    int it = 0;
+    bool cur_dma = false;
+    if (seg < p.kv.nseg) {
+        cur_dma = key0 + KVB <= p.kv.len[seg];
+        if (cur_dma) dma_tile(0, seg, key0);
+    }
+    while (seg < p.kv.nseg) {
+        const int stage = it & 1;
+        const int64_t cur_len = p.kv.len[seg], cur_k0 = key0;
+        if (cur_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else reg_tile(stage, seg, cur_k0);
+        __syncthreads();
+        // advance + prefetch the next tile by DMA (if it is a full tile)
+        int nseg_ = seg;
+        int64_t nk0 = key0 + KVB;
+        if (nk0 >= cur_len) {
+            nk0 = 0;
+            ++nseg_;
+            while (nseg_ < p.kv.nseg && p.kv.len[nseg_] <= 0) ++nseg_;
+        }
+        bool next_dma = false;
+        if (nseg_ < p.kv.nseg) {
+            next_dma = nk0 + KVB <= p.kv.len[nseg_];
+            if (next_dma) dma_tile(stage ^ 1, nseg_, nk0);
+        }
+        const char* base = smem + stage * STAGE;
+
+        // ---- S^T = K Q^T ----
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(base + koff[kk] + sub * 8192);
+                mma32(kf, qf[kk], s[sub]);
+            }
+        }
+        if (cur_k0 + KVB > cur_len) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t key = cur_k0 + sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (key >= cur_len) s[sub][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (exp2 domain) ----
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+        {
+            const unsigned u = __float_as_uint(mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_run, mx * p.sc);
+        if (__any(m_new > m_run)) {          // some row's max moved: rescale (exact: alpha == 1 where it did not)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][r], p.sc, -m_run));
+                s[sub][r] = pv;
+                psum += pv;
+            }
+        l_run += psum;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                const bf16x8 pf = pack8<T>(s[sub], si * 8);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(base + voff[sub * 2 + si] + d * 4096);
+                    mma32(vf, pf, o[d]);
+                }
+            }
+        seg = nseg_;
+        key0 = nk0;
+        cur_dma = next_dma;
+        ++it;
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (qvalid) {
+        T* op = (T*)p.out + b * p.o_bs + qrow * p.o_ls + (int64_t)h * D + hi * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][rq * 4 + e] * inv;
+                T* dst = op + d * 32 + rq * 8;
+                if (p.accumulate) {
+                    f32x4 prev = load4(dst);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]) + prev[e];
+                }
+                store4(dst, v);
+            }
+    }
+}
+
 template <typename T>
 int launch(const AttnArgs& p, int D, hipStream_t st) {
     dim3 grid((unsigned)((int64_t)p.nq_tiles * p.heads * p.B)), block(256);
+    if (sizeof(T) == 2 && D == 128 && !getenv("M4D_ATTN_GENERIC")) {
+        hipLaunchKernelGGL(attn128_kernel, grid, block, 0, st, p);
+        return 0;
+    }
     switch (D) {
         case 32: hipLaunchKernelGGL((attn_kernel<T, 32>), grid, block, 0, st, p); break;
         case 64: hipLaunchKernelGGL((attn_kernel<T, 64>), grid, block, 0, st, p); break;
