@@ -6,19 +6,9 @@
 
 namespace {
 
-constexpr int MAXV = 8;  // float4 vectors per thread: C <= 256 * 4 * 8 = 8192
-
-template <int G> M4D_DEV float group_sum(float v, float* red) {
-    v = wave_sum(v);
-    if constexpr (G == 256) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        __syncthreads();
-        if (lane == 0) red[wave] = v;
-        __syncthreads();
-        v = red[0] + red[1] + red[2] + red[3];
-    }
-    return v;
-}
+// One WAVE per row (4 rows per 256-thread workgroup): the row lives in registers (MAXV float4 per lane), both
+// reductions are wave64 shuffles, no LDS and no barrier, so many rows are in flight per CU (HBM latency hiding).
+// MAXV is picked per launch from C: 8 (C <= 2048), 20 (C <= 5120), 32 (C <= 8192).
 
 // ------------------------------------------------------------------ LayerNorm + modulate
 struct LnArgs {
@@ -28,15 +18,13 @@ struct LnArgs {
     int C; float eps;
 };
 
-// G = threads cooperating on one row (64: one wave per row, 4 rows per workgroup; 256: one row per workgroup)
-template <typename TI, typename TO, int G>
+template <typename TI, typename TO, int MAXV>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
-    __shared__ float red[4];
+    constexpr int G = 64;
     const int tid = threadIdx.x;
-    const int sub = G == 64 ? (tid >> 6) : 0;
-    const int lt = G == 64 ? (tid & 63) : tid;
-    const int64_t row = (int64_t)blockIdx.x * (256 / G) + sub;
-    const bool active = row < p.rows;   // G==64: whole wave uniform; G==256: always true
+    const int sub = tid >> 6, lt = tid & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + sub;
+    const bool active = row < p.rows;   // wave-uniform
     const int C = p.C, nv = C >> 2;
     f32x4 v[MAXV];
     float s = 0.f;
@@ -49,7 +37,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
     }
-    const float mean = group_sum<G>(s, red) / C;
+    const float mean = wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -59,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
             for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
         }
     }
-    const float rstd = rsqrtf(group_sum<G>(q, red) / C + p.eps);
+    const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
     if (!active) return;
     const int64_t sample = row / p.rows_per_sample, l = row % p.rows_per_sample;
     const float* sh = p.shift ? p.shift + sample * p.mod_stride : nullptr;
@@ -94,29 +82,56 @@ struct RmsArgs {
     int C, head_dim; float eps;
 };
 
-template <typename T, int G>
+// 16-byte accesses for both dtypes: EPV = 8 bf16 / 4 fp32 elements per lane per access
+template <typename T, int EPV> M4D_DEV void load_vec(const T* p, float (&v)[EPV]) {
+    if constexpr (EPV == 8) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)r[e];
+    } else {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = r[e];
+    }
+}
+template <typename T, int EPV> M4D_DEV void store_vec(T* p, const float (&v)[EPV]) {
+    if constexpr (EPV == 8) {
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x8*>(p) = r;
+    } else {
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = v[e];
+        *reinterpret_cast<f32x4*>(p) = r;
+    }
+}
+
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs p) {
-    __shared__ float red[4];
+    constexpr int EPV = 16 / sizeof(T);
+    constexpr int NVEC = MAXV * 4 / EPV;
     const int tid = threadIdx.x;
-    const int sub = G == 64 ? (tid >> 6) : 0;
-    const int lt = G == 64 ? (tid & 63) : tid;
-    const int64_t row = (int64_t)blockIdx.x * (256 / G) + sub;
+    const int sub = tid >> 6, lt = tid & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + sub;
     const bool active = row < p.rows;
     const int which = blockIdx.y;
-    const int C = p.C, nv = C >> 2;
+    const int C = p.C, nvec = C / EPV;     // host guarantees C % 8 == 0 for bf16
     T* xr = (T*)p.x[which] + (active ? row : 0) * p.ld;
     const float* w = p.w[which];
-    f32x4 v[MAXV];
+    float v[NVEC][EPV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c4 = lt + i * G;
-        if (c4 < nv) {
-            v[i] = load4(xr + c4 * 4);
-            s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    for (int i = 0; i < NVEC; ++i) {
+        const int cv = lt + i * 64;
+        if (cv < nvec) {
+            load_vec<T, EPV>(xr + cv * EPV, v[i]);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) s += v[i][e] * v[i][e];
         }
     }
-    const float inv = rsqrtf(group_sum<G>(s, red) / C + p.eps);
+    const float inv = rsqrtf(wave_sum(s) / C + p.eps);
     if (!active) return;
     const int64_t l = row % p.rows_per_sample;
     const bool rot = p.cos_t && l < p.rope_len;
@@ -124,26 +139,32 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs p) {
     const float* ct = rot ? p.cos_t + (p.pos_offset + l) * half : nullptr;
     const float* st = rot ? p.sin_t + (p.pos_offset + l) * half : nullptr;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c4 = lt + i * G;
-        if (c4 < nv) {
-            const int c = c4 * 4;
-            f32x4 y;
-            const f32x4 wv = load4(w + c);
+    for (int i = 0; i < NVEC; ++i) {
+        const int cv = lt + i * 64;
+        if (cv < nvec) {
+            const int c = cv * EPV;
+            float y[EPV];
             // reference: (x * rsqrt(..)).to(x.dtype) * weight  (wan_transformer4d.py:391-394)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = round_through<T>(v[i][e] * inv) * wv[e];
-            if (rot) {
-                const int pi = (c % p.head_dim) >> 1;  // pair index inside the head; c is even, pairs (c,c+1),(c+2,c+3)
-                const f32x2 cs = *reinterpret_cast<const f32x2*>(ct + pi);
-                const f32x2 sn = *reinterpret_cast<const f32x2*>(st + pi);
-                const float a0 = y[0], b0 = y[1], a1 = y[2], b1 = y[3];
-                y[0] = a0 * cs[0] - b0 * sn[0];
-                y[1] = a0 * sn[0] + b0 * cs[0];
-                y[2] = a1 * cs[1] - b1 * sn[1];
-                y[3] = a1 * sn[1] + b1 * cs[1];
+            for (int e = 0; e < EPV; e += 4) {
+                const f32x4 wv = load4(w + c + e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[e + j] = round_through<T>(v[i][e + j] * inv) * wv[j];
             }
-            store4(xr + c, y);
+            if (rot) {
+                const int pi = (c % p.head_dim) >> 1;  // first pair index inside the head; pairs are (c+2j, c+2j+1)
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) {
+                    const f32x2 cs = *reinterpret_cast<const f32x2*>(ct + pi + (e >> 1));
+                    const f32x2 sn = *reinterpret_cast<const f32x2*>(st + pi + (e >> 1));
+                    const float a0 = y[e], b0 = y[e + 1], a1 = y[e + 2], b1 = y[e + 3];
+                    y[e] = a0 * cs[0] - b0 * sn[0];
+                    y[e + 1] = a0 * sn[0] + b0 * cs[0];
+                    y[e + 2] = a1 * cs[1] - b1 * sn[1];
+                    y[e + 3] = a1 * sn[1] + b1 * cs[1];
+                }
+            }
+            store_vec<T, EPV>(xr + c, y);
         }
     }
 }
@@ -251,7 +272,7 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
                                const float* ln_w, const float* ln_b, float eps, const float* g_ss,
                                const float* g_gate, int64_t g_period, int64_t g_len, m4d_stream stream) {
     M4D_CHECK_ARG(x && out && rows > 0, "ln_modulate: null/empty");
-    M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 256 * 4 * MAXV, "ln_modulate: C=%d must be a multiple of 4 and <= 8192", C);
+    M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 8192, "ln_modulate: C=%d must be a multiple of 4 and <= 8192", C);
     M4D_CHECK_ARG((shift == nullptr) == (scale == nullptr), "ln_modulate: shift and scale must both be set or both NULL");
     M4D_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr), "ln_modulate: ln_w and ln_b must both be set or both NULL");
     M4D_CHECK_ARG(g_ss == nullptr || (g_gate && g_period > 0), "ln_modulate: guidance needs gate and period");
@@ -260,12 +281,12 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
     p.rows = rows; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows; p.mod_stride = mod_stride;
     p.g_period = g_period > 0 ? g_period : 1; p.g_len = g_len; p.C = C; p.eps = eps;
     hipStream_t st = (hipStream_t)stream;
-    const bool small = C <= 64 * 4 * MAXV;  // one wave per row
-    dim3 block(256), grid((unsigned)(small ? (rows + 3) / 4 : rows));
+    dim3 block(256), grid((unsigned)((rows + 3) / 4));
 #define LN_LAUNCH(TI, TO)                                                                             \
     do {                                                                                              \
-        if (small) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 64>), grid, block, 0, st, p);       \
-        else hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 256>), grid, block, 0, st, p);            \
+        if (C <= 2048) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 8>), grid, block, 0, st, p);    \
+        else if (C <= 5120) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 20>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 32>), grid, block, 0, st, p);             \
     } while (0)
     if (x_dt == M4D_F32 && out_dt == M4D_F32) LN_LAUNCH(float, float);
     else if (x_dt == M4D_F32 && out_dt == M4D_BF16) LN_LAUNCH(float, bf16_t);
@@ -282,8 +303,9 @@ extern "C" int m4d_rmsnorm_rope(m4d_dtype dt, void* x0, void* x1, int64_t ld, co
                                 int64_t rows_per_sample, int64_t rope_len, int64_t pos_offset, m4d_stream stream) {
     M4D_CHECK_ARG(x0 && w0 && rows > 0, "rmsnorm_rope: null/empty");
     M4D_CHECK_ARG(x1 == nullptr || w1 != nullptr, "rmsnorm_rope: x1 without w1");
-    M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 256 * 4 * MAXV, "rmsnorm_rope: C=%d must be a multiple of 4 and <= 8192", C);
-    M4D_CHECK_ARG(head_dim > 0 && head_dim % 4 == 0 && C % head_dim == 0, "rmsnorm_rope: head_dim=%d must divide C and be a multiple of 4", head_dim);
+    M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 8192, "rmsnorm_rope: C=%d must be a multiple of 4 and <= 8192", C);
+    M4D_CHECK_ARG(head_dim > 0 && head_dim % 8 == 0 && C % head_dim == 0, "rmsnorm_rope: head_dim=%d must divide C and be a multiple of 8", head_dim);
+    M4D_CHECK_ARG(dt != M4D_BF16 || (ld % 8 == 0 && ((uintptr_t)x0 % 16) == 0 && (x1 == nullptr || ((uintptr_t)x1 % 16) == 0)), "rmsnorm_rope: bf16 rows must be 16-byte aligned");
     M4D_CHECK_ARG((cos_t == nullptr) == (sin_t == nullptr), "rmsnorm_rope: cos and sin must both be set or both NULL");
     M4D_CHECK_ARG(ld % 4 == 0 && ld >= C, "rmsnorm_rope: bad ld");
     RmsArgs p;
@@ -291,15 +313,17 @@ extern "C" int m4d_rmsnorm_rope(m4d_dtype dt, void* x0, void* x1, int64_t ld, co
     p.ld = ld; p.rows = rows; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows;
     p.rope_len = rope_len; p.pos_offset = pos_offset; p.C = C; p.head_dim = head_dim; p.eps = eps;
     hipStream_t st = (hipStream_t)stream;
-    const bool small = C <= 64 * 4 * MAXV;
-    dim3 block(256), grid((unsigned)(small ? (rows + 3) / 4 : rows), x1 ? 2 : 1);
-    if (dt == M4D_BF16) {
-        if (small) hipLaunchKernelGGL((rmsnorm_rope_kernel<bf16_t, 64>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((rmsnorm_rope_kernel<bf16_t, 256>), grid, block, 0, st, p);
-    } else if (dt == M4D_F32) {
-        if (small) hipLaunchKernelGGL((rmsnorm_rope_kernel<float, 64>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((rmsnorm_rope_kernel<float, 256>), grid, block, 0, st, p);
-    } else { m4d_set_error("rmsnorm_rope: bad dtype"); return -1; }
+    dim3 block(256), grid((unsigned)((rows + 3) / 4), x1 ? 2 : 1);
+#define RMS_LAUNCH(T)                                                                                 \
+    do {                                                                                              \
+        if (C <= 2048) hipLaunchKernelGGL((rmsnorm_rope_kernel<T, 8>), grid, block, 0, st, p);        \
+        else if (C <= 5120) hipLaunchKernelGGL((rmsnorm_rope_kernel<T, 20>), grid, block, 0, st, p);  \
+        else hipLaunchKernelGGL((rmsnorm_rope_kernel<T, 32>), grid, block, 0, st, p);                 \
+    } while (0)
+    if (dt == M4D_BF16) RMS_LAUNCH(bf16_t);
+    else if (dt == M4D_F32) RMS_LAUNCH(float);
+    else { m4d_set_error("rmsnorm_rope: bad dtype"); return -1; }
+#undef RMS_LAUNCH
     M4D_CHECK_LAUNCH("rmsnorm_rope");
     return 0;
 }
