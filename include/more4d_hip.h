@@ -127,6 +127,50 @@ int m4d_cfg_euler(float* x, m4d_dtype v_dt, const void* v, int64_t n, float guid
 int m4d_unary(m4d_dtype in_dt, const void* x, m4d_dtype out_dt, void* out, int64_t n, int act,
               m4d_stream stream);
 
+/* ------------------------------------------------------------------ Motion-Sensitive 3D-VAE (channels-last) */
+
+/* Causal 3-D / 2-D convolution as an implicit GEMM on channels-last activations.  Replaces CausalConv3d
+ * (wan_vae.py:21-40), the Conv2d of Resample (:81-100, incl. nn.Upsample nearest-exact x2 and ZeroPad2d((0,1,0,1))),
+ * the 1x1 convs (:203, :238-239, :509-510) and the adaptors' Conv2d (trajectory_module.py:73-100, 142, 170, 216, 254).
+ *   x:   T [Tin, Hin, Win, *] with `x_pixel_stride` elements between pixels; channels [0, Cin) are used
+ *        (tsplit: logical frame f reads physical frame f>>1, channels (f&1)*Cin + [0, Cin) — upsample3d, :138-141);
+ *   w:   T [Cout, kt*kh*kw*Cin], K ordered (dt, dh, dw, c)  (the host repacks nn.Conv weights once);
+ *   out[(to,ho,wo), co] = bias[co] + sum x[to*st+dt-pad_t, ho*sh+dh-pad_h, wo*sw+dw-pad_w, c] * w[co, (dt,dh,dw,c)]
+ *        (+ resid[(to,ho,wo), co]); taps outside [0,Tin<<tsplit) x [0,Hin<<ups) x [0,Win<<ups) read zero;
+ *   ups: the H/W indices address a nearest-exact 2x up-sampled view of x (:61-67).
+ * The caller provides causality by keeping the conv's 2-frame tail in front of the chunk (pad_t = 0) or by
+ * pad_t = 2 for a cold start.  Requirements: Cin*sizeof(T) % 16 == 0, Cout % 4 == 0. */
+int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
+                const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin,
+                int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h, int pad_w, int To,
+                int Ho, int Wo, int ups, int tsplit, m4d_stream stream);
+
+/* RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:43-58) fused with the following SiLU
+ * (:199-201, :319, :424).  x/out: T [P, C] with row strides; gamma float [C]. */
+int m4d_rmsnorm_silu_cl(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_ld,
+                        int64_t P, int C, int silu, m4d_stream stream);
+
+/* GroupNorm(G groups, eps) + affine (+ x*sigmoid(x)) per frame on [F, HW, C] (trajectory_module.py:54-60): two
+ * deterministic passes; `partial` is a float workspace of m4d_groupnorm_cl_workspace(F, HW, G) elements. */
+int64_t m4d_groupnorm_cl_workspace(int F, int64_t HW, int G);
+int m4d_groupnorm_cl(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight,
+                     const float* bias, int F, int64_t HW, int C, int G, float eps, int silu, m4d_stream stream);
+
+/* out[r, c] = softmax_c(x[r, c] * scale) for c < C, 0 for C <= c < Cpad — the score matrix of the VAE's single-head
+ * mid-block attention (wan_vae.py:256-260; head dim 384 > the flash kernel's 128). */
+int m4d_softmax_rows(m4d_dtype in_dt, const void* x, int64_t ldx, m4d_dtype out_dt, void* out, int64_t ldo, int64_t rows,
+                     int C, int Cpad, float scale, m4d_stream stream);
+
+/* Layout boundaries of the VAE path.  ncthw_to_cl: dst[(t,h,w), c] = (src[c,t,h,w]*scale+shift)*ch_scale[c]+ch_shift[c]
+ * for c < C, zero for C <= c < Cp.  cl_to_ncthw: the inverse with act: 0 none, 1 clamp(-1,1) (wan_vae.py:827),
+ * 2 sigmoid(v + aux[c,t,h,w]) (trajectory_module.py:193). */
+int m4d_ncthw_to_cl(m4d_dtype src_dt, const void* src, m4d_dtype dst_dt, void* dst, int64_t dst_pixel_stride, int C, int Cp,
+                    int T, int H, int W, float scale, float shift, const float* ch_scale, const float* ch_shift,
+                    m4d_stream stream);
+int m4d_cl_to_ncthw(m4d_dtype src_dt, const void* src, int64_t src_pixel_stride, m4d_dtype dst_dt, void* dst, int C, int T,
+                    int H, int W, float scale, float shift, const float* ch_scale, const float* ch_shift, int act,
+                    const void* aux, m4d_stream stream);
+
 /* out[b, i] = a[b, i] + bias[i]  (float32; a: [B, n], bias: [n]) — `(self.modulation + e)` of
  * WanAttentionBlock (:659) and Head (:718). */
 int m4d_add_bcast(const float* a, const float* bias, float* out, int64_t B, int64_t n, m4d_stream stream);

@@ -39,6 +39,18 @@ SIGNATURES = {
     "m4d_cfg_euler": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
     "m4d_unary": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "m4d_add_bcast": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "m4d_conv_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
+                    [c_int] * 22 + [c_void_p]),
+    "m4d_rmsnorm_silu_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "m4d_groupnorm_cl_workspace": (c_int64, [c_int, c_int64, c_int]),
+    "m4d_groupnorm_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                 c_int, c_float, c_int, c_void_p]),
+    "m4d_softmax_rows": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
+                                 c_void_p]),
+    "m4d_ncthw_to_cl": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
+                                c_float, c_void_p, c_void_p, c_void_p]),
+    "m4d_cl_to_ncthw": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                                c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

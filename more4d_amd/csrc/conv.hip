@@ -1,0 +1,235 @@
+// m4d_conv_cl: causal 3-D / 2-D convolution on channels-last activations as an IMPLICIT GEMM on the gfx950 MFMA
+// (replaces nn.Conv3d / nn.Conv2d of wan_vae.py :21-40, :83-100, :238-239 and trajectory_module.py :73-100).
+//
+//   out[(to,ho,wo), co] = bias[co] + sum_{dt,dh,dw,c} x[ti, hi, wi, c] * w[co, (dt,dh,dw,c)]  (+ resid[(to,ho,wo), co])
+//   ti = to*st + dt - pad_t,  hi = ho*sh + dh - pad_h,  wi = wo*sw + dw - pad_w;   out-of-range taps read zero.
+// The GEMM view is M = To*Ho*Wo output pixels, N = Cout, K = kt*kh*kw*Cin with K ordered (dt, dh, dw, c), so a
+// 16-byte chunk of K is 8 (bf16) / 4 (fp32) CONSECUTIVE CHANNELS of one tap: the A-operand loader gathers those
+// chunks straight from the [T,H,W,C] tensor — no im2col buffer, no torch.cat / F.pad copies (the reference pads and
+// concatenates before every conv, wan_vae.py :33-38).  Causality: the caller keeps each conv's last two input frames
+// in front of the chunk in the same buffer (a 2-frame tail), so the time axis is a plain "valid" convolution.
+// Fused into the loader: nearest-exact 2x spatial up-sampling (`ups`, wan_vae.py :61-67, :81-87) and the temporal
+// de-interleave of upsample3d's time_conv output (`tsplit`: logical frame f = physical frame f>>1, channel half f&1,
+// wan_vae.py :138-141).  Fused into the epilogue: bias and the residual / shortcut add (:224).
+// Tiling, LDS image, fragment convention and epilogue lane layout are those of gemm_bt_kernel (gemm.hip): 128x128
+// tile, 4 waves, K-tile of 128 bytes per row, register-staged copies one tile ahead, XOR-swizzled LDS rows.
+#include "common.h"
+#include "more4d_hip.h"
+
+namespace {
+
+struct ConvArgs {
+    const void* x; const void* w; const void* bias; const void* resid; void* out;
+    int64_t xs;            // elements between consecutive input pixels (>= Cin; 2*Cin with tsplit)
+    int64_t ldo, ldr;      // row strides (elements) of out / resid
+    int Tin, Hin, Win, Cin, Cout;
+    int kt, kh, kw, st, sh, sw, pad_t, pad_h, pad_w;
+    int To, Ho, Wo;
+    int ups, tsplit;
+    int64_t M, K;
+    int tiles_m, tiles_n;
+};
+
+constexpr int ROWB = 128, BM = 128, BN = 128;
+constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+
+M4D_DEV int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    constexpr int ES = sizeof(T);
+    constexpr int KT = ROWB / ES;
+    constexpr int KSTEPS = KT / 16;
+    constexpr int EPC = 16 / ES;
+    typedef typename Frag8<T>::type frag_t;
+
+    // consecutive workgroups walk tiles_n fastest inside 8-row bands (A rows are re-read by every n tile)
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int srow = t >> 3, schunk = t & 7;
+
+    // ---- per-thread output pixels of the 4 staged A rows ----
+    int ti0[4], hi0[4], wi0[4];
+    unsigned amask = 0, wmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + srow + 32 * i;
+        if (m < p.M) {
+            amask |= 1u << i;
+            const int wo = (int)(m % p.Wo);
+            const int64_t r = m / p.Wo;
+            const int ho = (int)(r % p.Ho), to = (int)(r / p.Ho);
+            ti0[i] = to * p.st - p.pad_t;
+            hi0[i] = ho * p.sh - p.pad_h;
+            wi0[i] = wo * p.sw - p.pad_w;
+        } else { ti0[i] = hi0[i] = wi0[i] = 0; }
+        if (n0 + srow + 32 * i < p.Cout) wmask |= 1u << i;
+    }
+    const char* pw = (const char*)p.w + ((n0 + srow) * p.K) * ES + schunk * 16;
+    const int64_t sw_ = 32 * p.K * ES;
+    const int khw = p.kh * p.kw;
+    const int Hl = p.Hin << p.ups, Wl = p.Win << p.ups;     // logical (up-sampled) input extent
+    const int Tl = p.Tin << p.tsplit;
+
+    uint4 ra[4], rw[4];
+    auto gload = [&](int ktile) {
+        const int64_t k = (int64_t)ktile * KT + schunk * EPC;
+        const bool kin = k < p.K;
+        int dt = 0, dh = 0, dw = 0, c = 0;
+        if (kin) {
+            const int tap = (int)(k / p.Cin);
+            c = (int)(k - (int64_t)tap * p.Cin);
+            dt = tap / khw;
+            const int r2 = tap - dt * khw;
+            dh = r2 / p.kw;
+            dw = r2 - dh * p.kw;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kin && ((amask >> i) & 1)) {
+                int ti = ti0[i] + dt, hh = hi0[i] + dh, ww = wi0[i] + dw;
+                if (ti >= 0 && ti < Tl && hh >= 0 && hh < Hl && ww >= 0 && ww < Wl) {
+                    int cc = c;
+                    if (p.tsplit) { cc += (ti & 1) * p.Cin; ti >>= 1; }
+                    if (p.ups) { hh >>= 1; ww >>= 1; }
+                    const int64_t pix = ((int64_t)ti * p.Hin + hh) * p.Win + ww;
+                    v = *reinterpret_cast<const uint4*>((const T*)p.x + pix * p.xs + cc);
+                }
+            }
+            ra[i] = v;
+            rw[i] = (kin && ((wmask >> i) & 1)) ? *reinterpret_cast<const uint4*>(pw + i * sw_ + (int64_t)ktile * ROWB)
+                                                : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto swrite = [&](int stage) {
+        char* sA = smem + stage * STAGE_BYTES;
+        char* sW = sA + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = lds_off(srow + 32 * i, schunk);
+            *reinterpret_cast<uint4*>(sA + off) = ra[i];
+            *reinterpret_cast<uint4*>(sW + off) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto compute = [&](int stage) {
+        const char* sA = smem + stage * STAGE_BYTES;
+        const char* sW = sA + BM * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            frag_t fa[2], fw[2];
+            const int c0 = (kk * 16 + hi * 8) * ES / 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rowa = wm * 64 + i * 32 + li, roww = wn * 64 + i * 32 + li;
+                if constexpr (ES == 2) {
+                    fa[i] = *reinterpret_cast<const frag_t*>(sA + lds_off(rowa, c0));
+                    fw[i] = *reinterpret_cast<const frag_t*>(sW + lds_off(roww, c0));
+                } else {
+                    f32x4 lo = *reinterpret_cast<const f32x4*>(sA + lds_off(rowa, c0));
+                    f32x4 hi4 = *reinterpret_cast<const f32x4*>(sA + lds_off(rowa, c0 + 1));
+                    fa[i] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    lo = *reinterpret_cast<const f32x4*>(sW + lds_off(roww, c0));
+                    hi4 = *reinterpret_cast<const f32x4*>(sW + lds_off(roww, c0 + 1));
+                    fw[i] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) mma32(fw[ni], fa[mi], acc[ni][mi]);
+        }
+    };
+
+    const int nk = (int)((p.K + KT - 1) / KT);
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        compute(kt & 1);
+        if (kt + 1 < nk) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds 4 consecutive output channels of one pixel ----
+    const T* bias = (const T*)p.bias;
+    const T* resid = (const T*)p.resid;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int64_t nb = n0 + wn * 64 + ni * 32 + rq * 8 + hi * 4;
+                if (nb >= p.Cout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][rq * 4 + e];
+                if (bias) v += load4(bias + nb);
+                if (resid) {
+                    const f32x4 r = load4(resid + m * p.ldr + nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]) + r[e];   // conv output is T, then x + h (:224)
+                }
+                store4((T*)p.out + m * p.ldo + nb, v);
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
+                           const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win,
+                           int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h,
+                           int pad_w, int To, int Ho, int Wo, int ups, int tsplit, m4d_stream stream) {
+    const int es = dt == M4D_BF16 ? 2 : 4;
+    M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "conv_cl: bad dtype %d", (int)dt);
+    M4D_CHECK_ARG(x && w && out, "conv_cl: null pointer");
+    M4D_CHECK_ARG(Tin > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && To > 0 && Ho > 0 && Wo > 0, "conv_cl: empty problem");
+    M4D_CHECK_ARG(kt >= 1 && kh >= 1 && kw >= 1 && st >= 1 && sh >= 1 && sw >= 1, "conv_cl: bad kernel/stride");
+    M4D_CHECK_ARG((Cin * es) % 16 == 0, "conv_cl: Cin*sizeof(T) must be a multiple of 16 (pad the channels): Cin=%d", Cin);
+    M4D_CHECK_ARG(Cout % 4 == 0, "conv_cl: Cout must be a multiple of 4 (pad the filters): Cout=%d", Cout);
+    M4D_CHECK_ARG((x_pixel_stride * es) % 16 == 0 && x_pixel_stride >= (int64_t)Cin * (tsplit ? 2 : 1), "conv_cl: bad input pixel stride");
+    M4D_CHECK_ARG(out_ld % 4 == 0 && out_ld >= Cout && (!resid || (resid_ld % 4 == 0 && resid_ld >= Cout)), "conv_cl: bad out/resid stride");
+    M4D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0, "conv_cl: pointers must be 16-byte aligned");
+    M4D_CHECK_ARG((ups == 0 || ups == 1) && (tsplit == 0 || tsplit == 1), "conv_cl: ups/tsplit are flags");
+    ConvArgs p;
+    p.x = x; p.w = w; p.bias = bias; p.resid = resid; p.out = out;
+    p.xs = x_pixel_stride; p.ldo = out_ld; p.ldr = resid_ld;
+    p.Tin = Tin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout;
+    p.kt = kt; p.kh = kh; p.kw = kw; p.st = st; p.sh = sh; p.sw = sw; p.pad_t = pad_t; p.pad_h = pad_h; p.pad_w = pad_w;
+    p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
+    p.M = (int64_t)To * Ho * Wo;
+    p.K = (int64_t)kt * kh * kw * Cin;
+    p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (Cout + BN - 1) / BN;
+    const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+    M4D_CHECK_ARG(nwg < (1ll << 31), "conv_cl: too many tiles");
+    dim3 grid((unsigned)nwg), block(256);
+    if (dt == M4D_BF16) hipLaunchKernelGGL(conv_cl_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv_cl_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+    M4D_CHECK_LAUNCH("conv_cl");
+    return 0;
+}

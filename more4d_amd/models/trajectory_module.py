@@ -1,0 +1,191 @@
+"""Trajectory adaptors of the Motion-Sensitive VAE — MI355X-native host side.
+
+Drop-in for `MoRe4D/models/trajectory_module.py` (VAEEncoderadaptor :125-196, VAEDecoderadaptor :200-279): per-frame
+2-D ResNets that map XYZ trajectory fields <-> pseudo-RGB video around the Wan VAE.  Same parameter names
+(`conv_in`, `down.0.block.0.{norm1,conv1,norm2,conv2}` / `up.0.block.{0,1}.*`, `norm_out`, `conv_out`); the torch
+modules are parameter containers, the forward runs on channels-last activations with the HIP kernels:
+Conv2d 3x3 = implicit GEMM (`ops.conv_cl`, kt = 1), GroupNorm(32)+swish = `ops.groupnorm_cl`, and the boundary
+kernels fuse the final `sigmoid(h + x)` of the encoder adaptor.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def Normalize(in_channels, num_groups=32):
+    return torch.nn.GroupNorm(num_groups=num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout, temb_channels=512):
+        super().__init__()
+        self.in_channels = in_channels
+        out_channels = in_channels if out_channels is None else out_channels
+        self.out_channels = out_channels
+        self.use_conv_shortcut = conv_shortcut
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = torch.nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if temb_channels > 0:
+            self.temb_proj = torch.nn.Linear(temb_channels, out_channels)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = torch.nn.Dropout(dropout)
+        self.conv2 = torch.nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if self.in_channels != self.out_channels:
+            raise NotImplementedError("the adaptors only use in_channels == out_channels blocks")
+
+
+class _AdaptorBase(nn.Module):
+    """Shared runner: channels-last frames [F, H*W, C]."""
+
+    def _setup(self):
+        self._pack_cache = {}
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def _packed(self, conv):
+        T = self.dtype
+        key = (conv.weight._version, conv.weight.data_ptr(), T)
+        hit = self._pack_cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            w = conv.weight.detach()
+            co, ci, kh, kw = w.shape
+            cip, cop = (ci + 7) // 8 * 8, (co + 3) // 4 * 4
+            wp = torch.zeros((cop, kh, kw, cip), device=w.device, dtype=T)
+            wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+            bp = torch.zeros(cop, device=w.device, dtype=T)
+            bp[:co] = conv.bias.detach()
+            hit = (key, wp.view(cop, -1), bp, cip, cop)
+            self._pack_cache[id(conv)] = hit
+        return hit[1:]
+
+    def _f32(self, p):
+        key = (p._version, p.data_ptr())
+        hit = self._pack_cache.get(id(p))
+        if hit is None or hit[0] != key:
+            hit = (key, p.detach().float().contiguous())
+            self._pack_cache[id(p)] = hit
+        return hit[1]
+
+    def _conv(self, x, conv, F, H, W, cin, resid=None):
+        w, b, cip, cop = self._packed(conv)
+        assert cip == cin
+        return ops.conv_cl(x, w, b, Tin=F, Hin=H, Win=W, Cin=cin, k=(1, 3, 3), pad=(0, 1, 1), out_thw=(F, H, W),
+                           resid=resid), cop
+
+    def _gn_swish(self, x, norm, F, HW):
+        return ops.groupnorm_cl(x.view(F, HW, -1), self._f32(norm.weight), self._f32(norm.bias), F=F, HW=HW,
+                                groups=norm.num_groups, eps=norm.eps, silu=True).view(F * HW, -1)
+
+    def _resnet(self, h, blk, F, H, W):
+        c = blk.in_channels
+        y, _ = self._conv(self._gn_swish(h, blk.norm1, F, H * W), blk.conv1, F, H, W, c)
+        y, _ = self._conv(self._gn_swish(y, blk.norm2, F, H * W), blk.conv2, F, H, W, c, resid=h)
+        return y
+
+
+class VAEEncoderadaptor(_AdaptorBase):
+    def __init__(self, *, ch=128, out_ch=1, ch_mult=(1,), num_res_blocks=1, attn_resolutions=[], dropout=0.0,
+                 resamp_with_conv=True, in_channels=3, resolution=256, z_channels=4, double_z=True,
+                 use_linear_attn=False, attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        assert self.num_resolutions == 1
+        self.num_res_blocks, self.resolution, self.in_channels = num_res_blocks, resolution, in_channels
+        self.final_activation = nn.Sigmoid()
+        self.conv_in = torch.nn.Conv2d(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.in_ch_mult = in_ch_mult
+        self.down = nn.ModuleList()
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            attn = nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=self.temb_ch,
+                                         dropout=dropout))
+                block_in = block_out
+            down = nn.Module()
+            down.block = block
+            down.attn = attn
+            self.down.append(down)
+        self.norm_out = Normalize(block_out)
+        self.conv_out = zero_module(torch.nn.Conv2d(block_out, in_channels, kernel_size=3, stride=1, padding=1))
+        self._setup()
+
+    def forward(self, x):
+        """x [B, 3, F, H, W] -> sigmoid(net(x) + x), same shape (reference :177-196)."""
+        B, C, F, H, W = x.shape
+        T, dev = self.dtype, self.device
+        outs = []
+        for b in range(B):
+            xb = x[b].to(device=dev, dtype=T).contiguous()
+            h = ops.ncthw_to_cl(xb, T, Cp=8).view(F * H * W, 8)
+            h, _ = self._conv(h, self.conv_in, F, H, W, 8)
+            for blk in self.down[0].block:
+                h = self._resnet(h, blk, F, H, W)
+            h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
+            outs.append(ops.cl_to_ncthw(h, T, C=C, T=F, H=H, W=W, pixel_stride=cop, act=2, aux=xb))
+        return torch.stack(outs)
+
+
+class VAEDecoderadaptor(_AdaptorBase):
+    def __init__(self, *, ch=128, out_ch=3, ch_mult=(1,), num_res_blocks=1, attn_resolutions=[], dropout=0.0,
+                 resamp_with_conv=True, in_channels=3, resolution=256, z_channels=4, give_pre_end=False, tanh_out=False,
+                 use_linear_attn=False, attn_type="vanilla", **ignorekwargs):
+        super().__init__()
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        assert self.num_resolutions == 1
+        self.num_res_blocks, self.resolution, self.in_channels = num_res_blocks, resolution, in_channels
+        self.give_pre_end, self.tanh_out, self.out_ch = give_pre_end, tanh_out, out_ch
+        if tanh_out:
+            raise NotImplementedError("tanh_out is not used by MoRe4D (trajectory_module.py:203)")
+        self.conv_in = torch.nn.Conv2d(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            attn = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=self.temb_ch,
+                                         dropout=dropout))
+                block_in = block_out
+            up = nn.Module()
+            up.block = block
+            up.attn = attn
+            self.up.insert(0, up)
+        self.final_activation = None
+        self.norm_out = Normalize(block_in)
+        self.conv_out = torch.nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+        self._setup()
+
+    def forward(self, z):
+        """z [B, 3, F, H, W] -> [B, out_ch, F, H, W] (reference :260-279)."""
+        B, C, F, H, W = z.shape
+        T, dev = self.dtype, self.device
+        outs = []
+        for b in range(B):
+            zb = z[b].to(device=dev, dtype=T).contiguous()
+            h = ops.ncthw_to_cl(zb, T, Cp=8).view(F * H * W, 8)
+            h, _ = self._conv(h, self.conv_in, F, H, W, 8)
+            for blk in self.up[0].block:
+                h = self._resnet(h, blk, F, H, W)
+            h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
+            outs.append(ops.cl_to_ncthw(h, T, C=self.out_ch, T=F, H=H, W=W, pixel_stride=cop))
+        return torch.stack(outs)

@@ -239,3 +239,112 @@ def add_bcast(a, bias):
     lib = _lib.load()
     check(lib.m4d_add_bcast(_ptr(a), _ptr(bias), _ptr(out), a.numel() // n, n, _stream()), "m4d_add_bcast")
     return out
+
+
+# ------------------------------------------------------------------ Motion-Sensitive 3D-VAE (channels-last)
+
+def conv_cl(x, w, bias, *, Tin, Hin, Win, Cin, k, stride=(1, 1, 1), pad=(0, 0, 0), out_thw, x_pixel_stride=None,
+            resid=None, out=None, ups=False, tsplit=False):
+    """Implicit-GEMM conv on channels-last x (flat or [T,H,W,C]); w [Cout, kt*kh*kw*Cin] packed (dt,dh,dw,c).
+    Returns out [To*Ho*Wo, Cout] (or writes `out`, a row-strided 2-D view)."""
+    _dev(x, w, bias, resid, out)
+    Cout = w.shape[0]
+    kt, kh, kw = k
+    if w.shape[1] != kt * kh * kw * Cin:
+        raise ValueError(f"conv_cl: weight K {w.shape[1]} != {kt}*{kh}*{kw}*{Cin}")
+    if x.dtype != w.dtype or (bias is not None and bias.dtype != x.dtype) or (resid is not None and resid.dtype != x.dtype):
+        raise TypeError("conv_cl: dtype mismatch")
+    To, Ho, Wo = out_thw
+    M = To * Ho * Wo
+    if x_pixel_stride is None:
+        x_pixel_stride = Cin * (2 if tsplit else 1)
+    if out is None:
+        out = torch.empty((M, Cout), device=x.device, dtype=x.dtype)
+    om, ldo = _rows2d(out)
+    if om != M or out.shape[-1] != Cout:
+        raise ValueError(f"conv_cl: out {tuple(out.shape)} vs M={M} Cout={Cout}")
+    ldr = 0
+    if resid is not None:
+        rm, ldr = _rows2d(resid)
+        if rm != M or resid.shape[-1] != Cout:
+            raise ValueError("conv_cl: resid shape mismatch")
+    lib = _lib.load()
+    check(lib.m4d_conv_cl(dt_code(x.dtype), _ptr(x), x_pixel_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
+                          Tin, Hin, Win, Cin, Cout, kt, kh, kw, stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
+                          To, Ho, Wo, int(ups), int(tsplit), _stream()), "m4d_conv_cl")
+    return out
+
+
+def rmsnorm_silu_cl(x, gamma, *, silu=True, out=None):
+    """x [P, C] (row-strided) -> RMS_norm(x) (* SiLU) in x.dtype."""
+    _dev(x, gamma, out)
+    P, ldx = _rows2d(x)
+    C = x.shape[-1]
+    if out is None:
+        out = torch.empty((P, C), device=x.device, dtype=x.dtype)
+    po, ldo = _rows2d(out)
+    if po != P or out.shape[-1] != C or out.dtype != x.dtype:
+        raise ValueError("rmsnorm_silu_cl: out mismatch")
+    if gamma.dtype != torch.float32 or gamma.numel() != C:
+        raise TypeError("rmsnorm_silu_cl: gamma must be float32 [C]")
+    lib = _lib.load()
+    check(lib.m4d_rmsnorm_silu_cl(dt_code(x.dtype), _ptr(x), ldx, _ptr(gamma), _ptr(out), ldo, P, C, int(silu), _stream()),
+          "m4d_rmsnorm_silu_cl")
+    return out
+
+
+def groupnorm_cl(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, out=None):
+    """x [F, HW, C] contiguous channels-last -> GroupNorm (+swish)."""
+    _dev(x, weight, bias, out)
+    if not x.is_contiguous():
+        raise ValueError("groupnorm_cl: x must be contiguous")
+    C = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    n = lib.m4d_groupnorm_cl_workspace(F, HW, groups)
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    check(lib.m4d_groupnorm_cl(dt_code(x.dtype), _ptr(x), _ptr(out), _ptr(ws), n, _ptr(weight), _ptr(bias), F, HW, C, groups,
+                               eps, int(silu), _stream()), "m4d_groupnorm_cl")
+    return out
+
+
+def softmax_rows(x, out_dtype, *, C, Cpad, scale):
+    """x [R, >=C] float32/bf16 -> softmax(x[:, :C]*scale) in out_dtype [R, Cpad] (pad columns zero)."""
+    _dev(x)
+    R, ldx = _rows2d(x)
+    out = torch.empty((R, Cpad), device=x.device, dtype=out_dtype)
+    lib = _lib.load()
+    check(lib.m4d_softmax_rows(dt_code(x.dtype), _ptr(x), ldx, dt_code(out_dtype), _ptr(out), Cpad, R, C, Cpad, float(scale),
+                               _stream()), "m4d_softmax_rows")
+    return out
+
+
+def ncthw_to_cl(src, out_dtype, *, Cp=None, scale=1.0, shift=0.0, ch_scale=None, ch_shift=None, out=None):
+    """src [C,T,H,W] -> [T,H,W,Cp] channels-last (zero-padded channels), optional affine."""
+    _dev(src, ch_scale, ch_shift, out)
+    src = src.contiguous()
+    C, T, H, W = src.shape
+    Cp = Cp or C
+    if out is None:
+        out = torch.empty((T, H, W, Cp), device=src.device, dtype=out_dtype)
+    lib = _lib.load()
+    check(lib.m4d_ncthw_to_cl(dt_code(src.dtype), _ptr(src), dt_code(out.dtype), _ptr(out), out.stride(2), C, Cp, T, H, W,
+                              float(scale), float(shift), _ptr(ch_scale), _ptr(ch_shift), _stream()), "m4d_ncthw_to_cl")
+    return out
+
+
+def cl_to_ncthw(src, out_dtype, *, C, T, H, W, pixel_stride, scale=1.0, shift=0.0, ch_scale=None, ch_shift=None, act=0,
+                aux=None):
+    """channels-last src (pixel_stride elements per pixel) -> [C,T,H,W]; act: 0 none, 1 clamp(-1,1), 2 sigmoid(v+aux)."""
+    _dev(src, ch_scale, ch_shift, aux)
+    out = torch.empty((C, T, H, W), device=src.device, dtype=out_dtype)
+    if aux is not None:
+        aux = aux.contiguous()
+        if aux.dtype != out_dtype or aux.numel() != out.numel():
+            raise ValueError("cl_to_ncthw: aux must match the output")
+    lib = _lib.load()
+    check(lib.m4d_cl_to_ncthw(dt_code(src.dtype), _ptr(src), pixel_stride, dt_code(out_dtype), _ptr(out), C, T, H, W,
+                              float(scale), float(shift), _ptr(ch_scale), _ptr(ch_shift), act, _ptr(aux), _stream()),
+          "m4d_cl_to_ncthw")
+    return out

@@ -185,3 +185,100 @@ def unary(x, out_dtype, act=0, out=None):
 
 def add_bcast(a, bias):
     return a + bias.reshape(a.shape[1:])
+
+
+# ------------------------------------------------------------------ VAE ops (channels-last)
+NAMES += ["conv_cl", "rmsnorm_silu_cl", "groupnorm_cl", "softmax_rows", "ncthw_to_cl", "cl_to_ncthw"]
+
+
+def conv_cl(x, w, bias, *, Tin, Hin, Win, Cin, k, stride=(1, 1, 1), pad=(0, 0, 0), out_thw, x_pixel_stride=None,
+            resid=None, out=None, ups=False, tsplit=False):
+    kt, kh, kw = k
+    Cout = w.shape[0]
+    xs = x_pixel_stride or Cin * (2 if tsplit else 1)
+    flat = x.reshape(-1)
+    cw = Cin * (2 if tsplit else 1)
+    xv = torch.as_strided(flat, (Tin, Hin, Win, cw), (Hin * Win * xs, Win * xs, xs, 1), flat.storage_offset()).float()
+    if tsplit:
+        xv = torch.stack([xv[..., :Cin], xv[..., Cin:]], dim=1).reshape(2 * Tin, Hin, Win, Cin)
+    if ups:
+        xv = xv.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    To, Ho, Wo = out_thw
+    Tl, Hl, Wl = xv.shape[:3]
+    need_t = (To - 1) * stride[0] + kt - Tl - pad[0]
+    need_h = (Ho - 1) * stride[1] + kh - Hl - pad[1]
+    need_w = (Wo - 1) * stride[2] + kw - Wl - pad[2]
+    xin = xv.permute(3, 0, 1, 2).unsqueeze(0)
+    xin = F.pad(xin, (pad[2], max(need_w, 0), pad[1], max(need_h, 0), pad[0], max(need_t, 0)))
+    wt = w.float().view(Cout, kt, kh, kw, Cin).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(xin, wt, None if bias is None else bias.float(), stride=stride)[0]
+    y = y[:, :To, :Ho, :Wo].permute(1, 2, 3, 0).reshape(To * Ho * Wo, Cout).contiguous()
+    if resid is not None:
+        y = y.to(x.dtype).float() + resid.reshape(To * Ho * Wo, Cout).float()
+    y = y.to(x.dtype)
+    if out is None:
+        return y
+    out.copy_(y.view(out.shape))
+    return out
+
+
+def rmsnorm_silu_cl(x, gamma, *, silu=True, out=None):
+    xf = x.float()
+    C = x.shape[-1]
+    y = xf / xf.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * gamma
+    if silu:
+        y = F.silu(y.to(x.dtype).float())
+    y = y.to(x.dtype)
+    if out is None:
+        return y
+    out.copy_(y.view(out.shape))
+    return out
+
+
+def groupnorm_cl(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, out=None):
+    C = x.shape[-1]
+    y = torch.nn.functional.group_norm(x.float().view(F, HW, C).permute(0, 2, 1), groups, weight, bias, eps)
+    if silu:
+        y = y.to(x.dtype).float()
+        y = y * torch.sigmoid(y)
+    y = y.permute(0, 2, 1).reshape(x.shape).to(x.dtype).contiguous()
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def softmax_rows(x, out_dtype, *, C, Cpad, scale):
+    R = x.shape[0]
+    out = torch.zeros((R, Cpad), dtype=out_dtype)
+    out[:, :C] = torch.softmax(x[:, :C].float() * scale, dim=-1).to(out_dtype)
+    return out
+
+
+def ncthw_to_cl(src, out_dtype, *, Cp=None, scale=1.0, shift=0.0, ch_scale=None, ch_shift=None, out=None):
+    C, T, H, W = src.shape
+    Cp = Cp or C
+    v = src.float() * scale + shift
+    if ch_scale is not None:
+        v = v * ch_scale.view(C, 1, 1, 1) + ch_shift.view(C, 1, 1, 1)
+    res = torch.zeros((T, H, W, Cp), dtype=out_dtype)
+    res[..., :C] = v.permute(1, 2, 3, 0).to(out_dtype)
+    if out is None:
+        return res
+    out.copy_(res.view(out.shape))
+    return out
+
+
+def cl_to_ncthw(src, out_dtype, *, C, T, H, W, pixel_stride, scale=1.0, shift=0.0, ch_scale=None, ch_shift=None, act=0,
+                aux=None):
+    flat = src.reshape(-1)
+    v = torch.as_strided(flat, (T, H, W, C), (H * W * pixel_stride, W * pixel_stride, pixel_stride, 1),
+                         flat.storage_offset()).float()
+    v = v.permute(3, 0, 1, 2) * scale + shift
+    if ch_scale is not None:
+        v = v * ch_scale.view(C, 1, 1, 1) + ch_shift.view(C, 1, 1, 1)
+    if act == 1:
+        v = v.clamp(-1, 1)
+    elif act == 2:
+        v = torch.sigmoid(v + aux.float().view(C, T, H, W))
+    return v.to(out_dtype).contiguous()

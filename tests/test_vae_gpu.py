@@ -1,0 +1,138 @@
+"""GPU parity of the Motion-Sensitive VAE path: every VAE kernel against the torch stand-ins of tests/cpu_ops.py
+(themselves pinned to the reference by tests/test_vae_host_logic.py), then the full encode/decode and the two
+adaptors against the fixtures produced by the reference itself."""
+import pytest
+import torch
+
+import cpu_ops
+from util import load_keys, load_npz, rel_err, rms_rel_err
+from weights import fill
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # name, Tin,Hin,Win,Cin,Cout, k, stride, pad, out_thw, ups, tsplit
+    ("c333_tail", 6, 9, 11, 16, 24, (3, 3, 3), (1, 1, 1), (0, 1, 1), (4, 9, 11), False, False),
+    ("c333_cold", 3, 8, 8, 8, 96, (3, 3, 3), (1, 1, 1), (2, 1, 1), (3, 8, 8), False, False),
+    ("c133", 2, 10, 12, 96, 96, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 10, 12), False, False),
+    ("down2d", 2, 10, 12, 32, 32, (1, 3, 3), (1, 2, 2), (0, 0, 0), (2, 5, 6), False, False),
+    ("up2d", 2, 5, 6, 64, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 10, 12), True, False),
+    ("up3d_tsplit", 2, 5, 6, 32, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 10, 12), True, True),
+    ("time_s2", 5, 6, 7, 48, 48, (3, 1, 1), (2, 1, 1), (0, 0, 0), (2, 6, 7), False, False),
+    ("c111_big", 1, 20, 30, 384, 192, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 20, 30), False, False),
+    ("cout4", 2, 9, 9, 96, 4, (3, 3, 3), (1, 1, 1), (2, 1, 1), (2, 9, 9), False, False),
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_cl(dt, case):
+    from more4d_amd import ops
+    _, Tin, Hin, Win, Cin, Cout, k, stride, pad, out_thw, ups, tsplit = case
+    cw = Cin * (2 if tsplit else 1)
+    x = rnd(Tin, Hin, Win, cw, seed=1).to(dt)
+    K = k[0] * k[1] * k[2] * Cin
+    w = rnd(Cout, K, seed=2, scale=K ** -0.5).to(dt)
+    b = rnd(Cout, seed=3).to(dt)
+    M = out_thw[0] * out_thw[1] * out_thw[2]
+    r = rnd(M, Cout, seed=4).to(dt)
+    kw = dict(Tin=Tin, Hin=Hin, Win=Win, Cin=Cin, k=k, stride=stride, pad=pad, out_thw=out_thw, ups=ups, tsplit=tsplit)
+    tol = 1e-4 if dt == torch.float32 else 2.5e-2
+    ref = cpu_ops.conv_cl(x.float(), w.float(), b.float(), **kw)
+    out = ops.conv_cl(x.to(DEV), w.to(DEV), b.to(DEV), **kw)
+    assert rel_err(out.float().cpu(), ref) < tol
+    ref = cpu_ops.conv_cl(x.float(), w.float(), None, resid=r.float(), **kw)
+    out = ops.conv_cl(x.to(DEV), w.to(DEV), None, resid=r.to(DEV), **kw)
+    assert rel_err(out.float().cpu(), ref) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [16, 96, 192, 384])
+def test_rmsnorm_silu_cl(dt, C):
+    from more4d_amd import ops
+    x = rnd(301, C, seed=1, scale=2.0).to(dt)
+    g = rnd(C, seed=2) * 0.1 + 1
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+    for silu in (True, False):
+        ref = cpu_ops.rmsnorm_silu_cl(x.float(), g, silu=silu)
+        out = ops.rmsnorm_silu_cl(x.to(DEV), g.to(DEV), silu=silu)
+        assert rel_err(out.float().cpu(), ref) < tol
+    wide = torch.zeros(301, C + 16, device=DEV, dtype=dt)
+    ops.rmsnorm_silu_cl(x.to(DEV), g.to(DEV), out=wide[:, 8:8 + C])
+    assert rel_err(wide[:, 8:8 + C].float().cpu(), cpu_ops.rmsnorm_silu_cl(x.float(), g)) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_groupnorm_softmax_layouts(dt):
+    from more4d_amd import ops
+    F, HW, C = 3, 5000, 128
+    x = (rnd(F, HW, C, seed=1) * 1.5 + 0.3).to(dt)
+    w, b = rnd(C, seed=2) * 0.1 + 1, rnd(C, seed=3) * 0.1
+    ref = cpu_ops.groupnorm_cl(x.float(), w, b, F=F, HW=HW)
+    out = ops.groupnorm_cl(x.to(DEV), w.to(DEV), b.to(DEV), F=F, HW=HW)
+    assert rel_err(out.float().cpu(), ref) < (2e-5 if dt == torch.float32 else 2e-2)
+    out2 = ops.groupnorm_cl(x.to(DEV), w.to(DEV), b.to(DEV), F=F, HW=HW)
+    assert torch.equal(out, out2)      # deterministic two-pass reduction
+    s = rnd(70, 77, seed=4, scale=3.0)
+    p = ops.softmax_rows(s.to(DEV), dt, C=75, Cpad=80, scale=0.3)
+    refp = cpu_ops.softmax_rows(s, torch.float32, C=75, Cpad=80, scale=0.3)
+    assert rel_err(p.float().cpu(), refp) < (1e-5 if dt == torch.float32 else 8e-3)
+    v = rnd(3, 4, 6, 10, seed=5)
+    cs, sh = rnd(3, seed=6), rnd(3, seed=7)
+    a = ops.ncthw_to_cl(v.to(DEV), dt, Cp=8, scale=2.0, shift=-1.0, ch_scale=cs.to(DEV), ch_shift=sh.to(DEV))
+    refa = cpu_ops.ncthw_to_cl(v, torch.float32, Cp=8, scale=2.0, shift=-1.0, ch_scale=cs, ch_shift=sh)
+    assert rel_err(a.float().cpu(), refa) < (1e-6 if dt == torch.float32 else 8e-3)
+    for act, aux in ((0, None), (1, None), (2, rnd(3, 4, 6, 10, seed=8).to(dt))):
+        o = ops.cl_to_ncthw(a, dt, C=3, T=4, H=6, W=10, pixel_stride=8, ch_scale=cs.to(DEV), ch_shift=sh.to(DEV), act=act,
+                            aux=None if aux is None else aux.to(DEV))
+        refo = cpu_ops.cl_to_ncthw(a.float().cpu(), torch.float32, C=3, T=4, H=6, W=10, pixel_stride=8, ch_scale=cs,
+                                   ch_shift=sh, act=act, aux=None if aux is None else aux.float())
+        assert rel_err(o.float().cpu(), refo) < (1e-5 if dt == torch.float32 else 1e-2)
+
+
+def make_vae(dtype):
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    vae = AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(load_keys("vae_keys.json"), 2024))
+    return vae.to(DEV, dtype)
+
+
+def test_vae_roundtrip_fp32():
+    """Full-size network on [1,3,9,32,32] (3 chunks) vs the reference's own encode / decode outputs."""
+    z = load_npz("vae_roundtrip.npz")
+    vae = make_vae(torch.float32)
+    with torch.no_grad():
+        enc = vae._encode(z["x"].to(DEV))
+        assert rel_err(enc.cpu(), z["enc"]) < 1e-3
+        dec = vae.decode(z["enc"][:, :16].to(DEV)).sample
+        assert rel_err(dec.cpu(), z["dec"]) < 1e-3
+        assert torch.equal(vae.encode(z["x"].to(DEV))[0].mode(), enc[:, :16])
+
+
+def test_vae_roundtrip_bf16_budget():
+    z = load_npz("vae_roundtrip.npz")
+    vae = make_vae(torch.bfloat16)
+    with torch.no_grad():
+        enc = vae._encode(z["x"].to(DEV, torch.bfloat16))
+        dec = vae.decode(z["enc"][:, :16].to(DEV, torch.bfloat16)).sample
+    assert rms_rel_err(enc.float().cpu(), z["enc"]) < 4e-2
+    assert rms_rel_err(dec.float().cpu(), z["dec"]) < 6e-2
+
+
+@pytest.mark.parametrize("which", ["enc", "dec"])
+def test_adaptors_fp32(which):
+    from more4d_amd.models.trajectory_module import VAEDecoderadaptor, VAEEncoderadaptor
+    z = load_npz(f"adaptor_{which}.npz")
+    m = (VAEEncoderadaptor if which == "enc" else VAEDecoderadaptor)().eval()
+    m.load_state_dict({k[3:]: v for k, v in z.items() if k.startswith("sd.")}, strict=True)
+    m = m.to(DEV)
+    with torch.no_grad():
+        out = m(z["x"].to(DEV))
+    assert rel_err(out.cpu(), z["out"]) < 1e-3
