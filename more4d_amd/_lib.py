@@ -40,7 +40,7 @@ SIGNATURES = {
     "m4d_unary": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "m4d_add_bcast": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "m4d_conv_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
-                    [c_int] * 22 + [c_void_p]),
+                    [c_int] * 19 + [c_void_p]),
     "m4d_rmsnorm_silu_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "m4d_groupnorm_cl_workspace": (c_int64, [c_int, c_int64, c_int]),
     "m4d_groupnorm_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int,

@@ -30,6 +30,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} not exported"
     lib.m4d_version.restype = ctypes.c_int
     assert lib.m4d_version() >= 100
+    # every binding has exactly as many argtypes as the header declares parameters
+    flat = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for name, params in re.findall(r"\b(m4d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", flat):
+        n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        assert n == len(_lib.SIGNATURES[name][1]), f"{name}: header has {n} parameters, binding {len(_lib.SIGNATURES[name][1])}"
 
 
 def test_product_path_fails_loudly_without_gpu():
