@@ -29,6 +29,13 @@ class SequenceParallelGroup:
         dist.all_gather(parts, x, group=self.group)
         return torch.cat(parts, dim=dim)
 
+    def _gather_into(self, dst, src):
+        """One flat all-gather (RCCL: a single collective into a contiguous buffer); list form for backends without it."""
+        try:
+            dist.all_gather_into_tensor(dst, src, group=self.group)
+        except (RuntimeError, NotImplementedError, AttributeError):
+            dist.all_gather(list(dst.unbind(0)), src, group=self.group)
+
     def gather_kv(self, k, vt, B, Ls, C, key_len):
         """k: T [B*Ls, C] (this rank's keys after RMSNorm+RoPE), vt: T [C, B*Ls].  Returns one KV segment per
         rank; segment r covers global tokens [r*Ls, (r+1)*Ls) of each sample, of which
@@ -36,8 +43,8 @@ class SequenceParallelGroup:
         W = self.world_size
         kg = torch.empty((W,) + tuple(k.shape), device=k.device, dtype=k.dtype)
         vg = torch.empty((W,) + tuple(vt.shape), device=vt.device, dtype=vt.dtype)
-        dist.all_gather(list(kg.unbind(0)), k.contiguous(), group=self.group)
-        dist.all_gather(list(vg.unbind(0)), vt.contiguous(), group=self.group)
+        self._gather_into(kg, k.contiguous())
+        self._gather_into(vg, vt.contiguous())
         segs = []
         for r in range(W):
             n = max(0, min(Ls, key_len - r * Ls))
