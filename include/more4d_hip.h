@@ -55,6 +55,19 @@ int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t
                 int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                 const float* gate, int64_t gate_stride, int64_t rows_per_sample, m4d_stream stream);
 
+/* Weight pre-shuffle for the production GEMM.  m4d_pack_frag re-lays a row-major bf16 matrix W[rows, K] (an nn.Linear
+ * weight) out ONCE into MFMA fragment order: out[rb = row/32][kb = k/16][lane][8], lane (li, hi) holding
+ * W[rb*32+li][kb*16+hi*8 .. +8); rows are zero-padded to 32 (out has m4d_pack_frag_elems(rows, K) elements).
+ * m4d_gemm_bt_packed is m4d_gemm_bt with that operand packed: packed_side 0 = W (the N side, ordinary Linear),
+ * 1 = A (the M side: V^T = W_v x^T); the other operand stays row-major.  The packed fragments stream straight into
+ * VGPRs, only the activation tile uses the global->LDS DMA path (the measured limiter of the unpacked kernel).
+ * bf16 only, K % 64 == 0. */
+int64_t m4d_pack_frag_elems(int64_t rows, int64_t K);
+int m4d_pack_frag(m4d_dtype dt, const void* W, int64_t ld, void* out, int64_t rows, int64_t K, m4d_stream stream);
+int m4d_gemm_bt_packed(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, int packed_side,
+                       const void* bias, int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                       int epilogue, const float* gate, int64_t gate_stride, int64_t rows_per_sample, m4d_stream stream);
+
 /* LayerNorm (no affine | affine) * (1 + scale) + shift, optional spatial guidance, cast to T.
  * Replaces WanLayerNorm + modulation (:662, :677, :720), norm3 (:611-613, :674), the LayerNorms of
  * MLPProj (:729-732) and SpatialGuidanceModule.forward (:757-783).

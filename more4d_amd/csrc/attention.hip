@@ -282,9 +282,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_kernel(Att
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
-__global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
+// NW waves (32 queries each) share every K/V^T tile: NW = 8 doubles the flops per DMA'd byte vs two 4-wave workgroups
+// per CU (256 flop/B instead of 128; the global->LDS path is the scarce resource).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
     typedef bf16_t T;
-    constexpr int D = 128, KVB = 64, STAGE = 32768, VOFF = 16384;
+    constexpr int D = 128, KVB = 64, STAGE = 32768, VOFF = 16384, QB = NW * 32, IPW = 16 / NW;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int HB = p.heads * p.B;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
     }
     const int b = hb / p.heads, h = hb % p.heads;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, hi = lane >> 5;
-    const int64_t qrow = (int64_t)qt * 128 + wave * 32 + li;
+    const int64_t qrow = (int64_t)qt * QB + wave * 32 + li;
     const bool qvalid = qrow < p.Lq;
 
     bf16x8 qf[8];
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) voff[c] = VOFF + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
     }
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_AS char*)smem;
     // DMA lane roles: K instr = 4 rows x 256 B, V^T instr = 8 rows x 128 B; wave w issues instr w*4 .. w*4+3 of each
     const int k_r = lane >> 4, k_lc0 = lane & 15;     // row within the 4-row group, physical chunk
     const int v_r = lane >> 3, v_pc = lane & 7;
@@ -344,8 +348,8 @@ __global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
         const int64_t kls = p.kv.k_ls[s], vls = p.kv.vt_ls[s];
         char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int blk = wave * 4 + i;
+        for (int i = 0; i < IPW; ++i) {
+            const int blk = wave * IPW + i;
             const int krow = blk * 4 + k_r;                       // 0..63
             const int klc = k_lc0 ^ (krow & 15);
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(kp + krow * kls + klc * 8),
@@ -363,8 +367,8 @@ __global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
         const int64_t kls = p.kv.k_ls[s], vls = p.kv.vt_ls[s];
         char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = t + 256 * i;
+        for (int i = 0; i < 1024 / (NW * 64); ++i) {
+            const int c = t + NW * 64 * i;
             {
                 const int row = c >> 4, ch = c & 15;
                 const int64_t key = k0 + row;
@@ -412,20 +416,31 @@ __global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
             next_dma = nk0 + KVB <= p.kv.len[nseg_];
             if (next_dma) dma_tile(stage ^ 1, nseg_, nk0);
         }
-        const char* base = smem + stage * STAGE;
 
-        // ---- S^T = K Q^T ----
+        // ---- S^T = K Q^T ----  16 (kk, sub) steps; K fragments are read 4 steps ahead from inline asm with counted
+        // lgkmcnt (hipcc serialises ds_read -> lgkmcnt(0) -> MFMA here, exposing the LDS latency 16 times per phase)
         f32x16 s[2];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+        const unsigned sb = lds0 + stage * STAGE;
+        unsigned ka[8], va[4];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(base + koff[kk] + sub * 8192);
-                mma32(kf, qf[kk], s[sub]);
-            }
-        }
+        for (int kk = 0; kk < 8; ++kk) ka[kk] = sb + koff[kk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) va[c] = sb + voff[c];
+        bf16x8 fb0, fb1, fb2, fb3;
+#define M4D_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define M4D_LGKM(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define M4D_QK(B, KK, SUB, OFF, W) do { M4D_LGKM(W); mma32(B, qf[KK], s[SUB]); if ((KK) + 2 < 8) M4D_DSR(B, ka[((KK) + 2) & 7], OFF); } while (0)
+        M4D_DSR(fb0, ka[0], 0); M4D_DSR(fb1, ka[0], 8192); M4D_DSR(fb2, ka[1], 0); M4D_DSR(fb3, ka[1], 8192);
+        M4D_QK(fb0, 0, 0, 0, 3); M4D_QK(fb1, 0, 1, 8192, 3); M4D_QK(fb2, 1, 0, 0, 3); M4D_QK(fb3, 1, 1, 8192, 3);
+        M4D_QK(fb0, 2, 0, 0, 3); M4D_QK(fb1, 2, 1, 8192, 3); M4D_QK(fb2, 3, 0, 0, 3); M4D_QK(fb3, 3, 1, 8192, 3);
+        M4D_QK(fb0, 4, 0, 0, 3); M4D_QK(fb1, 4, 1, 8192, 3); M4D_QK(fb2, 5, 0, 0, 3); M4D_QK(fb3, 5, 1, 8192, 3);
+        M4D_QK(fb0, 6, 0, 0, 3); M4D_QK(fb1, 6, 1, 8192, 2); M4D_QK(fb2, 7, 0, 0, 1); M4D_QK(fb3, 7, 1, 8192, 0);
+        // first four V^T fragments start now and land under the softmax arithmetic
+        M4D_DSR(fb0, va[0], 0); M4D_DSR(fb1, va[0], 4096); M4D_DSR(fb2, va[0], 8192); M4D_DSR(fb3, va[0], 12288);
         if (cur_k0 + KVB > cur_len) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -464,18 +479,20 @@ __global__ __launch_bounds__(256, 2) void attn128_kernel(AttnArgs p) {
                 psum += pv;
             }
         l_run += psum;
-        // ---- O^T += V^T P^T ----
+        // ---- O^T += V^T P^T ----  16 (c, d) steps, V^T fragments 4 steps ahead
+        bf16x8 pf[4];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int si = 0; si < 2; ++si) {
-                const bf16x8 pf = pack8<T>(s[sub], si * 8);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(base + voff[sub * 2 + si] + d * 4096);
-                    mma32(vf, pf, o[d]);
-                }
-            }
+        for (int c = 0; c < 4; ++c) pf[c] = pack8<T>(s[c >> 1], (c & 1) * 8);
+        __builtin_amdgcn_sched_barrier(0);
+#define M4D_PV(B, C, DD, OFF, W) do { M4D_LGKM(W); mma32(B, pf[C], o[DD]); if ((C) + 1 < 4) M4D_DSR(B, va[((C) + 1) & 3], OFF); } while (0)
+        M4D_PV(fb0, 0, 0, 0, 3); M4D_PV(fb1, 0, 1, 4096, 3); M4D_PV(fb2, 0, 2, 8192, 3); M4D_PV(fb3, 0, 3, 12288, 3);
+        M4D_PV(fb0, 1, 0, 0, 3); M4D_PV(fb1, 1, 1, 4096, 3); M4D_PV(fb2, 1, 2, 8192, 3); M4D_PV(fb3, 1, 3, 12288, 3);
+        M4D_PV(fb0, 2, 0, 0, 3); M4D_PV(fb1, 2, 1, 4096, 3); M4D_PV(fb2, 2, 2, 8192, 3); M4D_PV(fb3, 2, 3, 12288, 3);
+        M4D_PV(fb0, 3, 0, 0, 3); M4D_PV(fb1, 3, 1, 4096, 2); M4D_PV(fb2, 3, 2, 8192, 1); M4D_PV(fb3, 3, 3, 12288, 0);
+#undef M4D_PV
+#undef M4D_QK
+#undef M4D_LGKM
+#undef M4D_DSR
         seg = nseg_;
         key0 = nk0;
         cur_dma = next_dma;
@@ -508,7 +525,18 @@ template <typename T>
 int launch(const AttnArgs& p, int D, hipStream_t st) {
     dim3 grid((unsigned)((int64_t)p.nq_tiles * p.heads * p.B)), block(256);
     if (sizeof(T) == 2 && D == 128 && !getenv("M4D_ATTN_GENERIC")) {
-        hipLaunchKernelGGL(attn128_kernel, grid, block, 0, st, p);
+        int64_t keys = 0;
+        for (int i = 0; i < p.kv.nseg; ++i) keys += p.kv.len[i] > 0 ? p.kv.len[i] : 0;
+        // 256-query workgroups (8 waves share each K/V tile) for long self-attention; short key loops (cross-attention)
+        // keep the 4-wave workgroups (measured: 1000 vs 924 TF at Lk = 21840, 657 vs 678 TF at Lk = 512)
+        const bool w8 = p.Lq > 1024 && keys >= 2048 && !getenv("M4D_ATTN_W4");
+        AttnArgs q = p;
+        if (w8) {
+            q.nq_tiles = (int)((p.Lq + 255) / 256);
+            hipLaunchKernelGGL(attn128_kernel<8>, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(512), 0, st, q);
+        } else {
+            hipLaunchKernelGGL(attn128_kernel<4>, grid, block, 0, st, q);
+        }
         return 0;
     }
     switch (D) {

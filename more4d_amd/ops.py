@@ -51,10 +51,38 @@ def _rows2d(t):
     return rows, ld
 
 
+class Packed:
+    """A weight re-laid-out by `pack_frag` (MFMA fragment order) together with its logical shape."""
+    __slots__ = ("data", "rows", "K")
+
+    def __init__(self, data, rows, K):
+        self.data, self.rows, self.K = data, rows, K
+
+
+def pack_frag(w):
+    """bf16 weight [rows, K] (row-strided) -> Packed (fragment order, rows padded to 32)."""
+    _dev(w)
+    rows, ld = _rows2d(w)
+    K = w.shape[-1]
+    lib = _lib.load()
+    out = torch.empty(lib.m4d_pack_frag_elems(rows, K), device=w.device, dtype=w.dtype)
+    check(lib.m4d_pack_frag(dt_code(w.dtype), _ptr(w), ld, _ptr(out), rows, K, _stream()), "m4d_pack_frag")
+    return Packed(out, rows, K)
+
+
+def packed_ok(M, N, K, dtype):
+    """Shapes the packed production kernel takes (otherwise callers use the row-major weight)."""
+    return dtype == torch.bfloat16 and K % 64 == 0 and M >= 512 and N >= 512
+
+
 def gemm_bt(a, w, bias=None, *, out=None, epilogue=EPI_STORE, gate=None, gate_stride=0, rows_per_sample=0,
             bias_on_m=False, out_rows_ld=None):
     """out = epilogue(a @ w^T + bias).  a [M,K] (row-strided), w [N,K] (row-strided).
-    EPI_RESID_GATE / EPI_STORE_F32 write float32 `out`; others write a.dtype."""
+    EPI_RESID_GATE / EPI_STORE_F32 write float32 `out`; others write a.dtype.
+    Either operand may be a `Packed` weight (pack_frag): the production bf16 kernel streams it from VGPRs."""
+    if isinstance(a, Packed) or isinstance(w, Packed):
+        return _gemm_bt_packed(a, w, bias, out=out, epilogue=epilogue, gate=gate, gate_stride=gate_stride,
+                               rows_per_sample=rows_per_sample, bias_on_m=bias_on_m)
     _dev(a, w, bias, out, gate)
     if a.dtype != w.dtype:
         raise TypeError(f"gemm_bt: A {a.dtype} vs W {w.dtype}")
@@ -81,6 +109,35 @@ def gemm_bt(a, w, bias=None, *, out=None, epilogue=EPI_STORE, gate=None, gate_st
     lib = _lib.load()
     check(lib.m4d_gemm_bt(dt_code(a.dtype), _ptr(a), lda, _ptr(w), ldw, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
                           M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _stream()), "m4d_gemm_bt")
+    return out
+
+
+def _gemm_bt_packed(a, w, bias, *, out, epilogue, gate, gate_stride, rows_per_sample, bias_on_m):
+    side = 1 if isinstance(a, Packed) else 0
+    pk, act = (a, w) if side else (w, a)
+    _dev(pk.data, act, bias, out, gate)
+    rows_act, ld_act = _rows2d(act)
+    K = act.shape[-1]
+    if pk.K != K:
+        raise ValueError(f"gemm_bt(packed): K mismatch {pk.K} vs {K}")
+    M, N = (pk.rows, rows_act) if side else (rows_act, pk.rows)
+    f32_out = epilogue in (EPI_RESID_GATE, EPI_STORE_F32)
+    if out is None:
+        if epilogue == EPI_RESID_GATE:
+            raise ValueError("gemm_bt: EPI_RESID_GATE needs the residual tensor as `out`")
+        out = torch.empty((M, N), device=act.device, dtype=torch.float32 if f32_out else act.dtype)
+    if out.dtype != (torch.float32 if f32_out else act.dtype):
+        raise TypeError("gemm_bt(packed): out dtype")
+    om, ldc = _rows2d(out)
+    if om != M or out.shape[-1] != N:
+        raise ValueError(f"gemm_bt(packed): out shape {tuple(out.shape)} vs M={M} N={N}")
+    if bias is not None and (bias.dtype != act.dtype or bias.numel() != (M if bias_on_m else N)):
+        raise ValueError("gemm_bt(packed): bias must have the activation dtype and N (or M) elements")
+    lib = _lib.load()
+    A_ptr, lda, W_ptr, ldw = (_ptr(pk.data), K, _ptr(act), ld_act) if side else (_ptr(act), ld_act, _ptr(pk.data), K)
+    check(lib.m4d_gemm_bt_packed(dt_code(act.dtype), A_ptr, lda, W_ptr, ldw, side, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
+                                 M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _stream()),
+          "m4d_gemm_bt_packed")
     return out
 
 

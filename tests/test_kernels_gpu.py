@@ -300,3 +300,32 @@ def test_cfg_euler_unary_add_bcast():
     assert torch.equal(o.unary(a.to(DEV), torch.bfloat16).cpu(), a.to(torch.bfloat16))
     e0, m = rnd(2, 6, 128, seed=4), rnd(1, 6, 128, seed=5)
     assert torch.equal(o.add_bcast(e0.to(DEV), m.to(DEV)).cpu(), e0 + m)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 520, 192), (515, 1028, 64), (768, 512, 320), (600, 2048, 1024)])
+def test_gemm_packed_weights(M, N, K):
+    """Production kernel with the weight pre-shuffled into MFMA fragment order (packed side 0 = W, 1 = A)."""
+    o = ops()
+    dt = torch.bfloat16
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = q(a, dt) @ q(w, dt).t() + q(b, dt)
+    ad, wd, bd = a.to(DEV, dt), w.to(DEV, dt), b.to(DEV, dt)
+    wp = o.pack_frag(wd)
+    out = o.gemm_bt(ad, wp, bd)
+    assert rel_err(out.float().cpu(), ref) < BF16_TOL
+    assert torch.equal(out, o.gemm_bt(ad, wd, bd))          # same products, same fp32 accumulation order per element? (K order)
+    out = o.gemm_bt(ad, wp, bd, epilogue=o.EPI_GELU_TANH)
+    assert rel_err(out.float().cpu(), torch.nn.functional.gelu(ref, approximate="tanh")) < BF16_TOL
+    # residual + gate epilogue
+    B, L = 2, M // 2
+    gate = rnd(B, 6, N, seed=4)
+    resid = rnd(B * L, N, seed=5)
+    r = resid.to(DEV).clone()
+    gd = gate.to(DEV)
+    o.gemm_bt(ad[:B * L], wp, bd, out=r, epilogue=o.EPI_RESID_GATE, gate=gd[:, 2], gate_stride=6 * N, rows_per_sample=L)
+    y = ref[:B * L].to(dt).float()
+    assert rel_err(r.cpu(), resid + y * gate[:, 2].repeat_interleave(L, dim=0)) < BF16_TOL
+    # packed operand on the M side with a per-row bias: V^T = W x^T + b[:, None]
+    outT = o.gemm_bt(wp, ad, bd, bias_on_m=True) if M % 4 == 0 else None
+    if outT is not None:
+        assert rel_err(outT.float().cpu(), (q(w, dt) @ q(a, dt).t()) + q(b, dt)[:, None]) < BF16_TOL

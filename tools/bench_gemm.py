@@ -34,6 +34,24 @@ def main():
         ms = s.elapsed_time(e) / n
         tf = 2 * M * N * K / ms / 1e9
         res[name] = dict(M=M, N=N, K=K, ms=round(ms, 4), tflops=round(tf, 1), relerr=err)
+        # packed-weight production kernel: weight side is W unless the weight is the M operand (v_t)
+        if name == "v_t":
+            pk = ops.pack_frag(a); args = (pk, w)
+        else:
+            pk = ops.pack_frag(w); args = (a, pk)
+        kw = dict(bias_on_m=True) if name == "v_t" else {}
+        bb = torch.randn(M if name == "v_t" else N, device=dev, dtype=torch.bfloat16)
+        out2 = ops.gemm_bt(*args, bb, **kw)
+        ref2 = ops.gemm_bt(a, w, bb, **kw)
+        res[name]["packed_equal"] = bool(torch.equal(out2, ref2))
+        for _ in range(5):
+            ops.gemm_bt(*args, bb, out=out2, **kw)
+        torch.cuda.synchronize(); s.record()
+        for _ in range(n):
+            ops.gemm_bt(*args, bb, out=out2, **kw)
+        e.record(); torch.cuda.synchronize()
+        ms2 = s.elapsed_time(e) / n
+        res[name]["packed_ms"] = round(ms2, 4); res[name]["packed_tflops"] = round(2 * M * N * K / ms2 / 1e9, 1)
         print(name, res[name], flush=True)
     print(json.dumps(res))
 
