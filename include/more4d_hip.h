@@ -44,7 +44,7 @@ typedef enum {
 
 /* C[M,N] = A[M,K] * W[N,K]^T (+ bias) with a fused epilogue.  Replaces every nn.Linear and the
  * kernel==stride convs (patch_embedding :898-899, ref_conv :946) of the DiT, the 1x1(x1) convs of the
- * VAE, and (through m4d_im2col_*) its 3x3(x3) convs.
+ * VAE's attention block (its 3x3(x3) convs are m4d_conv_cl).
  *   A: T [M,K] row stride lda; W: T [N,K] row stride ldw (nn.Linear weight layout);
  *   bias: T [N] (or T [M] when bias_on_m != 0), may be NULL;
  *   out: T [M,N] (STORE/GELU/SILU) or float [M,N] (STORE_F32), row stride ldc;
@@ -187,6 +187,16 @@ int m4d_cl_to_ncthw(m4d_dtype src_dt, const void* src, int64_t src_pixel_stride,
 /* out[b, i] = a[b, i] + bias[i]  (float32; a: [B, n], bias: [n]) — `(self.modulation + e)` of
  * WanAttentionBlock (:659) and Head (:718). */
 int m4d_add_bcast(const float* a, const float* bias, float* out, int64_t B, int64_t n, m4d_stream stream);
+
+/* TeaCache step skipping (cache_utils.py:19-74, wan_transformer4d.py:1201-1270), all float32:
+ * axpby: out = a*x + b*y (residual re-use x + r, residual capture x_out - x_in);
+ * rel_l1: out2 = { sum|cur - prev|, sum|prev| } over the modulated timestep embedding [B,6,C]. */
+int m4d_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, m4d_stream stream);
+int m4d_rel_l1(const float* prev, const float* cur, float* out2, int64_t n, m4d_stream stream);
+
+/* Bilinear resize, align_corners=False, of a channels-last map [B,Hi,Wi,C] -> [B,Ho,Wo,C]: the OmniMAE feature map
+ * of the Motion Perception Module resized to the latent token grid (wan_transformer4d.py:1152). */
+int m4d_bilinear_cl(m4d_dtype dt, const void* x, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, m4d_stream stream);
 
 #ifdef __cplusplus
 }

@@ -258,6 +258,49 @@ __global__ __launch_bounds__(256) void add_bcast_kernel(const float* a, const fl
         out[i] = a[i] + bias[i % n];
 }
 
+// out = a*x + b*y (float32): TeaCache residual add / subtract (wan_transformer4d.py:1226, 1268-1270)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float* out, int64_t n, float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + b * y[i];
+}
+
+// out[0] = sum|cur - prev|, out[1] = sum|prev| (one workgroup; TeaCache's relative-L1 on the [B,6,C] modulation, cache_utils.py)
+__global__ __launch_bounds__(1024) void rel_l1_kernel(const float* prev, const float* cur, float* out, int64_t n) {
+    __shared__ float rd[16], rp[16];
+    float d = 0.f, pp = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) { d += fabsf(cur[i] - prev[i]); pp += fabsf(prev[i]); }
+    d = wave_sum(d); pp = wave_sum(pp);
+    if ((threadIdx.x & 63) == 0) { rd[threadIdx.x >> 6] = d; rp[threadIdx.x >> 6] = pp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < 16; ++i) { a += rd[i]; b += rp[i]; }
+        out[0] = a; out[1] = b;
+    }
+}
+
+// bilinear resize (align_corners = False, torch semantics) of a channels-last map [B, Hi, Wi, C] -> [B, Ho, Wo, C]
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_cl_kernel(const T* x, T* out, int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    const float sh = (float)Hi / Ho, sw = (float)Wi / Wo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float fy = fmaxf((ho + 0.5f) * sh - 0.5f, 0.f), fx = fmaxf((wo + 0.5f) * sw - 0.5f, 0.f);
+        const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+        const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+        const float ly = fy - y0, lx = fx - x0;
+        const T* xb = x + (int64_t)b * Hi * Wi * C + c;
+        const float v00 = (float)xb[((int64_t)y0 * Wi + x0) * C], v01 = (float)xb[((int64_t)y0 * Wi + x1) * C];
+        const float v10 = (float)xb[((int64_t)y1 * Wi + x0) * C], v11 = (float)xb[((int64_t)y1 * Wi + x1) * C];
+        out[i] = (T)((1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11));
+    }
+}
+
 inline unsigned grid_for(int64_t n, int per_block = 256) {
     int64_t g = (n + per_block - 1) / per_block;
     if (g > 2048 * 4) g = 2048 * 4;
@@ -393,5 +436,30 @@ extern "C" int m4d_add_bcast(const float* a, const float* bias, float* out, int6
     dim3 block(256), grid(grid_for(B * n));
     hipLaunchKernelGGL(add_bcast_kernel, grid, block, 0, (hipStream_t)stream, a, bias, out, B * n, n);
     M4D_CHECK_LAUNCH("add_bcast");
+    return 0;
+}
+
+extern "C" int m4d_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, m4d_stream stream) {
+    M4D_CHECK_ARG(x && y && out && n > 0, "axpby: null/empty");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, out, n, a, b);
+    M4D_CHECK_LAUNCH("axpby");
+    return 0;
+}
+
+extern "C" int m4d_rel_l1(const float* prev, const float* cur, float* out2, int64_t n, m4d_stream stream) {
+    M4D_CHECK_ARG(prev && cur && out2 && n > 0, "rel_l1: null/empty");
+    hipLaunchKernelGGL(rel_l1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, prev, cur, out2, n);
+    M4D_CHECK_LAUNCH("rel_l1");
+    return 0;
+}
+
+extern "C" int m4d_bilinear_cl(m4d_dtype dt, const void* x, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                               m4d_stream stream) {
+    M4D_CHECK_ARG(x && out && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_cl: null/empty");
+    dim3 grid(grid_for((int64_t)B * Ho * Wo * C)), block(256);
+    if (dt == M4D_BF16) hipLaunchKernelGGL(bilinear_cl_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, B, Hi, Wi, Ho, Wo, C);
+    else if (dt == M4D_F32) hipLaunchKernelGGL(bilinear_cl_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)out, B, Hi, Wi, Ho, Wo, C);
+    else { m4d_set_error("bilinear_cl: bad dtype"); return -1; }
+    M4D_CHECK_LAUNCH("bilinear_cl");
     return 0;
 }

@@ -596,8 +596,6 @@ class WanTransformer4DModel(nn.Module):
             raise NotImplementedError("y_camera / subject_ref are not part of the 4D-STraG path")
         if t.dim() != 1:
             raise NotImplementedError("per-token timesteps (ti2v) are not part of the 4D-STraG path")
-        if self.teacache is not None:
-            raise NotImplementedError("TeaCache step skipping is a 'next' row (SURVEY §8f rank 1), not built yet")
         if first_frame is not None and self.use_omnimae_guidance and first_frame_features is None:
             raise NotImplementedError("pass OmniMAE outputs via first_frame_features=(patch_feats, cls); the ViT-B "
                                       "extractor is outside the hot path (SURVEY §8f rank 3)")
@@ -653,8 +651,45 @@ class WanTransformer4DModel(nn.Module):
             c = _Ctx(B, L, Lp, grid, cos, sin, L, self._f32cache, key_len)
         if guid is not None and sp is not None:
             raise NotImplementedError("spatial guidance with sequence parallelism")
-        for i, block in enumerate(self.blocks):
-            block.run(xres, e0, c, cc, i, guid)
+        # ---- TeaCache (reference :1201-1270): skip the blocks when the accumulated, rescaled relative-L1 change of the
+        # modulated timestep embedding stays under the threshold, re-using the previous residual of the token stream
+        should_calc = True
+        tc = self.teacache
+        if tc is not None:
+            if cond_flag:
+                if tc.cnt < tc.num_skip_start_steps or tc.previous_modulated_input is None:
+                    should_calc = True
+                    tc.accumulated_rel_l1_distance = 0
+                else:
+                    rel = ops.rel_l1(tc.previous_modulated_input, e0)
+                    tc.accumulated_rel_l1_distance += float(tc.rescale_func(rel))
+                    if tc.accumulated_rel_l1_distance < tc.rel_l1_thresh:
+                        should_calc = False
+                    else:
+                        tc.accumulated_rel_l1_distance = 0
+                tc.previous_modulated_input = e0.clone()
+                tc.should_calc = should_calc
+            else:
+                should_calc = tc.should_calc
+            prev = tc.previous_residual_cond if cond_flag else tc.previous_residual_uncond
+            if prev is None:
+                should_calc = True
+        if should_calc:
+            ori = xres.clone() if tc is not None else None
+            for i, block in enumerate(self.blocks):
+                block.run(xres, e0, c, cc, i, guid)
+            if tc is not None:      # residual stays in HBM (288 GB) — the reference's `offload` flag is accepted and ignored
+                res_ = ops.axpby(xres, ori, 1.0, -1.0)
+                if cond_flag:
+                    tc.previous_residual_cond = res_
+                else:
+                    tc.previous_residual_uncond = res_
+        else:
+            xres = ops.axpby(xres, prev[-xres.size(0):].contiguous(), 1.0, 1.0)
+        if tc is not None and cond_flag:
+            tc.cnt += 1
+            if tc.cnt == tc.num_steps:
+                tc.reset()
         out = self.head.run(xres, e, self._f32cache)          # float32 [B, Lp or Ls, 64]
         if sp is not None:
             out = sp.all_gather(out, dim=1)
@@ -669,10 +704,37 @@ class WanTransformer4DModel(nn.Module):
         patch, cls = feats
         T = self.dtype
         h, w = hw
+        if patch.dim() == 3 and patch.shape[1] == 196 and hasattr(self, "feature_adapter"):
+            patch = self._adapt_features(patch, hw)          # raw OmniMAE 14x14 patch features (:1150-1152)
         if patch.dim() != 3 or patch.shape[1] != h * w or patch.shape[2] != self.dino_dim:
-            raise NotImplementedError("first_frame_features must be adapter outputs resized to [B, h*w, 768]")
+            raise ValueError("first_frame_features: expected OmniMAE patch features [B,196,768] or adapted [B,h*w,768]")
         src = cls.view(cls.shape[0], 1, -1).expand(-1, h * w, -1) if self.use_cls_token else patch
         return ops.unary(src.to(self.device).contiguous(), T, act=1), h * w, latent_T * h * w
+
+    def _adapt_features(self, patch, hw):
+        """feature_adapter (Conv3x3 - SiLU - Conv3x3 on the 14x14 map) + bilinear resize to the token grid (reference
+        :889-893, :1150-1152).  [B,196,768] is already channels-last [B,14,14,768]."""
+        T, dev = self.dtype, self.device
+        B = patch.shape[0]
+        x = patch.to(device=dev, dtype=T).contiguous().view(B * 196, self.dino_dim)
+
+        def packed(conv):
+            key = (conv.weight._version, conv.weight.data_ptr(), T)
+            hit = self._f32cache.get(("pk", id(conv)))
+            if hit is None or hit[0] != key:
+                wp = conv.weight.detach().to(T).permute(0, 2, 3, 1).contiguous().view(conv.weight.shape[0], -1)
+                hit = (key, wp, conv.bias.detach().to(T).contiguous())
+                self._f32cache[("pk", id(conv))] = hit
+            return hit[1], hit[2]
+
+        for j, conv in ((0, self.feature_adapter[0]), (2, self.feature_adapter[2])):
+            wp, bp = packed(conv)
+            x = ops.conv_cl(x, wp, bp, Tin=B, Hin=14, Win=14, Cin=self.dino_dim, k=(1, 3, 3), pad=(0, 1, 1),
+                            out_thw=(B, 14, 14))
+            if j == 0:
+                x = ops.unary(x, T, act=1)
+        y = ops.bilinear_cl(x.view(B, 14, 14, self.dino_dim), hw)
+        return y.view(B, hw[0] * hw[1], self.dino_dim)
 
     def unpatchify(self, x, grid_sizes):
         """Reference-compatible helper (:1343-1366) for callers that hold head outputs: x list of [L, 64]."""

@@ -405,3 +405,41 @@ def cl_to_ncthw(src, out_dtype, *, C, T, H, W, pixel_stride, scale=1.0, shift=0.
                               float(scale), float(shift), _ptr(ch_scale), _ptr(ch_shift), act, _ptr(aux), _stream()),
           "m4d_cl_to_ncthw")
     return out
+
+
+# ------------------------------------------------------------------ TeaCache / guidance helpers
+
+def axpby(x, y, a=1.0, b=1.0, out=None):
+    """float32 out = a*x + b*y."""
+    _dev(x, y, out)
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.numel() != y.numel():
+        raise TypeError("axpby: float32 tensors of equal size")
+    x, y = x.contiguous(), y.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    check(lib.m4d_axpby(_ptr(x), _ptr(y), _ptr(out), x.numel(), float(a), float(b), _stream()), "m4d_axpby")
+    return out
+
+
+def rel_l1(prev, cur):
+    """(|cur-prev|.mean() / |prev|.mean()) as a python float (host sync, like the reference's .cpu().item())."""
+    _dev(prev, cur)
+    prev, cur = prev.contiguous().float(), cur.contiguous().float()
+    out = torch.empty(2, device=prev.device, dtype=torch.float32)
+    lib = _lib.load()
+    check(lib.m4d_rel_l1(_ptr(prev), _ptr(cur), _ptr(out), prev.numel(), _stream()), "m4d_rel_l1")
+    d, p_ = out.cpu().tolist()
+    return d / p_
+
+
+def bilinear_cl(x, out_hw):
+    """x [B, Hi, Wi, C] channels-last -> [B, Ho, Wo, C] (bilinear, align_corners=False)."""
+    _dev(x)
+    x = x.contiguous()
+    B, Hi, Wi, C = x.shape
+    out = torch.empty((B, out_hw[0], out_hw[1], C), device=x.device, dtype=x.dtype)
+    lib = _lib.load()
+    check(lib.m4d_bilinear_cl(dt_code(x.dtype), _ptr(x), _ptr(out), B, Hi, Wi, out_hw[0], out_hw[1], C, _stream()),
+          "m4d_bilinear_cl")
+    return out

@@ -282,3 +282,23 @@ def cl_to_ncthw(src, out_dtype, *, C, T, H, W, pixel_stride, scale=1.0, shift=0.
     elif act == 2:
         v = torch.sigmoid(v + aux.float().view(C, T, H, W))
     return v.to(out_dtype).contiguous()
+
+
+NAMES += ["axpby", "rel_l1", "bilinear_cl"]
+
+
+def axpby(x, y, a=1.0, b=1.0, out=None):
+    r = a * x + b * y
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
+def rel_l1(prev, cur):
+    return float((cur.float() - prev.float()).abs().mean() / prev.float().abs().mean())
+
+
+def bilinear_cl(x, out_hw):
+    y = F.interpolate(x.float().permute(0, 3, 1, 2), size=tuple(out_hw), mode="bilinear", align_corners=False)
+    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)

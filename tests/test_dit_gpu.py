@@ -133,3 +133,30 @@ def test_scheduler_step_matches_golden():
     x1 = sch.step(z["v"].to(DEV), sch.timesteps[0], z["x"].to(DEV), return_dict=False)[0]
     x2 = sch.step(z["v"].to(DEV), sch.timesteps[1], x1, return_dict=False)[0]
     assert rel_err(x1.cpu(), z["x1"]) < 1e-5 and rel_err(x2.cpu(), z["x2"]) < 1e-5
+
+
+def test_teacache_and_small_kernels():
+    """axpby / rel_l1 / bilinear kernels vs torch, and TeaCache control flow on the device."""
+    import torch.nn.functional as F
+    from more4d_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(1000, 33, generator=g), torch.randn(1000, 33, generator=g)
+    assert rel_err(ops.axpby(x.to(DEV), y.to(DEV), 1.0, -1.0).cpu(), x - y) < 1e-6
+    assert abs(ops.rel_l1(x.to(DEV), y.to(DEV)) - float((y - x).abs().mean() / x.abs().mean())) < 1e-4
+    f = torch.randn(2, 14, 14, 96, generator=g)
+    ref = F.interpolate(f.permute(0, 3, 1, 2), size=(30, 52), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    assert rel_err(ops.bilinear_cl(f.to(DEV), (30, 52)).cpu(), ref) < 1e-5
+    z = load_npz("dit_tiny.npz")
+    m = tiny_model()
+    args = dict(x=z["x"].to(DEV), context=[z["ctx0"].to(DEV), z["ctx1"].to(DEV)], seq_len=int(z["seq_len"]),
+                clip_fea=z["clip"].to(DEV), y=z["y"].to(DEV))
+    with torch.no_grad():
+        base2 = m(t=z["t"].to(DEV) - 30, **args)
+        m.enable_teacache([1.0, 0.0], num_steps=4, rel_l1_thresh=0.0, num_skip_start_steps=1)
+        m(t=z["t"].to(DEV), **args)
+        b = m(t=z["t"].to(DEV) - 30, **args)
+        assert rel_err(b.cpu(), base2.cpu()) < 1e-5
+        m.enable_teacache([1.0, 0.0], num_steps=4, rel_l1_thresh=1e9, num_skip_start_steps=1)
+        a = m(t=z["t"].to(DEV), **args)
+        b = m(t=z["t"].to(DEV) - 30, **args)
+        assert torch.isfinite(b).all() and rel_err(b.cpu(), a.cpu()) < 0.5

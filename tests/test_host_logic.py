@@ -156,3 +156,44 @@ def test_sequence_parallel_equals_single_rank(world):
         p.join(60)
         assert p.exitcode == 0
     assert err < 1e-4
+
+
+def test_teacache_and_guidance_adapter_host_logic(monkeypatch):
+    """TeaCache: threshold 0 must reproduce the plain forward; a huge threshold must re-use the residual (second call
+    == first call + nothing recomputed).  Guidance adapter: conv-SiLU-conv + bilinear resize equals torch's."""
+    import torch.nn.functional as F
+    from more4d_amd.models import WanTransformer4DModel
+    cpu_ops.install(monkeypatch)
+    z = load_npz("dit_tiny.npz")
+    m = WanTransformer4DModel(**TINY)
+    m.load_state_dict(fill(load_keys("dit_tiny_keys.json"), 1234))
+    m.eval()
+    args = dict(x=z["x"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len"]), clip_fea=z["clip"], y=z["y"])
+    with torch.no_grad():
+        base = m(t=z["t"], **args)
+        base2 = m(t=z["t"] - 30, **args)
+        m.enable_teacache([1.0, 0.0], num_steps=4, rel_l1_thresh=0.0, num_skip_start_steps=1)
+        a = m(t=z["t"], **args)
+        b = m(t=z["t"] - 30, **args)                       # threshold 0: always recomputed
+        assert rel_err(a, base) < 1e-6 and rel_err(b, base2) < 1e-6
+        m.enable_teacache([1.0, 0.0], num_steps=4, rel_l1_thresh=1e9, num_skip_start_steps=1)
+        a = m(t=z["t"], **args)
+        calls = []
+        orig = m.blocks[0].run
+        m.blocks[0].run = lambda *aa, **kk: calls.append(1) or orig(*aa, **kk)
+        b = m(t=z["t"] - 30, **args)                       # skipped: blocks not executed, residual re-used
+        assert not calls
+        assert torch.isfinite(b).all() and rel_err(b, a) < 0.5
+        m.disable_teacache()
+    # guidance adapter
+    g = WanTransformer4DModel(**{**TINY, "use_omnimae_guidance": True})
+    g.eval()
+    gen = torch.Generator().manual_seed(0)
+    for p_ in g.feature_adapter.parameters():
+        p_.data = torch.randn(p_.shape, generator=gen) * 0.02
+    feats = torch.randn(2, 196, 768, generator=gen)
+    with torch.no_grad():
+        mine = g._adapt_features(feats, (6, 9))
+        ref = g.feature_adapter(feats.view(2, 14, 14, 768).permute(0, 3, 1, 2))
+        ref = F.interpolate(ref, size=(6, 9), mode="bilinear", align_corners=False).flatten(2).transpose(1, 2)
+    assert rel_err(mine, ref) < 1e-5
