@@ -36,6 +36,30 @@ class SequenceParallelGroup:
         except (RuntimeError, NotImplementedError, AttributeError):
             dist.all_gather(list(dst.unbind(0)), src, group=self.group)
 
+    def gather_start(self, x):
+        """Begin an all-gather of this rank's shard; returns (gathered buffer [W, *x.shape], work handle).  The
+        collective runs on RCCL's stream after the work already enqueued on the current stream, so the caller can keep
+        launching kernels (the next projection GEMM) while the shards travel over xGMI."""
+        x = x.contiguous()
+        buf = torch.empty((self.world_size,) + tuple(x.shape), device=x.device, dtype=x.dtype)
+        try:
+            work = dist.all_gather_into_tensor(buf, x, group=self.group, async_op=True)
+        except (RuntimeError, NotImplementedError, AttributeError):
+            work = dist.all_gather(list(buf.unbind(0)), x, group=self.group, async_op=True)
+        return buf, work, x
+
+    def gather_finish(self, hk, hv, B, Ls, C, key_len):
+        """Wait for both gathers (the current stream waits, not the host) and describe one K/V segment per rank."""
+        (kg, wk, _), (vg, wv, _) = hk, hv
+        for w in (wk, wv):
+            if w is not None:
+                w.wait()
+        segs = []
+        for r in range(self.world_size):
+            n = max(0, min(Ls, key_len - r * Ls))
+            segs.append(KV(kg[r].reshape(-1), vg[r], Ls * C, C, Ls, B * Ls, n))
+        return segs
+
     def gather_kv(self, k, vt, B, Ls, C, key_len):
         """k: T [B*Ls, C] (this rank's keys after RMSNorm+RoPE), vt: T [C, B*Ls].  Returns one KV segment per
         rank; segment r covers global tokens [r*Ls, (r+1)*Ls) of each sample, of which

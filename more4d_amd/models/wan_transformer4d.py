@@ -123,19 +123,27 @@ class WanSelfAttention(nn.Module):
         """xn: T [B, Lp, C] modulated input; accumulates o-proj * gate into xres (float32) in place."""
         B, Lp, C = xn.shape
         n, d = self.num_heads, self.head_dim
-        q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
-        k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
-        vt = ops.gemm_bt(self.v.weight, xn, self.v.bias, bias_on_m=True)          # V^T [C, B*Lp]
-        if self.qk_norm:
-            wq, wk = _f32(self.norm_q.weight, c.f32cache), _f32(self.norm_k.weight, c.f32cache)
-            ops.rmsnorm_rope(q, wq, k, wk, head_dim=d, eps=self.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp,
-                             rope_len=c.rope_len, pos_offset=c.pos_offset)
-        else:  # no norm configured: rope only is not a reference configuration for Wan checkpoints
+        if not self.qk_norm:  # rope without norm is not a reference configuration for Wan checkpoints
             raise NotImplementedError("qk_norm=False is not supported by the fused rmsnorm+rope kernel")
+        wq, wk = _f32(self.norm_q.weight, c.f32cache), _f32(self.norm_k.weight, c.f32cache)
+        rope = dict(head_dim=d, eps=self.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
+                    pos_offset=c.pos_offset)
         if c.sp is None or c.sp.world_size == 1:
+            q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
+            k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
+            vt = ops.gemm_bt(self.v.weight, xn, self.v.bias, bias_on_m=True)          # V^T [C, B*Lp]
+            ops.rmsnorm_rope(q, wq, k, wk, **rope)
             segs = [KV(k, vt, Lp * C, C, Lp, B * Lp, c.key_len)]
         else:
-            segs = c.sp.gather_kv(k, vt, B, Lp, C, c.key_len)
+            # T-sharded: K and V^T are all-gathered over xGMI while the next projections run (async collectives)
+            k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
+            ops.rmsnorm_rope(k, wk, **rope)
+            hk = c.sp.gather_start(k)
+            vt = ops.gemm_bt(self.v.weight, xn, self.v.bias, bias_on_m=True)
+            hv = c.sp.gather_start(vt)
+            q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
+            ops.rmsnorm_rope(q, wq, **rope)
+            segs = c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)
         o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
         ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=gate,
                     gate_stride=gate_stride, rows_per_sample=Lp)
