@@ -253,6 +253,98 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256_kernel(GemmArgs p) {
     }
 }
 
+// ============================================================================ 256x256, staggered operand rings
+// Same tile / waves / MFMA loop as gemm_bt256_kernel, but the two operands use SEPARATE LDS rings of different depth:
+// A (activations) 3 slots, W 2 slots = 5 x 32 KiB = all 160 KiB of the CU's LDS.  Per iteration a wave issues the DMA of
+// W(t+1) and A(t+2): at the next barrier only W(t+1) (32 KiB per CU, not 64) must have drained; the A tile always has a
+// whole extra iteration in flight.  vmcnt(4) retires everything except the newest A batch (in-order counter).
+constexpr int SLOT3 = 256 * ROWB;      // 32 KiB per operand slot
+
+__global__ __launch_bounds__(512, 2) void gemm_bt256s_kernel(GemmArgs p) {
+    typedef bf16_t T;
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = (int)(p.K / 64);
+    const int lrow = lane >> 3, pc = lane & 7;
+    const T* ga[4];
+    const T* gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 8 + wave) * 8 + lrow;
+        const int lc = pc ^ ((row >> 1) & 7);
+        ga[i] = (const T*)p.A + min(m0 + row, p.M - 1) * p.lda + lc * 8;
+        gw[i] = (const T*)p.W + min(n0 + row, p.N - 1) * p.ldw + lc * 8;
+    }
+    auto issue_a = [&](int kt, int slot) {
+        const int kc = min(kt, nk - 1);
+        char* s_ = dyn_smem + slot * SLOT3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(ga[i] + kc * 64), (LDS_AS void*)(s_ + (i * 8 + wave) * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&](int kt) {
+        const int kc = min(kt, nk - 1);
+        char* s_ = dyn_smem + (3 + (kt & 1)) * SLOT3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(gw[i] + kc * 64), (LDS_AS void*)(s_ + (i * 8 + wave) * 1024), 16, 0, 0);
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        aoff[kk] = lds_off(wm * 128 + li, kk * 2 + hi);
+        woff[kk] = lds_off(wn * 64 + li, kk * 2 + hi);
+    }
+    issue_a(0, 0);
+    issue_w(0);
+    issue_a(1, 1);
+    int aslot = 0;                       // kt % 3
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_w(kt + 1);
+        issue_a(kt + 2, aslot == 0 ? 2 : aslot - 1);      // (kt + 2) % 3
+        const char* sA = dyn_smem + aslot * SLOT3;
+        const char* sW = dyn_smem + (3 + (kt & 1)) * SLOT3;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[4], fw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sW + woff[kk] + i * 4096);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + aoff[kk] + i * 4096);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma32(fw[ni], fa[mi], acc[ni][mi]);
+        }
+        aslot = aslot == 2 ? 0 : aslot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const T* bias = (const T*)p.bias;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 128 + mi * 32 + li;
+        if (m >= p.M) continue;
+        const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;
+        const float* grow = (p.epilogue == M4D_EPI_RESID_GATE && p.gate) ? p.gate + (m / p.rows_per_sample) * p.gate_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) epilogue_tile<T>(p, acc[ni][mi], m, n0 + wn * 64 + ni * 32, hi, bm, grow);
+    }
+}
+
 // ============================================================================ 256x256, ping-pong wave groups
 // Same tile and wave layout, but the K loop is cut into K=32 slices held in a 4-slot LDS ring (4 x 32 KiB) and the
 // two wave groups (waves 0-3 = upper 128 rows, waves 4-7 = lower 128 rows; one wave of each group per SIMD) run ONE
@@ -390,12 +482,15 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)gemm_bt256pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)gemm_bt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * SLOT3);
             if (e != hipSuccess) { variant = -1; m4d_set_error("gemm_bt: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -3; }
         }
         p.tiles_m = (int)((M + BM2 - 1) / BM2); p.tiles_n = (int)((N + BN2 - 1) / BN2);
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
         M4D_CHECK_ARG(nwg < (1ll << 31), "gemm_bt: too many tiles");
-        if (variant == 1) hipLaunchKernelGGL(gemm_bt256_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE2_BYTES, st, p);
+        if (variant == 3) hipLaunchKernelGGL(gemm_bt256s_kernel, dim3((unsigned)nwg), dim3(512), 5 * SLOT3, st, p);
+        else if (variant == 1) hipLaunchKernelGGL(gemm_bt256_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE2_BYTES, st, p);
         else hipLaunchKernelGGL(gemm_bt256pp_kernel, dim3((unsigned)nwg), dim3(512), 4 * SLOT_BYTES, st, p);
     } else {
         p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);

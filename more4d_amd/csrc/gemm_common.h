@@ -39,50 +39,83 @@ M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn) {
 }
 
 // Epilogue for one 32(n) x 32(m) accumulator tile: this lane holds column m, rows nb0 + 8*rq + 4*hi + [0,4).
+// bf16 outputs are widened to 16-byte stores: a v_permlane32_swap per dword exchanges the 4-column groups of the two
+// half-waves so lanes 0-31 own columns 16j..16j+7 and lanes 32-63 columns 16j+8..16j+15 of their row (cdna guide T21:
+// the store tail is issue-bound, half the instructions = half the tail).
 template <typename T>
 M4D_DEV void epilogue_tile(const GemmArgs& p, const f32x16& acc, int64_t m, int64_t nb0, int hi, float bias_m,
                            const float* grow) {
     const T* bias = (const T*)p.bias;
+    f32x4 v[4];
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
         const int64_t nb = nb0 + rq * 8 + hi * 4;
-        if (nb >= p.N) continue;
-        f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[rq * 4 + e];
+        for (int e = 0; e < 4; ++e) v[rq][e] = acc[rq * 4 + e];
         if (bias) {
-            if (p.bias_on_m) { v += bias_m; }
-            else { v += load4(bias + nb); }
+            if (p.bias_on_m) { v[rq] += bias_m; }
+            else if (nb < p.N) { v[rq] += load4(bias + nb); }
         }
         switch (p.epilogue) {
             case M4D_EPI_GELU_TANH:
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                for (int e = 0; e < 4; ++e) v[rq][e] = gelu_tanh_f(v[rq][e]);
                 break;
             case M4D_EPI_GELU_ERF:
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                for (int e = 0; e < 4; ++e) v[rq][e] = gelu_erf_f(v[rq][e]);
                 break;
             case M4D_EPI_SILU:
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                for (int e = 0; e < 4; ++e) v[rq][e] = silu_f(v[rq][e]);
                 break;
             default: break;
         }
-        if (p.epilogue == M4D_EPI_RESID_GATE) {
+    }
+    if (p.epilogue == M4D_EPI_RESID_GATE) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int64_t nb = nb0 + rq * 8 + hi * 4;
+            if (nb >= p.N) continue;
             float* r = (float*)p.out + m * p.ldc + nb;
             f32x4 x = load4(r);
             f32x4 g = {1.f, 1.f, 1.f, 1.f};
             if (grow) g = load4(grow + nb);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] += round_through<T>(v[e]) * g[e];
+            for (int e = 0; e < 4; ++e) x[e] += round_through<T>(v[rq][e]) * g[e];
             store4(r, x);
-        } else if (p.epilogue == M4D_EPI_STORE_F32) {
+        }
+    } else if (p.epilogue == M4D_EPI_STORE_F32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
-            store4((float*)p.out + m * p.ldc + nb, v);
-        } else {
-            store4((T*)p.out + m * p.ldc + nb, v);
+        for (int rq = 0; rq < 4; ++rq) {
+            const int64_t nb = nb0 + rq * 8 + hi * 4;
+            if (nb >= p.N) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[rq][e] = round_through<T>(v[rq][e]);
+            store4((float*)p.out + m * p.ldc + nb, v[rq]);
+        }
+    } else {
+        if constexpr (sizeof(T) == 2) {
+            if ((p.N & 7) == 0 && (p.ldc & 7) == 0) {     // both half-waves of a row take the same branch: N % 8 == 0
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    union { bf16x4 h; unsigned u[2]; } a, b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a.h[e] = (bf16_t)v[2 * j][e]; b.h[e] = (bf16_t)v[2 * j + 1][e]; }
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a.u[0], b.u[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a.u[1], b.u[1], false, false);
+                    const int64_t nb = nb0 + j * 16 + hi * 8;
+                    if (nb < p.N)
+                        *reinterpret_cast<uint4*>((T*)p.out + m * p.ldc + nb) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int64_t nb = nb0 + rq * 8 + hi * 4;
+            if (nb >= p.N) continue;
+            store4((T*)p.out + m * p.ldc + nb, v[rq]);
         }
     }
 }

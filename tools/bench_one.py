@@ -11,6 +11,8 @@ if kind == "gemm":
     a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
     w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * K ** -0.5
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    if os.environ.get("PACKED"):
+        w = ops.pack_frag(w)
     for _ in range(4):
         ops.gemm_bt(a, w, None, out=out)
 else:
