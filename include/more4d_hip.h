@@ -136,7 +136,7 @@ int m4d_unpatchify(const float* tok, int64_t tok_bs, int64_t tok_row0, m4d_dtype
 int m4d_cfg_euler(float* x, m4d_dtype v_dt, const void* v, int64_t n, float guidance, float dsigma,
                   m4d_dtype round_dt, m4d_stream stream);
 
-/* Elementwise helpers: out = act(x) with dtype conversion (act: 0 copy/cast, 1 silu, 2 gelu_tanh). */
+/* Elementwise helpers: out = act(x) with dtype conversion (act: 0 copy/cast, 1 silu, 2 gelu_tanh, 3 gelu_erf). */
 int m4d_unary(m4d_dtype in_dt, const void* x, m4d_dtype out_dt, void* out, int64_t n, int act,
               m4d_stream stream);
 
@@ -197,6 +197,87 @@ int m4d_rel_l1(const float* prev, const float* cur, float* out2, int64_t n, m4d_
 /* Bilinear resize, align_corners=False, of a channels-last map [B,Hi,Wi,C] -> [B,Ho,Wo,C]: the OmniMAE feature map
  * of the Motion Perception Module resized to the latent token grid (wan_transformer4d.py:1152). */
 int m4d_bilinear_cl(m4d_dtype dt, const void* x, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, m4d_stream stream);
+
+/* ------------------------------------------------------------------ training step (train_wan.py:1891-2015)
+ * Backward halves of the DiT kernels above and the fused optimizer update.  The reference gets these from torch
+ * autograd (accelerator.backward, :1988) and torch.optim.AdamW (:1136-1142, :2014); GEMM-shaped gradients
+ * (dgrad = dy W, wgrad = dy^T x) are m4d_gemm_bt calls on m4d_transpose'd operands. */
+
+/* m4d_attention that also writes lse[b, h, l] = log2(sum_j exp2(s_lj * scale * log2 e)) (float [B, heads, Lq]),
+ * the only forward state the backward needs besides q, k, v, out. */
+int m4d_attention_lse(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,
+                      int64_t o_bs, int64_t o_ls, int B, int64_t Lq, int heads, int head_dim, float scale,
+                      int accumulate, float* lse, m4d_stream stream);
+
+/* Flash-attention backward of softmax(q k^T scale) v (the autograd of flash_attn / SDPA, :138-169, :202-233).
+ * Row-major operands: element (b, l, h, d) at ptr + b*bs + l*ls + h*head_dim + d.  Transposed operands (qt, kt, dot =
+ * q^T, k^T, dO^T): element (b, h, d, l) at ptr + b*bs + (h*head_dim + d)*ls + l (what m4d_transpose of the [B*L, C]
+ * matrix produces with bs = L, ls = B*L).  Only the first Lk of the Lk_rows key rows are real keys; dk / dv rows in
+ * [Lk, Lk_rows) are written as zero.  delta: float workspace [B, heads, Lq]; lse from m4d_attention_lse. */
+typedef struct {
+    const void *q, *k, *v, *o, *d_o, *qt, *kt, *dot;
+    const float* lse;
+    float* delta;
+    void *dq, *dk, *dv;
+    int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, o_bs, o_ls, do_bs, do_ls;
+    int64_t qt_bs, qt_ls, kt_bs, kt_ls, dot_bs, dot_ls;
+    int64_t dq_bs, dq_ls, dk_bs, dk_ls, dv_bs, dv_ls;
+    int64_t Lq, Lk, Lk_rows;
+    int32_t B, heads, head_dim, accumulate_dq, accumulate_dkv;
+    float scale;
+} m4d_attn_bwd_args;
+int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* args, m4d_stream stream);
+
+/* out[c, r] = in[r, c] for a T matrix [R, C] (leading dims in elements, multiples of 4). */
+int m4d_transpose(m4d_dtype dt, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C,
+                  m4d_stream stream);
+
+/* out[g, c] += sum_{r in group g} a[r, c] (* b[r, c] when b != NULL); float out [ceil(R/rows_per_group), C] must be
+ * initialised by the caller (atomic accumulation): bias gradients (sum of dy), gate gradients (sum of dx * y). */
+int m4d_colsum(m4d_dtype a_dt, const void* a, int64_t lda, m4d_dtype b_dt, const void* b, int64_t ldb, float* out,
+               int64_t R, int64_t C, int64_t rows_per_group, m4d_stream stream);
+
+/* out T [R, C] = in float [R, C] * gate[r / rows_per_sample, c] (gate NULL => cast only): the gradient of the gated
+ * residual `x + y * e[2]` (:669, :684) with respect to y. */
+int m4d_scale_cast(const float* in, const float* gate, int64_t gate_stride, int64_t rows_per_sample, m4d_dtype out_dt,
+                   void* out, int64_t R, int64_t C, m4d_stream stream);
+
+/* out float [R, C] = x float [R, C] + y T [R, C] * gate[r / rows_per_sample, c] (gate NULL => 1): the gated residual
+ * of :669 / :684 as a stand-alone op (the training recompute keeps y for the gate gradient). */
+int m4d_resid_gate(const float* x, m4d_dtype y_dt, const void* y, const float* gate, int64_t gate_stride,
+                   int64_t rows_per_sample, float* out, int64_t R, int64_t C, m4d_stream stream);
+
+/* out = a + b (T, n % 4 == 0): sums of gradient branches. */
+int m4d_add(m4d_dtype dt, const void* a, const void* b, void* out, int64_t n, m4d_stream stream);
+
+/* dy *= act'(pre) in place (act: 1 silu, 2 gelu_tanh, 3 gelu_erf; the m4d_unary / GEMM-epilogue activations). */
+int m4d_act_bwd(m4d_dtype dt, void* dy, const void* pre, int64_t n, int act, m4d_stream stream);
+
+/* Backward of m4d_ln_modulate without guidance: y = LN(x) * m + s with m = 1 + scale[sample] | ln_w | 1.
+ *   dx[r, :] += the LayerNorm input gradient (dx is the float residual-stream gradient, accumulated in place);
+ *   dshift[sample*red_stride + c] += sum_r dy, dscale[...] += sum_r dy * xhat (both NULL to skip; red_stride = 0
+ *   reduces over all samples: the affine weight / bias gradients of norm3, :674). */
+int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* dy, float* dx, int B, int64_t rows_per_sample, int C,
+                        const float* scale, int64_t mod_stride, const float* ln_w, float eps, float* dshift,
+                        float* dscale, int64_t red_stride, m4d_stream stream);
+
+/* Backward of m4d_rmsnorm_rope, in place on the gradient: dy0/dy1 T [rows, C] (row stride ld_dy) hold dL/d(output) on
+ * entry and dL/d(input) on return; x0/x1 are the PRE-norm inputs (row stride ld_x); dw0/dw1 float [C] accumulate the
+ * WanRMSNorm weight gradients (atomic, caller initialises). */
+int m4d_rmsnorm_rope_bwd(m4d_dtype dt, void* dy0, void* dy1, int64_t ld_dy, const void* x0, const void* x1, int64_t ld_x,
+                         const float* w0, const float* w1, float* dw0, float* dw1, int64_t rows, int C, int head_dim,
+                         float eps, const float* cos_t, const float* sin_t, int64_t rows_per_sample, int64_t rope_len,
+                         int64_t pos_offset, m4d_stream stream);
+
+/* *out += sum x^2 (float accumulation; the global gradient norm of :1991-1993 / clip_grad_norm_ :2009). */
+int m4d_sumsq(m4d_dtype dt, const void* x, int64_t n, float* out, m4d_stream stream);
+
+/* One torch.optim.AdamW step (decoupled weight decay, bias correction from `step` >= 1) on a flat parameter, with the
+ * clip coefficient fused: g = grad * (*grad_scale) (NULL => 1).  State dtype: float32 or the parameter dtype
+ * (the reference keeps bf16 state next to bf16 parameters, :1089, :1136-1142). */
+int m4d_adamw(m4d_dtype dt, void* param, const void* grad, m4d_dtype state_dt, void* exp_avg, void* exp_avg_sq, int64_t n,
+              float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale,
+              m4d_stream stream);
 
 #ifdef __cplusplus
 }

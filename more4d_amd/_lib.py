@@ -19,6 +19,15 @@ class KvSegs(Structure):
                 ("len", c_int64 * MAX_KV_SEGS), ("nseg", c_int32)]
 
 
+class AttnBwdArgs(Structure):
+    _fields_ = ([(n, c_void_p) for n in ("q", "k", "v", "o", "d_o", "qt", "kt", "dot", "lse", "delta", "dq", "dk", "dv")] +
+                [(n, c_int64) for n in ("q_bs", "q_ls", "k_bs", "k_ls", "v_bs", "v_ls", "o_bs", "o_ls", "do_bs", "do_ls",
+                                        "qt_bs", "qt_ls", "kt_bs", "kt_ls", "dot_bs", "dot_ls",
+                                        "dq_bs", "dq_ls", "dk_bs", "dk_ls", "dv_bs", "dv_ls", "Lq", "Lk", "Lk_rows")] +
+                [(n, c_int32) for n in ("B", "heads", "head_dim", "accumulate_dq", "accumulate_dkv")] +
+                [("scale", c_float)])
+
+
 # name -> (restype, argtypes); mirrors include/more4d_hip.h one to one
 SIGNATURES = {
     "m4d_version": (c_int, []),
@@ -36,6 +45,24 @@ SIGNATURES = {
                                  c_float, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "m4d_attention": (c_int, [c_int, c_void_p, c_int64, c_int64, POINTER(KvSegs), c_void_p, c_int64, c_int64,
                               c_int, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "m4d_attention_lse": (c_int, [c_int, c_void_p, c_int64, c_int64, POINTER(KvSegs), c_void_p, c_int64, c_int64,
+                                  c_int, c_int64, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "m4d_attention_bwd": (c_int, [c_int, POINTER(AttnBwdArgs), c_void_p]),
+    "m4d_transpose": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "m4d_colsum": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                           c_void_p]),
+    "m4d_scale_cast": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]),
+    "m4d_resid_gate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p]),
+    "m4d_add": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m4d_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "m4d_ln_modulate_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64,
+                                    c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m4d_rmsnorm_rope_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int64,
+                                     c_int64, c_int64, c_void_p]),
+    "m4d_sumsq": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "m4d_adamw": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                          c_float, c_float, c_int64, c_void_p, c_void_p]),
     "m4d_patchify": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_void_p]),
     "m4d_unpatchify": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

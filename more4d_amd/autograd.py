@@ -1,0 +1,304 @@
+"""Training path of the DiT (reference: scripts/4D_STraG_training/train_wan.py:1939-1988 calls
+`transformer3d(...)` under autocast and `accelerator.backward(loss)`).
+
+torch.autograd is used ONLY as the tape: every node below computes its forward and its gradients with the HIP
+kernels of libmore4d_hip.so (ops.*), so `loss.backward()`, DDP gradient hooks and torch optimizers keep working on
+the reference-named parameters.  One `BlockFn` node per WanAttentionBlock implements the reference's per-block
+gradient checkpointing (`enable_gradient_checkpointing`, wan_transformer4d.py:1273-1291): the forward keeps only the
+block input (float32 residual stream), the backward recomputes the block and walks it in reverse.  Parameter
+gradients leave each node as soon as that block is done, so DDP's bucketed all-reduce (RCCL) overlaps the
+remaining backward.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import (ACT_GELU_TANH, EPI_STORE, EPI_STORE_F32, KV)
+
+
+# ------------------------------------------------------------------ GEMM-shaped gradients
+def _tpad(x):
+    """x [R, C] -> x^T [C, Rp] with Rp = R rounded up (zero filled) so that the token axis can be the K of the
+    production GEMM kernel (K % 64 == 0; small problems only need the 16-byte row alignment)."""
+    R, C = x.shape
+    Rp = -(-R // 64) * 64 if R >= 512 else -(-R // 8) * 8
+    out = torch.empty((C, Rp), device=x.device, dtype=x.dtype)
+    if Rp != R:
+        out[:, R:].zero_()
+    ops.transpose(x, out=out[:, :R] if Rp != R else out)
+    return out
+
+
+def linear_bwd(x, w, dy, need_dx=True):
+    """y = x w^T + b.  x [R, K], w [N, K], dy [R, N] (all T) -> (dx [R, K] | None, dw [N, K], db float32 [N])."""
+    db = ops.colsum(dy)[0]
+    dx = ops.gemm_bt(dy, ops.transpose(w)) if need_dx else None          # dy [R,N] . (w^T)[K,N]^T
+    dw = ops.gemm_bt(_tpad(dy), _tpad(x))                               # dy^T [N,Rp] . (x^T)[K,Rp]^T
+    return dx, dw, db
+
+
+class LinearFn(Function):
+    """act(x w^T + b) computed in `cdt` (the kernels' T); output float32 when out_f32 (EPI_STORE_F32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, cdt, out_f32):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        x2 = x2.contiguous() if x2.dtype == cdt else ops.unary(x2.contiguous(), cdt)
+        w = weight.detach().reshape(weight.shape[0], -1).to(cdt)
+        b = bias.detach().to(cdt)
+        pre = None
+        if act:
+            pre = ops.gemm_bt(x2, w, b)
+            y = ops.unary(pre, torch.float32 if out_f32 else cdt, act=act)
+        else:
+            y = ops.gemm_bt(x2, w, b, epilogue=EPI_STORE_F32 if out_f32 else EPI_STORE)
+        ctx.save_for_backward(x2, w, pre)
+        ctx.meta = (act, cdt, x.shape, x.dtype, weight.shape, weight.dtype, bias.dtype)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        act, cdt, xshape, xdt, wshape, wdt, bdt = ctx.meta
+        N = w.shape[0]
+        dy2 = dy.reshape(-1, N).contiguous()
+        if dy2.dtype != cdt:
+            dy2 = ops.unary(dy2, cdt)
+        elif act and dy2.data_ptr() == dy.data_ptr():
+            dy2 = dy2.clone()
+        if act:
+            ops.act_bwd_(dy2, pre, act)
+        dx, dw, db = linear_bwd(x2, w, dy2, need_dx=ctx.needs_input_grad[0])
+        if dx is not None:
+            dx = dx.view(xshape)
+            if dx.dtype != xdt:
+                dx = ops.unary(dx, xdt)
+        return dx, dw.view(wshape).to(wdt), db.to(bdt), None, None, None
+
+
+class ActFn(Function):
+    """act(x) -> out_dtype (1 silu, 2 gelu_tanh, 3 gelu_erf)."""
+
+    @staticmethod
+    def forward(ctx, x, act, out_dtype):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.unary(x, out_dtype, act=act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        d = ops.unary(dy.contiguous(), x.dtype) if dy.dtype != x.dtype else dy.contiguous().clone()
+        ops.act_bwd_(d, x, ctx.act)
+        return d, None, None
+
+
+class LayerNormFn(Function):
+    """ln_modulate on a float32 [B, n, C] input: affine (ln_w, ln_b [C]) or modulated (shift, scale [B, C])."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, shift, scale, eps, out_dtype):
+        x = x.contiguous()
+        B, n, C = x.shape
+        w32 = ln_w.detach().float().contiguous() if ln_w is not None else None
+        b32 = ln_b.detach().float().contiguous() if ln_b is not None else None
+        sh = shift.detach().contiguous() if shift is not None else None
+        sc = scale.detach().contiguous() if scale is not None else None
+        y = ops.ln_modulate(x, out_dtype, shift=sh, scale=sc, mod_stride=C, rows_per_sample=n, ln_w=w32, ln_b=b32, eps=eps)
+        ctx.save_for_backward(x, w32, sc)
+        ctx.meta = (eps, ln_w.dtype if ln_w is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w32, sc = ctx.saved_tensors
+        eps, wdt = ctx.meta
+        B, n, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.zeros_like(x)
+        G = 1 if w32 is not None else B
+        d1 = torch.zeros((G, C), device=x.device, dtype=torch.float32)
+        d2 = torch.zeros((G, C), device=x.device, dtype=torch.float32)
+        ops.ln_modulate_bwd(x, dy, dx, B=B, rows_per_sample=n, scale=sc, mod_stride=C, ln_w=w32, eps=eps, dshift=d1,
+                            dscale=d2, red_stride=0 if w32 is not None else C)
+        if w32 is not None:
+            return dx, d2[0].to(wdt), d1[0].to(wdt), None, None, None, None
+        return dx, None, None, d1, d2, None, None
+
+
+# ------------------------------------------------------------------ one DiT block: recompute + backward
+def _block_param_names(blk):
+    return [n for n, _ in blk.named_parameters()]
+
+
+def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres):
+    """Recompute WanAttentionBlock.run on x0 keeping the intermediates, then back-propagate `dres`
+    (float32 [B, Lp, C], gradient w.r.t. the block output; overwritten with the gradient w.r.t. x0).
+    Returns (de0 [B,6,C] float32, dtxt, dimg, {param name: grad})."""
+    from .models.wan_transformer4d import _f32
+    B, Lp, C = x0.shape
+    R = B * Lp
+    sa, ca = blk.self_attn, blk.cross_attn
+    n, d = sa.num_heads, sa.head_dim
+    T = blk.ffn[0].weight.dtype
+    dev = x0.device
+    st = 6 * C
+    eps = blk.eps
+    f32 = lambda p: _f32(p, c.f32cache)  # noqa: E731
+    G = {}
+    if not sa.qk_norm:
+        raise NotImplementedError("training without qk_norm")
+
+    def zeros(*shape):
+        return torch.zeros(shape, device=dev, dtype=torch.float32)
+
+    e = ops.add_bcast(e0, f32(blk.modulation))                      # [B,6,C]: shift1 scale1 gate1 shift2 scale2 gate2
+    de = zeros(B, 6, C)
+    dres2 = dres.view(R, C)
+
+    # ================= recompute (reference :659-684) =================
+    xn1 = ops.ln_modulate(x0, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=Lp, eps=eps).view(R, C)
+    qkv_pre = torch.empty((R, 3 * C), device=dev, dtype=T)
+    for j, lin in enumerate((sa.q, sa.k, sa.v)):
+        ops.gemm_bt(xn1, lin.weight, lin.bias, out=qkv_pre[:, j * C:(j + 1) * C])
+    qkv = qkv_pre.clone()
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    rope = dict(head_dim=d, eps=sa.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
+                pos_offset=c.pos_offset)
+    ops.rmsnorm_rope(q, f32(sa.norm_q.weight), k, f32(sa.norm_k.weight), **rope)
+    vt = ops.transpose(v)                                            # V^T [C, R]
+    lse1 = torch.empty((B, n, Lp), device=dev, dtype=torch.float32)
+    o = ops.attention(q, [KV(k, vt, Lp * 3 * C, 3 * C, Lp, R, c.key_len)], B=B, Lq=Lp, heads=n, head_dim=d,
+                      q_bs=Lp * 3 * C, q_ls=3 * C, lse=lse1).view(R, C)
+    y1 = ops.gemm_bt(o, sa.o.weight, sa.o.bias)
+    x1 = ops.resid_gate(x0, y1, gate=e[:, 2], gate_stride=st, rows_per_sample=Lp)
+    if blk.cross_attn_norm:
+        xn3 = ops.ln_modulate(x1, T, ln_w=f32(blk.norm3.weight), ln_b=f32(blk.norm3.bias), eps=eps).view(R, C)
+    else:
+        xn3 = ops.unary(x1, T).view(R, C)
+    qc_pre = ops.gemm_bt(xn3, ca.q.weight, ca.q.bias)
+    qc = qc_pre.clone()
+    ops.rmsnorm_rope(qc, f32(ca.norm_q.weight), head_dim=d, eps=ca.eps)
+    srcs = [("txt", txt, txt_len, ca.k, ca.v, ca.norm_k)]
+    if img is not None and getattr(ca, "has_img", False):
+        srcs.append(("img", img, img_len, ca.k_img, ca.v_img, ca.norm_k_img))
+    cross = []
+    oc = None
+    for name, src, valid, kl, vl, nk in srcs:
+        Bc, Sp, _ = src.shape
+        s2 = src.reshape(Bc * Sp, C)
+        k_pre = ops.gemm_bt(s2, kl.weight, kl.bias)
+        kk = k_pre.clone()
+        ops.rmsnorm_rope(kk, f32(nk.weight), head_dim=d, eps=ca.eps)
+        vv = ops.gemm_bt(s2, vl.weight, vl.bias)
+        vvt = ops.transpose(vv)
+        lse = torch.empty((B, n, Lp), device=dev, dtype=torch.float32)
+        oo = ops.attention(qc, [KV(kk, vvt, Sp * C, C, Sp, Bc * Sp, valid)], B=B, Lq=Lp, heads=n, head_dim=d,
+                           q_bs=Lp * C, q_ls=C, lse=lse).view(R, C)
+        oc = oo if oc is None else ops.add(oc, oo)
+        cross.append((name, s2, Sp, valid, kl, vl, nk, k_pre, kk, vv, oo, lse))
+    yc = ops.gemm_bt(oc, ca.o.weight, ca.o.bias)
+    x2 = ops.resid_gate(x1, yc)
+    xn2 = ops.ln_modulate(x2, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=Lp, eps=eps).view(R, C)
+    pre = ops.gemm_bt(xn2, blk.ffn[0].weight, blk.ffn[0].bias)
+    h = ops.unary(pre, T, act=ACT_GELU_TANH)
+    y2 = ops.gemm_bt(h, blk.ffn[2].weight, blk.ffn[2].bias)
+
+    # ================= backward =================
+    # ---- ffn: x3 = x2 + y2 * gate2
+    de[:, 5].copy_(ops.colsum(dres2, y2, rows_per_group=Lp))
+    dy2 = ops.scale_cast(dres2, T, gate=e[:, 5], gate_stride=st, rows_per_sample=Lp)
+    del y2
+    dh, G["ffn.2.weight"], G["ffn.2.bias"] = linear_bwd(h, blk.ffn[2].weight, dy2)
+    del h, dy2
+    ops.act_bwd_(dh, pre, ACT_GELU_TANH)
+    del pre
+    dxn2, G["ffn.0.weight"], G["ffn.0.bias"] = linear_bwd(xn2, blk.ffn[0].weight, dh)
+    del dh
+    ops.ln_modulate_bwd(x2, dxn2, dres, B=B, rows_per_sample=Lp, scale=e[:, 4], mod_stride=st, eps=eps,
+                        dshift=de[:, 3], dscale=de[:, 4], red_stride=st)
+    # ---- cross attention: x2 = x1 + yc
+    dyc = ops.scale_cast(dres2, T)
+    doc, G["cross_attn.o.weight"], G["cross_attn.o.bias"] = linear_bwd(oc, ca.o.weight, dyc)
+    dqc = torch.empty((R, C), device=dev, dtype=T)
+    dctx = {}
+    for i, (name, s2, Sp, valid, kl, vl, nk, k_pre, kk, vv, oo, lse) in enumerate(cross):
+        dk = torch.empty_like(kk)
+        dv = torch.empty_like(vv)
+        ops.attention_bwd(qc, kk, vv, oo, doc, lse, B=B, Lq=Lp, Lk=valid, Lk_rows=Sp, heads=n, head_dim=d, dq=dqc, dk=dk,
+                          dv=dv, accumulate_dq=i > 0)
+        dwn = zeros(C)
+        ops.rmsnorm_rope_bwd_(dk, k_pre, f32(nk.weight), dwn, head_dim=d, eps=ca.eps)
+        sfx = "_img" if name == "img" else ""
+        G[f"cross_attn.norm_k{sfx}.weight"] = dwn
+        ds_k, G[f"cross_attn.k{sfx}.weight"], G[f"cross_attn.k{sfx}.bias"] = linear_bwd(s2, kl.weight, dk)
+        ds_v, G[f"cross_attn.v{sfx}.weight"], G[f"cross_attn.v{sfx}.bias"] = linear_bwd(s2, vl.weight, dv)
+        dctx[name] = ops.add(ds_k, ds_v).view(-1, Sp, C)
+    dwq = zeros(C)
+    ops.rmsnorm_rope_bwd_(dqc, qc_pre, f32(ca.norm_q.weight), dwq, head_dim=d, eps=ca.eps)
+    G["cross_attn.norm_q.weight"] = dwq
+    dxn3, G["cross_attn.q.weight"], G["cross_attn.q.bias"] = linear_bwd(xn3, ca.q.weight, dqc)
+    if blk.cross_attn_norm:
+        dw3, db3 = zeros(C), zeros(C)
+        ops.ln_modulate_bwd(x1, dxn3, dres, B=B, rows_per_sample=Lp, ln_w=f32(blk.norm3.weight), eps=eps, dshift=db3,
+                            dscale=dw3, red_stride=0)
+        G["norm3.weight"], G["norm3.bias"] = dw3, db3
+    else:
+        ops.resid_gate(dres, dxn3, out=dres)
+    # ---- self attention: x1 = x0 + y1 * gate1
+    de[:, 2].copy_(ops.colsum(dres2, y1, rows_per_group=Lp))
+    dy1 = ops.scale_cast(dres2, T, gate=e[:, 2], gate_stride=st, rows_per_sample=Lp)
+    do, G["self_attn.o.weight"], G["self_attn.o.bias"] = linear_bwd(o, sa.o.weight, dy1)
+    dqkv = torch.empty((R, 3 * C), device=dev, dtype=T)
+    ops.attention_bwd(q, k, v, o, do, lse1, B=B, Lq=Lp, Lk=c.key_len, Lk_rows=Lp, heads=n, head_dim=d,
+                      dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+    dwq, dwk = zeros(C), zeros(C)
+    ops.rmsnorm_rope_bwd_(dqkv[:, :C], qkv_pre[:, :C], f32(sa.norm_q.weight), dwq, dqkv[:, C:2 * C], qkv_pre[:, C:2 * C],
+                          f32(sa.norm_k.weight), dwk, **rope)
+    G["self_attn.norm_q.weight"], G["self_attn.norm_k.weight"] = dwq, dwk
+    wt = torch.empty((C, 3 * C), device=dev, dtype=T)               # [Wq^T | Wk^T | Wv^T]
+    for j, lin in enumerate((sa.q, sa.k, sa.v)):
+        ops.transpose(lin.weight, out=wt[:, j * C:(j + 1) * C])
+    dxn1 = ops.gemm_bt(dqkv, wt)
+    dwqkv = ops.gemm_bt(_tpad(dqkv), _tpad(xn1))                     # [3C, C]
+    dbqkv = ops.colsum(dqkv)[0]
+    for j, nm in enumerate(("q", "k", "v")):
+        G[f"self_attn.{nm}.weight"] = dwqkv[j * C:(j + 1) * C]
+        G[f"self_attn.{nm}.bias"] = dbqkv[j * C:(j + 1) * C]
+    ops.ln_modulate_bwd(x0, dxn1, dres, B=B, rows_per_sample=Lp, scale=e[:, 1], mod_stride=st, eps=eps,
+                        dshift=de[:, 0], dscale=de[:, 1], red_stride=st)
+    G["modulation"] = ops.colsum(de.view(B, 6 * C))[0].view(1, 6, C)
+    return de, dctx.get("txt"), dctx.get("img"), G
+
+
+class BlockFn(Function):
+    """WanAttentionBlock with per-block recompute.  apply(x, e0, txt, img, blk, c, txt_len, img_len, *params)."""
+
+    @staticmethod
+    def forward(ctx, x, e0, txt, img, blk, c, txt_len, img_len, *params):
+        from .models.wan_transformer4d import ContextCache
+        if c.sp is not None and c.sp.world_size > 1:
+            raise NotImplementedError("training uses data parallelism; sequence parallelism is the inference path")
+        out = x.detach().clone()
+        cc = ContextCache()
+        cc.txt, cc.txt_len, cc.img, cc.img_len = txt.detach(), txt_len, (img.detach() if img is not None else None), img_len
+        blk.run(out, e0.detach().contiguous(), c, cc, 0, None)
+        ctx.save_for_backward(x, e0, txt, img)
+        ctx.blk, ctx.c, ctx.lens = blk, c, (txt_len, img_len)
+        ctx.names = _block_param_names(blk)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, e0, txt, img = ctx.saved_tensors
+        blk = ctx.blk
+        dres = dout.contiguous().clone()
+        de, dtxt, dimg, G = block_backward(blk, x.detach(), e0.detach().contiguous(), ctx.c, txt.detach(), ctx.lens[0],
+                                           img.detach() if img is not None else None, ctx.lens[1], dres)
+        grads = []
+        for name, p in zip(ctx.names, blk.parameters()):
+            g = G.get(name)
+            grads.append(None if g is None else g.to(p.dtype).view(p.shape))
+        return (dres, de, dtxt, dimg, None, None, None, None, *grads)

@@ -18,6 +18,7 @@
 // LDS images are XOR-swizzled per 16-B chunk so fragment reads (ds_read_b128) are conflict-free.
 #include <stdlib.h>
 #include "common.h"
+#include "attn_common.h"
 #include "more4d_hip.h"
 
 namespace {
@@ -28,43 +29,8 @@ struct AttnArgs {
     int64_t q_bs, q_ls, o_bs, o_ls, Lq;
     int B, heads, nq_tiles, accumulate;
     float sc;  // softmax scale * log2(e)
+    float* lse;  // optional [B, heads, Lq]: log2-domain log-sum-exp of the scaled scores (training)
 };
-
-template <int RB> M4D_DEV int swz_off(int row, int chunk) {
-    constexpr int CPR = RB / 16;
-    if constexpr (CPR >= 16) return row * RB + ((chunk ^ (row & 15)) << 4);
-    else return row * RB + ((chunk ^ ((row / (16 / CPR)) & (CPR - 1))) << 4);
-}
-
-M4D_DEV int perm23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
-
-template <typename T> struct TileCfg;
-template <> struct TileCfg<bf16_t> { static constexpr int KVB = 64; };
-template <> struct TileCfg<float> { static constexpr int KVB = 32; };
-
-template <typename T> M4D_DEV typename Frag8<T>::type lds_frag(const char* base, int off0, int off1);
-template <> M4D_DEV bf16x8 lds_frag<bf16_t>(const char* base, int off0, int) {
-    return *reinterpret_cast<const bf16x8*>(base + off0);
-}
-template <> M4D_DEV f32x8 lds_frag<float>(const char* base, int off0, int off1) {
-    f32x4 lo = *reinterpret_cast<const f32x4*>(base + off0);
-    f32x4 hi = *reinterpret_cast<const f32x4*>(base + off1);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-template <typename T> M4D_DEV typename Frag8<T>::type pack8(const f32x16& s, int base);
-template <> M4D_DEV bf16x8 pack8<bf16_t>(const f32x16& s, int base) {
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)s[base + j];
-    return r;
-}
-template <> M4D_DEV f32x8 pack8<float>(const f32x16& s, int base) {
-    f32x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = s[base + j];
-    return r;
-}
 
 template <typename T, int D>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_kernel(AttnArgs p) {
@@ -250,6 +216,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_kernel(Att
     // ---- epilogue: normalise, (accumulate), store 4 consecutive d per lane ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (p.lse && qvalid && hi == 0) p.lse[((int64_t)b * p.heads + h) * p.Lq + qrow] = m_run + log2f(l_tot);
     if (qvalid) {
         T* op = (T*)p.out + b * p.o_bs + qrow * p.o_ls + (int64_t)h * D + hi * 4;
 #pragma unroll
@@ -501,6 +468,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (p.lse && qvalid && hi == 0) p.lse[((int64_t)b * p.heads + h) * p.Lq + qrow] = m_run + log2f(l_tot);
     if (qvalid) {
         T* op = (T*)p.out + b * p.o_bs + qrow * p.o_ls + (int64_t)h * D + hi * 4;
 #pragma unroll
@@ -550,9 +518,9 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int m4d_attention(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,
-                             int64_t o_bs, int64_t o_ls, int B, int64_t Lq, int heads, int head_dim, float scale,
-                             int accumulate, m4d_stream stream) {
+static int attention_impl(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,
+                          int64_t o_bs, int64_t o_ls, int B, int64_t Lq, int heads, int head_dim, float scale,
+                          int accumulate, float* lse, m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "attention: bad dtype %d", (int)dt);
     M4D_CHECK_ARG(q && kv && out, "attention: null pointer");
     M4D_CHECK_ARG(B > 0 && Lq > 0 && heads > 0, "attention: empty problem");
@@ -579,8 +547,22 @@ extern "C" int m4d_attention(m4d_dtype dt, const void* q, int64_t q_bs, int64_t 
     p.q_bs = q_bs; p.q_ls = q_ls; p.o_bs = o_bs; p.o_ls = o_ls; p.Lq = Lq;
     p.B = B; p.heads = heads; p.nq_tiles = (int)((Lq + 127) / 128); p.accumulate = accumulate;
     p.sc = scale * 1.4426950408889634f;
+    p.lse = lse;
     int rc = dt == M4D_BF16 ? launch<bf16_t>(p, head_dim, (hipStream_t)stream) : launch<float>(p, head_dim, (hipStream_t)stream);
     if (rc) { m4d_set_error("attention: unsupported configuration"); return rc; }
     M4D_CHECK_LAUNCH("attention");
     return 0;
+}
+
+extern "C" int m4d_attention(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,
+                             int64_t o_bs, int64_t o_ls, int B, int64_t Lq, int heads, int head_dim, float scale,
+                             int accumulate, m4d_stream stream) {
+    return attention_impl(dt, q, q_bs, q_ls, kv, out, o_bs, o_ls, B, Lq, heads, head_dim, scale, accumulate, nullptr, stream);
+}
+
+extern "C" int m4d_attention_lse(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,
+                                 int64_t o_bs, int64_t o_ls, int B, int64_t Lq, int heads, int head_dim, float scale,
+                                 int accumulate, float* lse, m4d_stream stream) {
+    M4D_CHECK_ARG(lse, "attention_lse: null lse");
+    return attention_impl(dt, q, q_bs, q_ls, kv, out, o_bs, o_ls, B, Lq, heads, head_dim, scale, accumulate, lse, stream);
 }

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void unary_kernel(const TI* x, TO* out, int64_
         float v = (float)x[i];
         if (act == 1) v = silu_f(v);
         else if (act == 2) v = gelu_tanh_f(v);
+        else if (act == 3) v = gelu_erf_f(v);
         out[i] = (TO)v;
     }
 }
@@ -419,7 +420,7 @@ extern "C" int m4d_cfg_euler(float* x, m4d_dtype v_dt, const void* v, int64_t n,
 extern "C" int m4d_unary(m4d_dtype in_dt, const void* x, m4d_dtype out_dt, void* out, int64_t n, int act,
                          m4d_stream stream) {
     M4D_CHECK_ARG(x && out && n > 0, "unary: null/empty");
-    M4D_CHECK_ARG(act >= 0 && act <= 2, "unary: bad act %d", act);
+    M4D_CHECK_ARG(act >= 0 && act <= 3, "unary: bad act %d", act);
     dim3 block(256), grid(grid_for(n));
     hipStream_t st = (hipStream_t)stream;
     if (in_dt == M4D_F32 && out_dt == M4D_F32) hipLaunchKernelGGL((unary_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)out, n, act);

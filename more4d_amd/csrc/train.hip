@@ -1,0 +1,540 @@
+// Training-step kernels of the DiT path (train_wan.py:1891-2015): the HBM-bound halves of the
+// backward pass (LayerNorm+modulate, RMSNorm+RoPE, activation derivatives, column reductions for bias /
+// modulation / norm-weight gradients, tile transpose for the wgrad/dgrad GEMM operands) and the fused
+// clip+AdamW update.  The GEMM-shaped halves reuse m4d_gemm_bt; attention has m4d_attention_bwd.
+#include "common.h"
+#include "more4d_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ transpose: out[c, r] = in[r, c]
+struct TrArgs { const void* in; void* out; int64_t R, C, ld_in, ld_out; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(TrArgs p) {
+    constexpr int PAD = sizeof(T) == 2 ? 2 : 1;      // odd dword row stride: conflict-free column reads
+    __shared__ T tile[64][64 + PAD];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    {
+        const int cx = (t & 15) * 4, ry = t >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = ry + i * 16;
+            const int64_t r = r0 + rr, c = c0 + cx;
+            if (r < p.R) {
+                const T* src = (const T*)p.in + r * p.ld_in + c;
+                if (c + 3 < p.C) {
+                    const f32x4 v = load4(src);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tile[rr][cx + e] = (T)v[e];
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < p.C) tile[rr][cx + e] = src[e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int rx = (t & 15) * 4, cy = t >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = cy + i * 16;
+            const int64_t c = c0 + cc, r = r0 + rx;
+            if (c < p.C) {
+                T* dst = (T*)p.out + c * p.ld_out + r;
+                if (r + 3 < p.R) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)tile[rx + e][cc];
+                    store4(dst, v);
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (r + e < p.R) dst[e] = tile[rx + e][cc];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ grouped column sums
+// out[g, c] += sum over the rows r of group g of a[r, c] (* b[r, c]);  g = r / rows_per_group
+struct ColArgs { const void *a, *b; float* out; int64_t R, C, lda, ldb, rows_per_group; int chunks; };
+
+template <typename TA, typename TB, bool HASB>
+__global__ __launch_bounds__(256) void colsum_kernel(ColArgs p) {
+    constexpr int RC = 256;                          // rows per workgroup
+    __shared__ f32x4 part[4][64];
+    const int t = threadIdx.x, lx = t & 63, ly = t >> 6;
+    const int64_t c = ((int64_t)blockIdx.x * 64 + lx) * 4;
+    const int64_t g = blockIdx.y / p.chunks, ch = blockIdx.y % p.chunks;
+    const int64_t rbeg = g * p.rows_per_group + ch * RC;
+    int64_t rend = rbeg + RC;
+    const int64_t gend = (g + 1) * p.rows_per_group < p.R ? (g + 1) * p.rows_per_group : p.R;
+    if (rend > gend) rend = gend;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < p.C) {
+        for (int64_t r = rbeg + ly; r < rend; r += 4) {
+            f32x4 v = load4((const TA*)p.a + r * p.lda + c);
+            if constexpr (HASB) v = v * load4((const TB*)p.b + r * p.ldb + c);
+            acc += v;
+        }
+    }
+    part[ly][lx] = acc;
+    __syncthreads();
+    if (ly == 0 && c < p.C) {
+        acc = part[0][lx] + part[1][lx] + part[2][lx] + part[3][lx];
+        float* o = p.out + g * p.C + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(o + e, acc[e]);
+    }
+}
+
+// ------------------------------------------------------------------ out T [R, C] = in f32 [R, C] * gate[sample, c]
+struct ScArgs { const float* in; void* out; const float* gate; int64_t R, C, rows_per_sample, gate_stride; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cast_kernel(ScArgs p) {
+    const int64_t nv = p.C >> 2, total = p.R * nv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nv, c = (i % nv) * 4;
+        f32x4 v = load4(p.in + r * p.C + c);
+        if (p.gate) v = v * load4(p.gate + (r / p.rows_per_sample) * p.gate_stride + c);
+        store4((T*)p.out + r * p.C + c, v);
+    }
+}
+
+// ------------------------------------------------------------------ out f32 = x f32 + y T * gate[sample, c]   (gated residual)
+struct RgArgs { const float* x; const void* y; const float* gate; float* out; int64_t R, C, rows_per_sample, gate_stride; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void resid_gate_kernel(RgArgs p) {
+    const int64_t nv = p.C >> 2, total = p.R * nv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nv, c = (i % nv) * 4;
+        f32x4 v = load4((const T*)p.y + r * p.C + c);
+        if (p.gate) v = v * load4(p.gate + (r / p.rows_per_sample) * p.gate_stride + c);
+        store4(p.out + r * p.C + c, load4(p.x + r * p.C + c) + v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4)
+        store4(out + i, load4(a + i) + load4(b + i));
+}
+
+// ------------------------------------------------------------------ dy *= act'(pre)   (act: 1 silu, 2 gelu_tanh, 3 gelu_erf)
+M4D_DEV float dact(float x, int act) {
+    if (act == 1) { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    if (act == 2) {
+        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+        const float th = tanhf(k0 * (x + k1 * x * x * x));
+        return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x * x);
+    }
+    if (act == 3) return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    return 1.f;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(T* dy, const T* pre, int64_t n, int act) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        f32x4 d = load4(dy + i);
+        const f32x4 x = load4(pre + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] *= dact(x[e], act);
+        store4(dy + i, d);
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm(+modulate / affine) backward
+// y = xhat * m + s,  m = 1 + scale[sample] (modulated) or ln_w (affine) or 1:
+//   dx += rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * m
+//   dshift[grp, c] += dy,  dscale[grp, c] += dy * xhat      (grp = sample for modulation, 0 for the affine weights)
+// One wave walks rows l = first, first + stride, ... of one sample keeping its column partials in registers.
+struct LnBwdArgs {
+    const float* x; const void* dy; float* dx;
+    const float *scale, *ln_w;
+    float *dshift, *dscale;
+    int64_t rows_per_sample, mod_stride, red_stride;   // red_stride: elements between samples in dshift/dscale (0 => shared)
+    int C, B; float eps;
+};
+
+template <typename TD, int MAXV>
+__global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
+    constexpr int G = 64;
+    const int lt = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sample = blockIdx.y;
+    const int C = p.C, nv = C >> 2;
+    const float* sc = p.scale ? p.scale + (int64_t)sample * p.mod_stride : nullptr;
+    f32x4 ps[MAXV], pq[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { ps[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pq[i] = ps[i]; }
+    for (int64_t l = (int64_t)blockIdx.x * 4 + wv; l < p.rows_per_sample; l += (int64_t)gridDim.x * 4) {
+        const int64_t row = (int64_t)sample * p.rows_per_sample + l;
+        const float* xr = p.x + row * C;
+        const TD* dr = (const TD*)p.dy + row * C;
+        f32x4 v[MAXV], g[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * G;
+            if (c4 < nv) {
+                v[i] = load4(xr + c4 * 4);
+                g[i] = load4(dr + c4 * 4);
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+        }
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * G;
+            if (c4 < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * G;
+            if (c4 < nv) {
+                const int c = c4 * 4;
+                f32x4 xh = (v[i] - mean) * rstd;
+                ps[i] += g[i];
+                pq[i] += g[i] * xh;
+                if (sc) g[i] = g[i] * (1.f + load4(sc + c));
+                else if (p.ln_w) g[i] = g[i] * load4(p.ln_w + c);
+                v[i] = xh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { m1 += g[i][e]; m2 += g[i][e] * xh[e]; }
+            }
+        }
+        m1 = wave_sum(m1) / C;
+        m2 = wave_sum(m2) / C;
+        float* dxr = p.dx + row * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * G;
+            if (c4 < nv) {
+                f32x4 d = (g[i] - m1 - v[i] * m2) * rstd;
+                store4(dxr + c4 * 4, load4(dxr + c4 * 4) + d);
+            }
+        }
+    }
+    if (p.dshift) {
+        float* o1 = p.dshift + (int64_t)sample * p.red_stride;
+        float* o2 = p.dscale + (int64_t)sample * p.red_stride;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * G;
+            if (c4 < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    atomicAdd(o1 + c4 * 4 + e, ps[i][e]);
+                    atomicAdd(o2 + c4 * 4 + e, pq[i][e]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RMSNorm(+RoPE) backward, in place on dy
+// forward (m4d_rmsnorm_rope): y = rot(xhat * w), xhat = x * rsqrt(mean(x^2) + eps)
+//   g = rot^T(dy);  dw[c] += g * xhat;  dx = rstd * (g*w - xhat * mean(g*w*xhat))
+struct RmsBwdArgs {
+    void* dy[2]; const void* x[2]; const float* w[2]; float* dw[2];
+    const float *cos_t, *sin_t;
+    int64_t ld_dy, ld_x, rows, rows_per_sample, rope_len, pos_offset;
+    int C, head_dim; float eps;
+};
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
+    const int lt = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int which = blockIdx.y;
+    const int C = p.C, nv = C >> 2;
+    const float* w = p.w[which];
+    const int half = p.head_dim >> 1;
+    f32x4 pw[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) pw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < p.rows; row += (int64_t)gridDim.x * 4) {
+        T* dr = (T*)p.dy[which] + row * p.ld_dy;
+        const T* xr = (const T*)p.x[which] + row * p.ld_x;
+        const int64_t l = row % p.rows_per_sample;
+        const bool rot = p.cos_t && l < p.rope_len;
+        const float* ct = rot ? p.cos_t + (p.pos_offset + l) * half : nullptr;
+        const float* st = rot ? p.sin_t + (p.pos_offset + l) * half : nullptr;
+        f32x4 v[MAXV], g[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * 64;
+            if (c4 < nv) {
+                const int c = c4 * 4;
+                v[i] = load4(xr + c);
+                g[i] = load4(dr + c);
+                if (rot) {   // transpose of the forward rotation on pairs (c, c+1), (c+2, c+3)
+                    const int pi = (c % p.head_dim) >> 1;
+                    const f32x2 cs = *reinterpret_cast<const f32x2*>(ct + pi);
+                    const f32x2 sn = *reinterpret_cast<const f32x2*>(st + pi);
+                    const float a0 = g[i][0], b0 = g[i][1], a1 = g[i][2], b1 = g[i][3];
+                    g[i][0] = a0 * cs[0] + b0 * sn[0];
+                    g[i][1] = -a0 * sn[0] + b0 * cs[0];
+                    g[i][2] = a1 * cs[1] + b1 * sn[1];
+                    g[i][3] = -a1 * sn[1] + b1 * cs[1];
+                }
+                s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            }
+        }
+        const float inv = rsqrtf(wave_sum(s) / C + p.eps);
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * 64;
+            if (c4 < nv) {
+                const f32x4 xh = v[i] * inv;
+                pw[i] += g[i] * xh;
+                g[i] = g[i] * load4(w + c4 * 4);
+                v[i] = xh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m2 += g[i][e] * xh[e];
+            }
+        }
+        m2 = wave_sum(m2) / C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * 64;
+            if (c4 < nv) store4(dr + c4 * 4, (g[i] - v[i] * m2) * inv);
+        }
+    }
+    float* o = p.dw[which];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = lt + i * 64;
+        if (c4 < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(o + c4 * 4 + e, pw[i][e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ sum of squares (global gradient norm)
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* x, int64_t n, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n & ~(int64_t)3;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n4; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        const f32x4 v = load4(x + i);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4)) { const float v = (float)x[n4 + threadIdx.x]; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------ fused clip + AdamW (torch.optim.AdamW semantics)
+struct AdamArgs {
+    void *p, *m, *v; const void* g;
+    int64_t n;
+    float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;
+    const float* grad_scale;     // optional device scalar multiplied into the gradient (clip coefficient)
+};
+template <typename T, typename TS>
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    const float gs = a.grad_scale ? *a.grad_scale : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = (float)((const T*)a.g)[i] * gs;
+        float w = (float)((T*)a.p)[i];
+        float m = (float)((TS*)a.m)[i], v = (float)((TS*)a.v)[i];
+        w *= 1.f - a.lr * a.wd;
+        m = a.beta1 * m + (1.f - a.beta1) * g;
+        v = a.beta2 * v + (1.f - a.beta2) * g * g;
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        w -= (a.lr / a.bc1) * (m / denom);
+        ((T*)a.p)[i] = (T)w;
+        ((TS*)a.m)[i] = (TS)m;
+        ((TS*)a.v)[i] = (TS)v;
+    }
+}
+
+inline unsigned grid_for(int64_t work, int per_block, unsigned cap = 65535u * 4) {
+    int64_t g = (work + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+#define DT_OK(dt) ((dt) == M4D_BF16 || (dt) == M4D_F32)
+
+extern "C" int m4d_transpose(m4d_dtype dt, const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t R, int64_t C,
+                             m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dt), "transpose: bad dtype");
+    M4D_CHECK_ARG(in && out && R > 0 && C > 0, "transpose: bad arguments");
+    M4D_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= C && ld_out >= R, "transpose: leading dims must be multiples of 4 and cover the rows");
+    const uintptr_t al = dt == M4D_BF16 ? 8 : 16;
+    M4D_CHECK_ARG(((uintptr_t)in % al) == 0 && ((uintptr_t)out % al) == 0, "transpose: tensors must be aligned to 4 elements");
+    TrArgs p{in, out, R, C, ld_in, ld_out};
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), block(256);
+    M4D_CHECK_ARG(grid.y <= 65535u, "transpose: too many rows (%lld)", (long long)R);
+    if (dt == M4D_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+    M4D_CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+extern "C" int m4d_colsum(m4d_dtype a_dt, const void* a, int64_t lda, m4d_dtype b_dt, const void* b, int64_t ldb, float* out,
+                          int64_t R, int64_t C, int64_t rows_per_group, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(a_dt) && (!b || DT_OK(b_dt)), "colsum: bad dtype");
+    M4D_CHECK_ARG(a && out && R > 0 && C > 0 && rows_per_group > 0, "colsum: bad arguments");
+    M4D_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && (!b || ldb % 4 == 0), "colsum: C and leading dims must be multiples of 4");
+    const int64_t G = (R + rows_per_group - 1) / rows_per_group;
+    ColArgs p{a, b, out, R, C, lda, ldb, rows_per_group, (int)((rows_per_group + 255) / 256)};
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)(G * p.chunks)), block(256);
+    M4D_CHECK_ARG((int64_t)G * p.chunks <= 65535, "colsum: too many row chunks");
+    hipStream_t st = (hipStream_t)stream;
+#define COLSUM(TA, TB, HB) hipLaunchKernelGGL((colsum_kernel<TA, TB, HB>), grid, block, 0, st, p)
+    if (!b) { if (a_dt == M4D_BF16) COLSUM(bf16_t, bf16_t, false); else COLSUM(float, float, false); }
+    else if (a_dt == M4D_BF16 && b_dt == M4D_BF16) COLSUM(bf16_t, bf16_t, true);
+    else if (a_dt == M4D_F32 && b_dt == M4D_BF16) COLSUM(float, bf16_t, true);
+    else if (a_dt == M4D_BF16 && b_dt == M4D_F32) COLSUM(bf16_t, float, true);
+    else COLSUM(float, float, true);
+#undef COLSUM
+    M4D_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+extern "C" int m4d_scale_cast(const float* in, const float* gate, int64_t gate_stride, int64_t rows_per_sample,
+                              m4d_dtype out_dt, void* out, int64_t R, int64_t C, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(out_dt), "scale_cast: bad dtype");
+    M4D_CHECK_ARG(in && out && R > 0 && C > 0 && C % 4 == 0 && rows_per_sample > 0, "scale_cast: bad arguments");
+    ScArgs p{in, out, gate, R, C, rows_per_sample, gate_stride};
+    dim3 grid(grid_for(R * (C / 4), 256, 16384)), block(256);
+    if (out_dt == M4D_BF16) hipLaunchKernelGGL(scale_cast_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(scale_cast_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+    M4D_CHECK_LAUNCH("scale_cast");
+    return 0;
+}
+
+extern "C" int m4d_resid_gate(const float* x, m4d_dtype y_dt, const void* y, const float* gate, int64_t gate_stride,
+                              int64_t rows_per_sample, float* out, int64_t R, int64_t C, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(y_dt), "resid_gate: bad dtype");
+    M4D_CHECK_ARG(x && y && out && R > 0 && C > 0 && C % 4 == 0 && rows_per_sample > 0, "resid_gate: bad arguments");
+    RgArgs p{x, y, gate, out, R, C, rows_per_sample, gate_stride};
+    dim3 grid(grid_for(R * (C / 4), 256, 16384)), block(256);
+    if (y_dt == M4D_BF16) hipLaunchKernelGGL(resid_gate_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(resid_gate_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+    M4D_CHECK_LAUNCH("resid_gate");
+    return 0;
+}
+
+extern "C" int m4d_add(m4d_dtype dt, const void* a, const void* b, void* out, int64_t n, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dt), "add: bad dtype");
+    M4D_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0, "add: bad arguments");
+    dim3 grid(grid_for(n / 4, 256, 16384)), block(256);
+    if (dt == M4D_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else hipLaunchKernelGGL(add_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, n);
+    M4D_CHECK_LAUNCH("add");
+    return 0;
+}
+
+extern "C" int m4d_act_bwd(m4d_dtype dt, void* dy, const void* pre, int64_t n, int act, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dt), "act_bwd: bad dtype");
+    M4D_CHECK_ARG(dy && pre && n > 0 && n % 4 == 0 && act >= 1 && act <= 3, "act_bwd: bad arguments");
+    dim3 grid(grid_for(n / 4, 256, 16384)), block(256);
+    if (dt == M4D_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (bf16_t*)dy, (const bf16_t*)pre, n, act);
+    else hipLaunchKernelGGL(act_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)dy, (const float*)pre, n, act);
+    M4D_CHECK_LAUNCH("act_bwd");
+    return 0;
+}
+
+extern "C" int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* dy, float* dx, int B, int64_t rows_per_sample,
+                                   int C, const float* scale, int64_t mod_stride, const float* ln_w, float eps, float* dshift,
+                                   float* dscale, int64_t red_stride, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dy_dt), "ln_modulate_bwd: bad dtype");
+    M4D_CHECK_ARG(x && dy && dx && B > 0 && rows_per_sample > 0, "ln_modulate_bwd: bad arguments");
+    M4D_CHECK_ARG(C % 4 == 0 && C <= 8192, "ln_modulate_bwd: C=%d must be a multiple of 4 and <= 8192", C);
+    M4D_CHECK_ARG(!(scale && ln_w), "ln_modulate_bwd: scale and ln_w are exclusive");
+    M4D_CHECK_ARG((dshift == nullptr) == (dscale == nullptr), "ln_modulate_bwd: dshift and dscale come together");
+    LnBwdArgs p{x, dy, dx, scale, ln_w, dshift, dscale, rows_per_sample, mod_stride, red_stride, C, B, eps};
+    int64_t nb = (rows_per_sample + 3) / 4;
+    const int64_t cap = (1024 + B - 1) / B;     // ~4 waves per SIMD chip-wide; more only adds atomics
+    if (nb > cap) nb = cap;
+    dim3 grid((unsigned)nb, (unsigned)B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LNB(TD, MV) hipLaunchKernelGGL((ln_bwd_kernel<TD, MV>), grid, block, 0, st, p)
+    const bool bf = dy_dt == M4D_BF16;
+    if (C <= 2048) { if (bf) LNB(bf16_t, 8); else LNB(float, 8); }
+    else if (C <= 5120) { if (bf) LNB(bf16_t, 20); else LNB(float, 20); }
+    else { if (bf) LNB(bf16_t, 32); else LNB(float, 32); }
+#undef LNB
+    M4D_CHECK_LAUNCH("ln_modulate_bwd");
+    return 0;
+}
+
+extern "C" int m4d_rmsnorm_rope_bwd(m4d_dtype dt, void* dy0, void* dy1, int64_t ld_dy, const void* x0, const void* x1,
+                                    int64_t ld_x, const float* w0, const float* w1, float* dw0, float* dw1, int64_t rows,
+                                    int C, int head_dim, float eps, const float* cos_t, const float* sin_t,
+                                    int64_t rows_per_sample, int64_t rope_len, int64_t pos_offset, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dt), "rmsnorm_rope_bwd: bad dtype");
+    M4D_CHECK_ARG(dy0 && x0 && w0 && dw0 && rows > 0, "rmsnorm_rope_bwd: bad arguments");
+    M4D_CHECK_ARG((dy1 == nullptr) == (x1 == nullptr) && (!dy1 || (w1 && dw1)), "rmsnorm_rope_bwd: second tensor incomplete");
+    M4D_CHECK_ARG(C % 4 == 0 && C <= 8192 && ld_dy % 4 == 0 && ld_x % 4 == 0, "rmsnorm_rope_bwd: C / leading dims must be multiples of 4, C <= 8192");
+    M4D_CHECK_ARG(!cos_t || (head_dim % 4 == 0 && C % head_dim == 0 && sin_t), "rmsnorm_rope_bwd: bad rope configuration");
+    RmsBwdArgs p;
+    p.dy[0] = dy0; p.dy[1] = dy1; p.x[0] = x0; p.x[1] = x1; p.w[0] = w0; p.w[1] = w1; p.dw[0] = dw0; p.dw[1] = dw1;
+    p.cos_t = cos_t; p.sin_t = sin_t;
+    p.ld_dy = ld_dy; p.ld_x = ld_x; p.rows = rows; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows;
+    p.rope_len = rope_len; p.pos_offset = pos_offset; p.C = C; p.head_dim = head_dim > 0 ? head_dim : 4; p.eps = eps;
+    int64_t nb = (rows + 3) / 4;
+    if (nb > 512) nb = 512;
+    dim3 grid((unsigned)nb, dy1 ? 2u : 1u), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define RMB(T, MV) hipLaunchKernelGGL((rms_bwd_kernel<T, MV>), grid, block, 0, st, p)
+    const bool bf = dt == M4D_BF16;
+    if (C <= 2048) { if (bf) RMB(bf16_t, 8); else RMB(float, 8); }
+    else if (C <= 5120) { if (bf) RMB(bf16_t, 20); else RMB(float, 20); }
+    else { if (bf) RMB(bf16_t, 32); else RMB(float, 32); }
+#undef RMB
+    M4D_CHECK_LAUNCH("rmsnorm_rope_bwd");
+    return 0;
+}
+
+extern "C" int m4d_sumsq(m4d_dtype dt, const void* x, int64_t n, float* out, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dt), "sumsq: bad dtype");
+    M4D_CHECK_ARG(x && out && n > 0, "sumsq: bad arguments");
+    M4D_CHECK_ARG(((uintptr_t)x % 16) == 0, "sumsq: tensor must be 16-byte aligned");
+    dim3 grid(grid_for(n / 4 + 1, 256, 2048)), block(256);
+    if (dt == M4D_BF16) hipLaunchKernelGGL(sumsq_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, n, out);
+    else hipLaunchKernelGGL(sumsq_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, n, out);
+    M4D_CHECK_LAUNCH("sumsq");
+    return 0;
+}
+
+extern "C" int m4d_adamw(m4d_dtype dt, void* param, const void* grad, m4d_dtype state_dt, void* exp_avg, void* exp_avg_sq,
+                         int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                         const float* grad_scale, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dt) && DT_OK(state_dt), "adamw: bad dtype");
+    M4D_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adamw: bad arguments");
+    M4D_CHECK_ARG(state_dt == M4D_F32 || state_dt == dt, "adamw: optimizer state must be float32 or the parameter dtype");
+    AdamArgs a;
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.grad_scale = grad_scale;
+    dim3 grid(grid_for(n, 256, 8192)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == M4D_BF16 && state_dt == M4D_BF16) hipLaunchKernelGGL((adamw_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);
+    else if (dt == M4D_BF16) hipLaunchKernelGGL((adamw_kernel<bf16_t, float>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((adamw_kernel<float, float>), grid, block, 0, st, a);
+    M4D_CHECK_LAUNCH("adamw");
+    return 0;
+}

@@ -607,6 +607,8 @@ class WanTransformer4DModel(nn.Module):
         if first_frame is not None and self.use_omnimae_guidance and first_frame_features is None:
             raise NotImplementedError("pass OmniMAE outputs via first_frame_features=(patch_feats, cls); the ViT-B "
                                       "extractor is outside the hot path (SURVEY §8f rank 3)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(x, t, context, seq_len, clip_fea, y, full_ref, first_frame_features)
         T, dev = self.dtype, self.device
         B = x.shape[0]
         x = x.to(dev)
@@ -703,6 +705,82 @@ class WanTransformer4DModel(nn.Module):
             out = sp.all_gather(out, dim=1)
         res = ops.unpatchify(out.contiguous(), n_ref, (f, h, w), self.patch_size, self.out_dim, T)
         return res
+
+    # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
+    def _forward_train(self, x, t, context, seq_len, clip_fea=None, y=None, full_ref=None, first_frame_features=None):
+        """Differentiable forward for `train_wan.py:1939-1951` (same arguments, same result as `forward`): every node
+        is a `more4d_amd.autograd` Function whose forward AND backward run in the HIP kernels; one recomputing node per
+        block (the reference trains with gradient checkpointing, :1273-1291).  Data parallel only."""
+        from ..autograd import ActFn, BlockFn, LayerNormFn, LinearFn
+        from ..ops import ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU
+        if self.sp_world_size > 1:
+            raise NotImplementedError("training is data parallel (DDP); sequence parallelism is the inference path")
+        if self.teacache is not None:
+            raise NotImplementedError("TeaCache is an inference-time approximation")
+        if first_frame_features is not None and self.use_omnimae_guidance:
+            raise NotImplementedError("spatial-guidance gradients are not built yet (DESIGN.md, out of scope this round)")
+        if isinstance(context, ContextCache):
+            raise ValueError("training needs the raw text embeddings (the context projections are trainable)")
+        if t.dim() != 1:
+            raise NotImplementedError("per-token timesteps (ti2v) are not part of the 4D-STraG path")
+        T, dev, C = self.dtype, self.device, self.dim
+        f32 = torch.float32
+        B = x.shape[0]
+        x = x.to(dev)
+        if y is not None:
+            y = y.to(device=dev, dtype=x.dtype)
+        pt, ph, pw = self.patch_size
+        f, h, w = x.shape[2] // pt, x.shape[3] // ph, x.shape[4] // pw
+        Lv, n_ref, grid = f * h * w, 0, (f, h, w)
+        if self.ref_conv is not None and full_ref is not None:
+            n_ref, grid = h * w, (f + 1, h, w)
+            seq_len = seq_len + n_ref
+        L = Lv + n_ref
+        key_len = L if self.mask_padding_keys else seq_len
+        assert L <= seq_len, f"sequence of {L} tokens exceeds seq_len={seq_len}"
+        Lp = _round8(seq_len)
+        # ---- tokens
+        parts = []
+        if n_ref:
+            rt = ops.patchify(full_ref.to(dev).unsqueeze(2), None, (1, ph, pw), T)
+            parts.append(LinearFn.apply(rt, self.ref_conv.weight, self.ref_conv.bias, 0, T, True))
+        parts.append(LinearFn.apply(ops.patchify(x, y, self.patch_size, T), self.patch_embedding.weight,
+                                    self.patch_embedding.bias, 0, T, True))
+        if Lp > L:
+            parts.append(torch.zeros((B, Lp - L, C), device=dev, dtype=f32))
+        xres = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
+        # ---- conditioning (float32 like the inference path, :1160-1171)
+        te0, te2, tp = self.time_embedding[0], self.time_embedding[2], self.time_projection[1]
+        s = sinusoidal_embedding_1d(self.freq_dim, t.to(dev)).float().contiguous()
+        e = LinearFn.apply(LinearFn.apply(s, te0.weight, te0.bias, ACT_SILU, f32, True), te2.weight, te2.bias, 0, f32, True)
+        e0 = LinearFn.apply(ActFn.apply(e, ACT_SILU, f32), tp.weight, tp.bias, 0, f32, True).view(B, 6, C)
+        Tp = _round8(self.text_len)
+        txt = torch.zeros((B, Tp, self.text_dim), device=dev, dtype=T)
+        for i, u in enumerate(context):
+            txt[i, :u.size(0)] = u.to(device=dev, dtype=T)
+        te = self.text_embedding
+        ctx_txt = LinearFn.apply(LinearFn.apply(txt, te[0].weight, te[0].bias, ACT_GELU_TANH, T, False),
+                                 te[2].weight, te[2].bias, 0, T, False)
+        ctx_img, img_len = None, 0
+        if clip_fea is not None and self.model_type == 'i2v':
+            n = clip_fea.shape[1]
+            src = torch.zeros((B, _round8(n), clip_fea.shape[2]), device=dev, dtype=f32)
+            src[:, :n] = clip_fea.to(dev)
+            p = self.img_emb.proj
+            a = LayerNormFn.apply(src, p[0].weight, p[0].bias, None, None, p[0].eps, T)
+            a = LinearFn.apply(a, p[1].weight, p[1].bias, ACT_GELU_ERF, T, False)
+            a = LinearFn.apply(a, p[3].weight, p[3].bias, 0, T, True)
+            ctx_img, img_len = LayerNormFn.apply(a, p[4].weight, p[4].bias, None, None, p[4].eps, T), n
+        cos, sin = self._rope_tables(grid, dev)
+        c = _Ctx(B, L, Lp, grid, cos, sin, L, self._f32cache, key_len)
+        for blk in self.blocks:
+            xres = BlockFn.apply(xres, e0, ctx_txt, ctx_img, blk, c, self.text_len, img_len, *blk.parameters())
+        # ---- head (:708-721) + unpatchify (:1343-1366)
+        m = e.view(B, 1, C) + self.head.modulation.float()
+        xn = LayerNormFn.apply(xres, None, None, m[:, 0], m[:, 1], self.head.eps, T)
+        out = LinearFn.apply(xn, self.head.head.weight, self.head.head.bias, 0, T, True)
+        u = out[:, n_ref:n_ref + Lv].reshape(B, f, h, w, pt, ph, pw, self.out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
+        return u.reshape(B, self.out_dim, f * pt, h * ph, w * pw).to(T)
 
     def _guidance_tables(self, feats, hw, latent_T):
         """OmniMAE patch features -> SiLU'd, adapter-convolved, resized [B, h*w, 768] table (reference

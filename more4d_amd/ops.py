@@ -194,8 +194,9 @@ class KV:
         self.k, self.vt, self.k_bs, self.k_ls, self.vt_bs, self.vt_ls, self.len = k, vt, k_bs, k_ls, vt_bs, vt_ls, length
 
 
-def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None):
-    """softmax(q k^T * scale) v over the concatenation of `segs` (list of KV).  q/out: [B, Lq, heads*head_dim]."""
+def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None, lse=None):
+    """softmax(q k^T * scale) v over the concatenation of `segs` (list of KV).  q/out: [B, Lq, heads*head_dim].
+    lse: optional float32 [B, heads, Lq] receiving the log2-domain log-sum-exp (training)."""
     _dev(q, out, *[s.k for s in segs], *[s.vt for s in segs])
     C = heads * head_dim
     if q_ls is None:
@@ -216,6 +217,14 @@ def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None
     if scale is None:
         scale = 1.0 / math.sqrt(head_dim)
     lib = _lib.load()
+    if lse is not None:
+        _dev(lse)
+        if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != B * heads * Lq:
+            raise ValueError("attention: lse must be contiguous float32 [B, heads, Lq]")
+        check(lib.m4d_attention_lse(dt_code(q.dtype), _ptr(q), q_bs, q_ls, kv, _ptr(out), out.stride(0), out.stride(1),
+                                    B, Lq, heads, head_dim, scale, int(accumulate), _ptr(lse), _stream()),
+              "m4d_attention_lse")
+        return out
     check(lib.m4d_attention(dt_code(q.dtype), _ptr(q), q_bs, q_ls, kv, _ptr(out), out.stride(0), out.stride(1), B, Lq,
                             heads, head_dim, scale, int(accumulate), _stream()), "m4d_attention")
     return out
@@ -271,7 +280,7 @@ def cfg_euler_(x, v, guidance, dsigma, round_dtype=torch.float32):
 
 
 def unary(x, out_dtype, act=0, out=None):
-    """act: 0 cast, 1 silu, 2 gelu(tanh)."""
+    """act: 0 cast, 1 silu, 2 gelu(tanh), 3 gelu(erf)."""
     _dev(x, out)
     x = x.contiguous()
     if out is None:
@@ -443,3 +452,158 @@ def bilinear_cl(x, out_hw):
     check(lib.m4d_bilinear_cl(dt_code(x.dtype), _ptr(x), _ptr(out), B, Hi, Wi, out_hw[0], out_hw[1], C, _stream()),
           "m4d_bilinear_cl")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- training step
+
+def transpose(x, out=None):
+    """out[c, r] = x[r, c] for a 2-D matrix (row stride = x.stride(0))."""
+    _dev(x, out)
+    R, C = x.shape
+    if out is None:
+        out = torch.empty((C, R), device=x.device, dtype=x.dtype)
+    check(_lib.load().m4d_transpose(dt_code(x.dtype), _ptr(x), x.stride(0), _ptr(out), out.stride(0), R, C, _stream()),
+          "m4d_transpose")
+    return out
+
+
+def colsum(a, b=None, *, rows_per_group=None, out=None):
+    """float32 [G, C]: sum over the rows of each group of a (* b).  a, b: [R, C] (row strides honoured)."""
+    _dev(a, b, out)
+    R, C = a.shape
+    if rows_per_group is None:
+        rows_per_group = R
+    G = (R + rows_per_group - 1) // rows_per_group
+    if out is None:
+        out = torch.zeros((G, C), device=a.device, dtype=torch.float32)
+    check(_lib.load().m4d_colsum(dt_code(a.dtype), _ptr(a), a.stride(0), dt_code(b.dtype) if b is not None else 0, _ptr(b),
+                                 b.stride(0) if b is not None else 0, _ptr(out), R, C, rows_per_group, _stream()),
+          "m4d_colsum")
+    return out
+
+
+def scale_cast(x, out_dtype, *, gate=None, gate_stride=0, rows_per_sample=0, out=None):
+    """out_dtype [R, C] = float32 x [R, C] * gate[sample, :]."""
+    _dev(x, gate, out)
+    C = x.shape[-1]
+    R = x.numel() // C
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    check(_lib.load().m4d_scale_cast(_ptr(x), _ptr(gate), gate_stride, rows_per_sample or R, dt_code(out_dtype), _ptr(out),
+                                     R, C, _stream()), "m4d_scale_cast")
+    return out
+
+
+def resid_gate(x, y, *, gate=None, gate_stride=0, rows_per_sample=0, out=None):
+    """float32 out = x + y * gate[sample, :]  (x float32 [.., C], y T of the same shape)."""
+    _dev(x, y, gate, out)
+    C = x.shape[-1]
+    R = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().m4d_resid_gate(_ptr(x), dt_code(y.dtype), _ptr(y), _ptr(gate), gate_stride, rows_per_sample or R,
+                                     _ptr(out), R, C, _stream()), "m4d_resid_gate")
+    return out
+
+
+def add(a, b, out=None):
+    """out = a + b for contiguous tensors of one dtype (numel % 4 == 0)."""
+    _dev(a, b, out)
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.load().m4d_add(dt_code(a.dtype), _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "m4d_add")
+    return out
+
+
+ACT_SILU, ACT_GELU_TANH, ACT_GELU_ERF = 1, 2, 3
+
+
+def act_bwd_(dy, pre, act):
+    """dy *= act'(pre) in place."""
+    _dev(dy, pre)
+    if dy.dtype != pre.dtype or not dy.is_contiguous() or not pre.is_contiguous():
+        raise ValueError("act_bwd_: contiguous tensors of one dtype")
+    check(_lib.load().m4d_act_bwd(dt_code(dy.dtype), _ptr(dy), _ptr(pre), dy.numel(), act, _stream()), "m4d_act_bwd")
+    return dy
+
+
+def ln_modulate_bwd(x, dy, dx, *, B, rows_per_sample, scale=None, mod_stride=0, ln_w=None, eps=1e-6, dshift=None,
+                    dscale=None, red_stride=0):
+    """dx (float32, accumulated in place) += LayerNorm-input gradient; dshift/dscale accumulate sum(dy), sum(dy*xhat)."""
+    _dev(x, dy, dx, scale, ln_w, dshift, dscale)
+    C = x.shape[-1]
+    check(_lib.load().m4d_ln_modulate_bwd(_ptr(x), dt_code(dy.dtype), _ptr(dy), _ptr(dx), B, rows_per_sample, C, _ptr(scale),
+                                          mod_stride, _ptr(ln_w), eps, _ptr(dshift), _ptr(dscale), red_stride, _stream()),
+          "m4d_ln_modulate_bwd")
+    return dx
+
+
+def rmsnorm_rope_bwd_(dy0, x0, w0, dw0, dy1=None, x1=None, w1=None, dw1=None, *, head_dim, eps=1e-6, cos=None, sin=None,
+                      rows_per_sample=0, rope_len=0, pos_offset=0):
+    """In place: dy{0,1} [rows, C] become the gradients w.r.t. the pre-norm inputs x{0,1}; dw{0,1} accumulate."""
+    _dev(dy0, x0, w0, dw0, dy1, x1, w1, dw1, cos, sin)
+    rows, ld = _rows2d(dy0)
+    _, ldx = _rows2d(x0)
+    if dy1 is not None and (_rows2d(dy1) != (rows, ld) or _rows2d(x1)[1] != ldx):
+        raise ValueError("rmsnorm_rope_bwd_: both tensors must share shape and strides")
+    C = dy0.shape[-1]
+    check(_lib.load().m4d_rmsnorm_rope_bwd(dt_code(dy0.dtype), _ptr(dy0), _ptr(dy1), ld, _ptr(x0), _ptr(x1), ldx, _ptr(w0),
+                                           _ptr(w1), _ptr(dw0), _ptr(dw1), rows, C, head_dim, eps, _ptr(cos), _ptr(sin),
+                                           rows_per_sample or rows, rope_len, pos_offset, _stream()),
+          "m4d_rmsnorm_rope_bwd")
+
+
+def attention_bwd(q, k, v, o, d_o, lse, *, B, Lq, Lk, Lk_rows, heads, head_dim, dq, dk, dv, scale=None,
+                  accumulate_dq=False, accumulate_dkv=False):
+    """Gradients of attention(): q, o, d_o, dq are [B*Lq, C]-shaped matrices (row stride honoured), k, v, dk, dv
+    [B*Lk_rows, C]; only the first Lk keys of each sample are real.  The transposed operands are built here."""
+    _dev(q, k, v, o, d_o, lse, dq, dk, dv)
+    C = heads * head_dim
+    for t in (q, k, v, o, d_o, dq, dk, dv):
+        if t.dtype != q.dtype or t.stride(-1) != 1:
+            raise TypeError("attention_bwd: operands must share a dtype and be row-major")
+        if t.dim() != 2 or t.shape[1] != C:
+            raise ValueError("attention_bwd: operands are 2-D [rows, heads*head_dim] matrices")
+    qt, kt, dot = transpose(q), transpose(k), transpose(d_o)
+    delta = torch.empty((B, heads, Lq), device=q.device, dtype=torch.float32)
+    a = _lib.AttnBwdArgs()
+    a.q, a.k, a.v, a.o, a.d_o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr()
+    a.qt, a.kt, a.dot, a.lse, a.delta = qt.data_ptr(), kt.data_ptr(), dot.data_ptr(), lse.data_ptr(), delta.data_ptr()
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+
+    def st(t, L):
+        return L * t.stride(0), t.stride(0)
+
+    a.q_bs, a.q_ls = st(q, Lq)
+    a.k_bs, a.k_ls = st(k, Lk_rows)
+    a.v_bs, a.v_ls = st(v, Lk_rows)
+    a.o_bs, a.o_ls = st(o, Lq)
+    a.do_bs, a.do_ls = st(d_o, Lq)
+    a.dq_bs, a.dq_ls = st(dq, Lq)
+    a.dk_bs, a.dk_ls = st(dk, Lk_rows)
+    a.dv_bs, a.dv_ls = st(dv, Lk_rows)
+    a.qt_bs, a.qt_ls = Lq, B * Lq
+    a.kt_bs, a.kt_ls = Lk_rows, B * Lk_rows
+    a.dot_bs, a.dot_ls = Lq, B * Lq
+    a.Lq, a.Lk, a.Lk_rows = Lq, Lk, Lk_rows
+    a.B, a.heads, a.head_dim = B, heads, head_dim
+    a.accumulate_dq, a.accumulate_dkv = int(accumulate_dq), int(accumulate_dkv)
+    a.scale = scale if scale is not None else 1.0 / math.sqrt(head_dim)
+    check(_lib.load().m4d_attention_bwd(dt_code(q.dtype), a, _stream()), "m4d_attention_bwd")
+
+
+def sumsq(x, out):
+    """out (float32 scalar tensor) += sum(x^2)."""
+    _dev(x, out)
+    check(_lib.load().m4d_sumsq(dt_code(x.dtype), _ptr(x), x.numel(), _ptr(out), _stream()), "m4d_sumsq")
+    return out
+
+
+def adamw_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+    _dev(p, g, m, v, grad_scale)
+    if not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()):
+        raise ValueError("adamw_: contiguous tensors required")
+    if g.dtype != p.dtype or m.dtype != v.dtype:
+        raise TypeError("adamw_: dtype mismatch")
+    check(_lib.load().m4d_adamw(dt_code(p.dtype), _ptr(p), _ptr(g), dt_code(m.dtype), _ptr(m), _ptr(v), p.numel(), lr, beta1,
+                                beta2, eps, weight_decay, step, _ptr(grad_scale), _stream()), "m4d_adamw")

@@ -118,7 +118,7 @@ def rmsnorm_rope(x0, w0, x1=None, w1=None, *, head_dim, eps=1e-6, cos=None, sin=
     return x0, x1
 
 
-def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None):
+def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None, lse=None):
     C = heads * head_dim
     if q_ls is None:
         q_ls = C
@@ -137,6 +137,8 @@ def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None
     v = torch.cat(vs, 1).view(B, -1, heads, head_dim)
     sc = scale if scale is not None else 1.0 / math.sqrt(head_dim)
     s_ = torch.einsum("bqhd,bkhd->bhqk", qf, k) * sc
+    if lse is not None:
+        lse.copy_(torch.logsumexp(s_, -1) * 1.4426950408889634)
     o = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s_, -1), v).reshape(B, Lq, C).to(q.dtype)
     if out is None:
         return o
@@ -176,6 +178,8 @@ def unary(x, out_dtype, act=0, out=None):
         y = F.silu(y)
     elif act == 2:
         y = F.gelu(y, approximate="tanh")
+    elif act == 3:
+        y = F.gelu(y)
     y = y.to(out_dtype)
     if out is not None:
         out.copy_(y)
@@ -302,3 +306,157 @@ def rel_l1(prev, cur):
 def bilinear_cl(x, out_hw):
     y = F.interpolate(x.float().permute(0, 3, 1, 2), size=tuple(out_hw), mode="bilinear", align_corners=False)
     return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
+# ------------------------------------------------------------------ training-step ops
+NAMES += ["transpose", "colsum", "scale_cast", "resid_gate", "add", "act_bwd_", "ln_modulate_bwd", "rmsnorm_rope_bwd_",
+          "attention_bwd", "sumsq", "adamw_"]
+
+
+def transpose(x, out=None):
+    if out is None:
+        return x.t().contiguous()
+    out.copy_(x.t())
+    return out
+
+
+def colsum(a, b=None, *, rows_per_group=None, out=None):
+    R, C = a.shape
+    rpg = rows_per_group or R
+    v = a.float() if b is None else a.float() * b.float()
+    G = (R + rpg - 1) // rpg
+    res = torch.stack([v[g * rpg:(g + 1) * rpg].sum(0) for g in range(G)])
+    if out is None:
+        return res
+    out += res.view(out.shape)
+    return out
+
+
+def scale_cast(x, out_dtype, *, gate=None, gate_stride=0, rows_per_sample=0, out=None):
+    C = x.shape[-1]
+    R = x.numel() // C
+    y = x.reshape(R, C).float()
+    if gate is not None:
+        rps = rows_per_sample or R
+        y = y * _strided_rows(gate, R // rps, gate_stride, C).repeat_interleave(rps, dim=0)
+    y = y.to(out_dtype).view(x.shape)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def resid_gate(x, y, *, gate=None, gate_stride=0, rows_per_sample=0, out=None):
+    C = x.shape[-1]
+    R = x.numel() // C
+    v = y.reshape(R, C).float()
+    if gate is not None:
+        rps = rows_per_sample or R
+        v = v * _strided_rows(gate, R // rps, gate_stride, C).repeat_interleave(rps, dim=0)
+    res = x.reshape(R, C) + v
+    if out is None:
+        return res.view(x.shape)
+    out.copy_(res.view(out.shape))
+    return out
+
+
+def add(a, b, out=None):
+    res = (a.float() + b.float()).to(a.dtype)
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+@torch.enable_grad()
+def act_bwd_(dy, pre, act):
+    x = pre.float().detach().requires_grad_(True)
+    y = {1: F.silu, 2: lambda t: F.gelu(t, approximate="tanh"), 3: F.gelu}[act](x)
+    (g,) = torch.autograd.grad(y, x, dy.float())
+    dy.copy_(g.to(dy.dtype))
+    return dy
+
+
+@torch.enable_grad()
+def ln_modulate_bwd(x, dy, dx, *, B, rows_per_sample, scale=None, mod_stride=0, ln_w=None, eps=1e-6, dshift=None,
+                    dscale=None, red_stride=0):
+    C = x.shape[-1]
+    rps = rows_per_sample
+    xf = x.reshape(B, rps, C).float().detach().requires_grad_(True)
+    mu = xf.mean(-1, keepdim=True)
+    xh = (xf - mu) * torch.rsqrt((xf - mu).pow(2).mean(-1, keepdim=True) + eps)
+    if scale is not None:
+        m = 1 + _strided_rows(scale, B, mod_stride, C).view(B, 1, C)
+    elif ln_w is not None:
+        m = ln_w.view(1, 1, C)
+    else:
+        m = 1.0
+    g = dy.reshape(B, rps, C).float()
+    (gx,) = torch.autograd.grad(xh * m, xf, g)
+    dx += gx.view(dx.shape)
+    if dshift is not None:
+        G = B if red_stride else 1
+        s1 = g.sum(1) if red_stride else g.sum((0, 1)).view(1, C)
+        s2 = (g * xh.detach()).sum(1) if red_stride else (g * xh.detach()).sum((0, 1)).view(1, C)
+        torch.as_strided(dshift, (G, C), (max(red_stride, 1), 1), dshift.storage_offset()).add_(s1)
+        torch.as_strided(dscale, (G, C), (max(red_stride, 1), 1), dscale.storage_offset()).add_(s2)
+    return dx
+
+
+@torch.enable_grad()
+def rmsnorm_rope_bwd_(dy0, x0, w0, dw0, dy1=None, x1=None, w1=None, dw1=None, *, head_dim, eps=1e-6, cos=None, sin=None,
+                      rows_per_sample=0, rope_len=0, pos_offset=0):
+    for dy, x, w, dw in ((dy0, x0, w0, dw0), (dy1, x1, w1, dw1)):
+        if dy is None:
+            continue
+        C = x.shape[-1]
+        rows = x.numel() // C
+        rps = rows_per_sample or rows
+        xf = x.reshape(rows, C).float().detach().requires_grad_(True)
+        wf = w.detach().clone().requires_grad_(True)
+        y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * wf
+        if cos is not None:
+            y5 = y.view(rows // rps, rps, C // head_dim, head_dim // 2, 2)
+            n = min(rope_len, rps)
+            c = cos[pos_offset:pos_offset + n].view(1, n, 1, -1)
+            s = sin[pos_offset:pos_offset + n].view(1, n, 1, -1)
+            a, b = y5[:, :n, :, :, 0], y5[:, :n, :, :, 1]
+            rot = torch.stack([a * c - b * s, a * s + b * c], -1)
+            y = torch.cat([rot, y5[:, n:]], 1).reshape(rows, C)
+        gx, gw = torch.autograd.grad(y, (xf, wf), dy.reshape(rows, C).float())
+        dy.copy_(gx.to(dy.dtype).view(dy.shape))
+        dw += gw
+
+
+@torch.enable_grad()
+def attention_bwd(q, k, v, o, d_o, lse, *, B, Lq, Lk, Lk_rows, heads, head_dim, dq, dk, dv, scale=None,
+                  accumulate_dq=False, accumulate_dkv=False):
+    C = heads * head_dim
+    qf = q.reshape(B, Lq, heads, head_dim).float().detach().requires_grad_(True)
+    kf = k.reshape(B, Lk_rows, heads, head_dim).float().detach().requires_grad_(True)
+    vf = v.reshape(B, Lk_rows, heads, head_dim).float().detach().requires_grad_(True)
+    sc = scale if scale is not None else 1.0 / math.sqrt(head_dim)
+    s_ = torch.einsum("bqhd,bkhd->bhqk", qf, kf[:, :Lk]) * sc
+    out = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s_, -1), vf[:, :Lk]).reshape(B * Lq, C)
+    gq, gk, gv = torch.autograd.grad(out, (qf, kf, vf), d_o.reshape(B * Lq, C).float())
+    for dst, g, acc in ((dq, gq, accumulate_dq), (dk, gk, accumulate_dkv), (dv, gv, accumulate_dkv)):
+        g = g.reshape(dst.shape)
+        dst.copy_((dst.float() + g).to(dst.dtype) if acc else g.to(dst.dtype))
+
+
+def sumsq(x, out):
+    out += x.float().pow(2).sum()
+    return out
+
+
+def adamw_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+    gf = g.float() * (float(grad_scale) if grad_scale is not None else 1.0)
+    pf, mf, vf = p.float(), m.float(), v.float()
+    pf = pf * (1 - lr * weight_decay)
+    mf = beta1 * mf + (1 - beta1) * gf
+    vf = beta2 * vf + (1 - beta2) * gf * gf
+    denom = vf.sqrt() / math.sqrt(1 - beta2 ** step) + eps
+    pf = pf - lr / (1 - beta1 ** step) * mf / denom
+    p.copy_(pf.to(p.dtype))
+    m.copy_(mf.to(m.dtype))
+    v.copy_(vf.to(v.dtype))

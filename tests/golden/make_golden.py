@@ -86,6 +86,37 @@ def make_dit_tiny(ref):
              seq_len_pad=np.int64(L + 5), seq_len=np.int64(L), out_ref=out_ref, out_noref=out_noref)
 
 
+def grad_sample(g, n=4096):
+    """Deterministic subsample of a gradient tensor (keeps the fixture small): every k-th element."""
+    flat = g.detach().reshape(-1)
+    k = max(1, flat.numel() // n)
+    return flat[::k][:n].clone()
+
+
+def make_dit_grads(ref):
+    """Training-step contract (train_wan.py:1939-1988): reference forward with autograd, thresholded-MSE loss
+    (custom_mse_loss :1953-1963, threshold 50, unit weighting), loss.backward(); per-parameter gradient norms and
+    subsampled gradient values of every parameter of the tiny DiT, on the dit_tiny.npz inputs (with ref row)."""
+    z = dict(np.load(os.path.join(HERE, "dit_tiny.npz")))
+    z = {k: torch.from_numpy(v) for k, v in z.items()}
+    with torch.enable_grad():
+        m = ref.dit.WanTransformer4DModel(**TINY_DIT).train()
+        load_recipe(m, None, seed=1234)
+        target = torch.randn(z["out_ref"].shape, generator=torch.Generator().manual_seed(21))
+        pred = m(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"],
+                 y=z["y"], full_ref=z["full_ref"])
+        diff = pred.float() - target
+        loss = (torch.nn.functional.mse_loss(pred.float(), target, reduction="none") * (diff.abs() <= 50).float()).mean()
+        loss.backward()
+    out = {"target": target, "loss": loss.detach(), "pred": pred.detach()}
+    for name, p_ in m.named_parameters():
+        if p_.grad is None:
+            continue
+        out["norm/" + name] = p_.grad.norm()
+        out["grad/" + name] = grad_sample(p_.grad)
+    npz_save("dit_tiny_grads.npz", **out)
+
+
 def make_dit_ops(ref):
     """Per-op vectors: sinusoid, rope (incl. padded tail), rmsnorm, LN-modulate, SDPA,
     self-attn, cross-attn, block (with and without spatial guidance), head."""
@@ -294,6 +325,8 @@ if __name__ == "__main__":
     if what in ("dit", "all"):
         make_dit_tiny(ref)
         make_dit_ops(ref)
+    if what in ("grads", "all"):
+        make_dit_grads(ref)
     if what in ("dit14b", "all"):
         make_block_14b_width(ref)
     if what in ("loop", "all"):
