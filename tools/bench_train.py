@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Train-step time of the 14B-shaped DiT (BASELINE.json configs[4] per-GPU work: batch 1, 49x480x832 latents,
+fwd + per-block recompute + bwd + clip + AdamW, bf16).  Usage:
+    python tools/bench_train.py [--layers 40] [--steps 2] [--warmup 1] [--profile-ops]
+With WORLD_SIZE > 1 (torch.distributed.run) the model is wrapped in DDP over RCCL (data parallel, one sample/GPU).
+Prints one JSON line: seconds per step, model FLOPs (4x forward) and the MFMA fraction."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import CFG_14B, MFMA_BF16_PEAK_TF, build_model, flops_per_forward  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--fp32-state", action="store_true")
+    ap.add_argument("--profile-ops", action="store_true", help="HIP-event time per ops.* entry point (adds syncs)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from more4d_amd import ops
+    from more4d_amd.optim import AdamW, clip_grad_norm_
+    cfg = dict(CFG_14B)
+    cfg["num_layers"] = args.layers
+    model = build_model(cfg, dev, torch.bfloat16).train()
+    net = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True,
+                  bucket_cap_mb=512)
+    opt = AdamW(model.parameters(), lr=2e-5, weight_decay=3e-2, eps=1e-10,
+                state_dtype=torch.float32 if args.fp32_state else None)
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    F_, H_, W_ = 13, 60, 104
+    lat = torch.randn(1, 16, F_, H_, W_, generator=g, device=dev)
+    noise = torch.randn(1, 16, F_, H_, W_, generator=g, device=dev)
+    y = torch.randn(1, 48, F_, H_, W_, generator=g, device=dev).bfloat16()
+    full_ref = torch.randn(1, 16, H_, W_, generator=g, device=dev).bfloat16()
+    ctx = [torch.randn(512, 4096, generator=g, device=dev)]
+    clip = torch.randn(1, 257, 1280, generator=g, device=dev)
+    Lv = F_ * (H_ // 2) * (W_ // 2)
+    L = Lv + (H_ // 2) * (W_ // 2)
+    sigma = 0.7
+    noisy = ((1 - sigma) * lat + sigma * noise).bfloat16()      # train_wan.py:1926
+    target = noise - lat                                        # :1929
+    t = torch.tensor([sigma * 1000.0], device=dev)
+
+    timers = {}
+    if args.profile_ops:
+        for name in ("gemm_bt", "attention", "attention_bwd", "transpose", "ln_modulate", "ln_modulate_bwd", "rmsnorm_rope",
+                     "rmsnorm_rope_bwd_", "colsum", "scale_cast", "resid_gate", "act_bwd_", "unary", "add", "adamw_", "sumsq"):
+            orig = getattr(ops, name)
+
+            def wrapped(*a, _o=orig, _n=name, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _o(*a, **k)
+                e.record()
+                timers.setdefault(_n, []).append((s, e))
+                return r
+            setattr(ops, name, wrapped)
+        import more4d_amd.autograd as ag
+        import more4d_amd.models.wan_transformer4d as wt
+        ag.ops = ops
+        wt.ops = ops
+
+    def step():
+        pred = net(x=noisy, t=t, context=ctx, seq_len=Lv, clip_fea=clip, y=y, full_ref=full_ref)
+        diff = pred.float() - target
+        loss = (diff * diff * (diff.abs() <= 50).float()).mean()            # custom_mse_loss :1953-1963
+        loss.backward()
+        clip_grad_norm_(model.parameters(), 0.05, optimizer=opt)
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    timers.clear()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = (time.perf_counter() - t0) / args.steps
+    gf, af = flops_per_forward(cfg, L, 1)
+    # fwd + recompute + bwd: GEMMs 1 + 1 + 2, attention 1 + 1 + 2.5 (five matmuls per pair instead of two)
+    model_flops = 4 * gf + 4.5 * af
+    out = {"metric": "train-step seconds, 14B DiT fwd+recompute+bwd+AdamW, batch 1/GPU, 49x480x832 bf16",
+           "value": dt, "unit": "s/step", "n_gpus": world, "layers": args.layers, "loss": float(loss.detach()),
+           "model_tflop": model_flops / 1e12, "mfma_frac": model_flops / dt / 1e12 / MFMA_BF16_PEAK_TF,
+           "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+           "state_dtype": "float32" if args.fp32_state else "bfloat16"}
+    if timers:
+        torch.cuda.synchronize()
+        out["ops_ms_per_step"] = {k: round(sum(s.elapsed_time(e) for s, e in v) / args.steps, 2) for k, v in
+                                  sorted(timers.items(), key=lambda kv: -sum(s.elapsed_time(e) for s, e in kv[1]))}
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
