@@ -13,6 +13,7 @@
 // role V^T plays in the forward; the host supplies them (m4d_transpose, HBM-bound, <2 % of the pass).
 // lse is the forward's log2-domain log-sum-exp, delta[q] = sum_d dO[q,d] O[q,d] (m4d_attention_bwd computes it).
 // Workgroup = 4 waves x 32 X rows; one wave per SIMD (512 VGPRs: two fragment sets + two accumulators).
+#include <stdlib.h>
 #include "common.h"
 #include "attn_common.h"
 #include "more4d_hip.h"
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(BwdArgs p) {
     }
 }
 
+#include "attention_bwd128.h"
+
 // delta[b, h, l] = sum_d dO[b, l, h, d] * O[b, l, h, d];  16 lanes x 8 elements per (row, head) for D = 128
 struct DeltaArgs {
     const void *o, *d_o; float* delta;
@@ -319,6 +322,32 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
     BwdArgs p;
     p.lse = a->lse; p.delta = a->delta; p.Lq = a->Lq;
     p.B = a->B; p.heads = a->heads; p.scale = a->scale; p.sc = a->scale * 1.4426950408889634f;
+    if (bf && a->head_dim == 128 && !getenv("M4D_ATTN_BWD_GENERIC")) {
+        // production path: three forward-shaped passes (attention_bwd128.h)
+        p.ybt = nullptr; p.ybt_bs = p.ybt_ls = 0; p.out_b = nullptr; p.ob_bs = p.ob_ls = 0;
+        // dQ: X = (Q, dO), Y = (K, V, K^T)
+        p.xa = a->q; p.xa_bs = a->q_bs; p.xa_ls = a->q_ls; p.xb = a->d_o; p.xb_bs = a->do_bs; p.xb_ls = a->do_ls;
+        p.ya = a->k; p.ya_bs = a->k_bs; p.ya_ls = a->k_ls; p.yb = a->v; p.yb_bs = a->v_bs; p.yb_ls = a->v_ls;
+        p.yat = a->kt; p.yat_bs = a->kt_bs; p.yat_ls = a->kt_ls;
+        p.out_a = a->dq; p.oa_bs = a->dq_bs; p.oa_ls = a->dq_ls;
+        p.LX = p.LXs = a->Lq; p.LY = a->Lk; p.nx_tiles = (int)((a->Lq + 255) / 256); p.accumulate = a->accumulate_dq;
+        if (launch_bwd128<BWD_DQ>(p, st)) { m4d_set_error("attention_bwd: cannot configure the dq kernel"); return -3; }
+        M4D_CHECK_LAUNCH("attention_bwd(dq128)");
+        // dK: X = (K, V), Y = (Q, dO, Q^T)
+        p.xa = a->k; p.xa_bs = a->k_bs; p.xa_ls = a->k_ls; p.xb = a->v; p.xb_bs = a->v_bs; p.xb_ls = a->v_ls;
+        p.ya = a->q; p.ya_bs = a->q_bs; p.ya_ls = a->q_ls; p.yb = a->d_o; p.yb_bs = a->do_bs; p.yb_ls = a->do_ls;
+        p.yat = a->qt; p.yat_bs = a->qt_bs; p.yat_ls = a->qt_ls;
+        p.out_a = a->dk; p.oa_bs = a->dk_bs; p.oa_ls = a->dk_ls;
+        p.LX = a->Lk; p.LXs = a->Lk_rows; p.LY = a->Lq; p.nx_tiles = (int)((a->Lk_rows + 255) / 256); p.accumulate = a->accumulate_dkv;
+        if (launch_bwd128<BWD_DK>(p, st)) { m4d_set_error("attention_bwd: cannot configure the dk kernel"); return -3; }
+        M4D_CHECK_LAUNCH("attention_bwd(dk128)");
+        // dV: X = (K), Y = (Q, dO^T)
+        p.yat = a->dot; p.yat_bs = a->dot_bs; p.yat_ls = a->dot_ls;
+        p.out_a = a->dv; p.oa_bs = a->dv_bs; p.oa_ls = a->dv_ls;
+        if (launch_bwd128<BWD_DV>(p, st)) { m4d_set_error("attention_bwd: cannot configure the dv kernel"); return -3; }
+        M4D_CHECK_LAUNCH("attention_bwd(dv128)");
+        return 0;
+    }
     // ---- pass Q: X = queries ----
     p.xa = a->q; p.xa_bs = a->q_bs; p.xa_ls = a->q_ls;
     p.xb = a->d_o; p.xb_bs = a->do_bs; p.xb_ls = a->do_ls;
