@@ -225,6 +225,8 @@ typedef struct {
     int64_t Lq, Lk, Lk_rows;
     int32_t B, heads, head_dim, accumulate_dq, accumulate_dkv;
     float scale;
+    float* ws;          /* optional float workspace of ws_elems >= B*Lk_rows*heads*head_dim elements: lets the dk / dv */
+    int64_t ws_elems;   /* passes split a long query loop over more workgroups when there are few keys (cross-attention) */
 } m4d_attn_bwd_args;
 int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* args, m4d_stream stream);
 

@@ -25,7 +25,7 @@ class AttnBwdArgs(Structure):
                                         "qt_bs", "qt_ls", "kt_bs", "kt_ls", "dot_bs", "dot_ls",
                                         "dq_bs", "dq_ls", "dk_bs", "dk_ls", "dv_bs", "dv_ls", "Lq", "Lk", "Lk_rows")] +
                 [(n, c_int32) for n in ("B", "heads", "head_dim", "accumulate_dq", "accumulate_dkv")] +
-                [("scale", c_float)])
+                [("scale", c_float), ("ws", c_void_p), ("ws_elems", c_int64)])
 
 
 # name -> (restype, argtypes); mirrors include/more4d_hip.h one to one

@@ -29,6 +29,10 @@ struct BwdArgs {
     int64_t LX, LXs, LY, Lq;      // X rows valid / stored, Y rows valid, query count (lse/delta row length)
     int B, heads, nx_tiles, accumulate;
     float sc, scale;
+    // production kernels only: blockIdx.y walks Y chunks of y_chunk rows and adds into the float workspace `ws`
+    // ([B, LXs, heads*D]) instead of storing (short X sides, e.g. 512 text keys against 21 840 queries)
+    float* ws;
+    int64_t y_chunk;
 };
 
 template <typename T, int D, bool KV>
@@ -240,6 +244,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(BwdArgs p) {
 
 #include "attention_bwd128.h"
 
+// float workspace [B, rows, C] -> T output rows (b, l) at out + b*bs + l*ls (+= when accumulate)
+struct WsArgs { const float* ws; void* out; int64_t bs, ls, rows; int C, B, accumulate; };
+__global__ __launch_bounds__(256) void ws_store_kernel(WsArgs p) {
+    const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nv = p.C >> 2, total = (int64_t)p.B * p.rows * nv;
+    if (i4 >= total) return;
+    const int64_t c = (i4 % nv) * 4, l = (i4 / nv) % p.rows, b = i4 / nv / p.rows;
+    f32x4 v = load4(p.ws + i4 * 4);
+    bf16_t* dst = (bf16_t*)p.out + b * p.bs + l * p.ls + c;
+    if (p.accumulate) v += load4(dst);
+    store4(dst, v);
+}
+
 // delta[b, h, l] = sum_d dO[b, l, h, d] * O[b, l, h, d];  16 lanes x 8 elements per (row, head) for D = 128
 struct DeltaArgs {
     const void *o, *d_o; float* delta;
@@ -248,19 +265,25 @@ struct DeltaArgs {
 };
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(DeltaArgs p) {
-    const int64_t total = (int64_t)p.B * p.heads * p.Lq;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int64_t l = idx % p.Lq;
-    const int h = (int)((idx / p.Lq) % p.heads), b = (int)(idx / p.Lq / p.heads);
-    const T* po = (const T*)p.o + b * p.o_bs + l * p.o_ls + (int64_t)h * p.D;
-    const T* pd = (const T*)p.d_o + b * p.do_bs + l * p.do_ls + (int64_t)h * p.D;
+    // D/8 lanes x 8 elements per (row, head): a wave reads 64 x 16 B contiguous bytes of each operand
+    const int lpr = p.D >> 3;                                   // lanes per (row, head): 4, 8 or 16
+    const int64_t total = (int64_t)p.B * p.Lq * p.heads;        // ordered (b, l, h): h fastest => contiguous memory
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = gid / lpr;
+    const int sub = (int)(gid % lpr);
     float s = 0.f;
-    for (int d = 0; d < p.D; d += 4) {
-        const f32x4 a = load4(po + d), c = load4(pd + d);
-        s += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+    int h = 0; int64_t l = 0, b = 0;
+    if (item < total) {
+        h = (int)(item % p.heads);
+        l = (item / p.heads) % p.Lq;
+        b = item / p.heads / p.Lq;
+        const T* po = (const T*)p.o + b * p.o_bs + l * p.o_ls + (int64_t)h * p.D + sub * 8;
+        const T* pd = (const T*)p.d_o + b * p.do_bs + l * p.do_ls + (int64_t)h * p.D + sub * 8;
+        const f32x4 a0 = load4(po), a1 = load4(po + 4), c0 = load4(pd), c1 = load4(pd + 4);
+        s = a0[0] * c0[0] + a0[1] * c0[1] + a0[2] * c0[2] + a0[3] * c0[3] + a1[0] * c1[0] + a1[1] * c1[1] + a1[2] * c1[2] + a1[3] * c1[3];
     }
-    p.delta[idx] = s;
+    for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (item < total && sub == 0) p.delta[(b * p.heads + h) * p.Lq + l] = s;
 }
 
 template <typename T, int D, bool KV>
@@ -313,13 +336,14 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         d.o = a->o; d.d_o = a->d_o; d.delta = a->delta;
         d.o_bs = a->o_bs; d.o_ls = a->o_ls; d.do_bs = a->do_bs; d.do_ls = a->do_ls; d.Lq = a->Lq;
         d.B = a->B; d.heads = a->heads; d.D = a->head_dim;
-        const int64_t total = (int64_t)a->B * a->heads * a->Lq;
+        const int64_t total = (int64_t)a->B * a->heads * a->Lq * (a->head_dim / 8);
         dim3 grid((unsigned)((total + 255) / 256)), block(256);
         if (bf) hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, grid, block, 0, st, d);
         else hipLaunchKernelGGL(attn_delta_kernel<float>, grid, block, 0, st, d);
         M4D_CHECK_LAUNCH("attention_bwd(delta)");
     }
     BwdArgs p;
+    p.ws = nullptr; p.y_chunk = 0;
     p.lse = a->lse; p.delta = a->delta; p.Lq = a->Lq;
     p.B = a->B; p.heads = a->heads; p.scale = a->scale; p.sc = a->scale * 1.4426950408889634f;
     if (bf && a->head_dim == 128 && !getenv("M4D_ATTN_BWD_GENERIC")) {
@@ -331,7 +355,7 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         p.yat = a->kt; p.yat_bs = a->kt_bs; p.yat_ls = a->kt_ls;
         p.out_a = a->dq; p.oa_bs = a->dq_bs; p.oa_ls = a->dq_ls;
         p.LX = p.LXs = a->Lq; p.LY = a->Lk; p.nx_tiles = (int)((a->Lq + 255) / 256); p.accumulate = a->accumulate_dq;
-        if (launch_bwd128<BWD_DQ>(p, st)) { m4d_set_error("attention_bwd: cannot configure the dq kernel"); return -3; }
+        if (launch_bwd128<BWD_DQ>(p, st, 1)) { m4d_set_error("attention_bwd: cannot configure the dq kernel"); return -3; }
         M4D_CHECK_LAUNCH("attention_bwd(dq128)");
         // dK: X = (K, V), Y = (Q, dO, Q^T)
         p.xa = a->k; p.xa_bs = a->k_bs; p.xa_ls = a->k_ls; p.xb = a->v; p.xb_bs = a->v_bs; p.xb_ls = a->v_ls;
@@ -339,13 +363,35 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         p.yat = a->qt; p.yat_bs = a->qt_bs; p.yat_ls = a->qt_ls;
         p.out_a = a->dk; p.oa_bs = a->dk_bs; p.oa_ls = a->dk_ls;
         p.LX = a->Lk; p.LXs = a->Lk_rows; p.LY = a->Lq; p.nx_tiles = (int)((a->Lk_rows + 255) / 256); p.accumulate = a->accumulate_dkv;
-        if (launch_bwd128<BWD_DK>(p, st)) { m4d_set_error("attention_bwd: cannot configure the dk kernel"); return -3; }
-        M4D_CHECK_LAUNCH("attention_bwd(dk128)");
-        // dV: X = (K), Y = (Q, dO^T)
-        p.yat = a->dot; p.yat_bs = a->dot_bs; p.yat_ls = a->dot_ls;
-        p.out_a = a->dv; p.oa_bs = a->dv_bs; p.oa_ls = a->dv_ls;
-        if (launch_bwd128<BWD_DV>(p, st)) { m4d_set_error("attention_bwd: cannot configure the dv kernel"); return -3; }
-        M4D_CHECK_LAUNCH("attention_bwd(dv128)");
+        // few key tiles against many queries (cross-attention): split the query loop over blockIdx.y
+        const int64_t blocks = (int64_t)p.nx_tiles * a->heads * a->B, ytiles = (a->Lq + 63) / 64;
+        const int64_t ws_need = (int64_t)a->B * a->Lk_rows * a->heads * 128;
+        int nsplit = 1;
+        if (a->ws && a->ws_elems >= ws_need && blocks < 192 && ytiles >= 32) {
+            nsplit = (int)((512 + blocks - 1) / blocks);
+            if (nsplit > ytiles / 8) nsplit = (int)(ytiles / 8);
+            if (nsplit > 16) nsplit = 16;
+        }
+        const int64_t chunk = nsplit > 1 ? ((ytiles + nsplit - 1) / nsplit) * 64 : 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {   // dV: X = (K), Y = (Q, dO^T)
+                p.yat = a->dot; p.yat_bs = a->dot_bs; p.yat_ls = a->dot_ls;
+                p.out_a = a->dv; p.oa_bs = a->dv_bs; p.oa_ls = a->dv_ls;
+            }
+            if (nsplit > 1) {
+                if (hipMemsetAsync(a->ws, 0, ws_need * sizeof(float), st) != hipSuccess) { m4d_set_error("attention_bwd: memset failed"); return -3; }
+                p.ws = a->ws; p.y_chunk = chunk;
+            }
+            const int rc2 = pass == 0 ? launch_bwd128<BWD_DK>(p, st, nsplit) : launch_bwd128<BWD_DV>(p, st, nsplit);
+            if (rc2) { m4d_set_error("attention_bwd: cannot configure the dk/dv kernel"); return -3; }
+            M4D_CHECK_LAUNCH("attention_bwd(dkv128)");
+            if (nsplit > 1) {
+                WsArgs w{a->ws, p.out_a, p.oa_bs, p.oa_ls, a->Lk_rows, a->heads * 128, a->B, p.accumulate};
+                const int64_t n4 = ws_need / 4;
+                hipLaunchKernelGGL(ws_store_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w);
+                M4D_CHECK_LAUNCH("attention_bwd(ws_store)");
+            }
+        }
         return 0;
     }
     // ---- pass Q: X = queries ----

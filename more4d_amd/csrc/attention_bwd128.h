@@ -151,11 +151,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
         return t < 64 ? glse[y] : gdel[y];
     };
 
-    bool cur_dma = YB <= p.LY;
-    if (cur_dma) dma_tile(0, 0);
-    float rstat = load_stat(0);
+    const int64_t y_begin = p.ws ? (int64_t)blockIdx.y * p.y_chunk : 0;
+    const int64_t y_end = p.ws ? (y_begin + p.y_chunk < p.LY ? y_begin + p.y_chunk : p.LY) : p.LY;
+    bool cur_dma = y_begin + YB <= p.LY;
+    if (cur_dma && y_begin < y_end) dma_tile(0, y_begin);
+    float rstat = load_stat(y_begin);
     int it = 0;
-    for (int64_t y0 = 0; y0 < p.LY; y0 += YB, ++it) {
+    for (int64_t y0 = y_begin; y0 < y_end; y0 += YB, ++it) {
         const int stage = it & 1;
         if (STAT_Y && t < 128) reinterpret_cast<float*>(smem + stage * STAGE + STAT_OFF)[t] = rstat;
         if (cur_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
         __syncthreads();
         const int64_t ny0 = y0 + YB;
         bool next_dma = false;
-        if (ny0 < p.LY) {
+        if (ny0 < y_end) {
             next_dma = ny0 + YB <= p.LY;
             if (next_dma) dma_tile(stage ^ 1, ny0);
             rstat = load_stat(ny0);
@@ -274,7 +276,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
         for (int c = 0; c < 4; ++c) va[c] += dl;
     }
 
-    if (xrow < p.LXs) {
+    if (p.ws) {
+        if (xrow < p.LXs && xvalid) {
+            float* w = p.ws + ((int64_t)b * p.LXs + xrow) * ((int64_t)p.heads * D) + (int64_t)h * D + hi * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(w + d * 32 + rq * 8 + e, acc[d][rq * 4 + e]);
+        }
+    } else if (xrow < p.LXs) {
         T* oa = (T*)p.out_a + b * p.oa_bs + xrow * p.oa_ls + (int64_t)h * D + hi * 4;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
 }
 
 template <int MODE>
-int launch_bwd128(const BwdArgs& p, hipStream_t st) {
+int launch_bwd128(const BwdArgs& p, hipStream_t st, int nsplit) {
     constexpr int STAGE = (MODE == BWD_DV ? 32768 : 49152) + (MODE == BWD_DQ ? 0 : 512);
     static bool configured = false;
     if (!configured) {
@@ -303,7 +315,7 @@ int launch_bwd128(const BwdArgs& p, hipStream_t st) {
             return -3;
         configured = true;
     }
-    dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B)), block(512);
+    dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B), (unsigned)nsplit), block(512);
     hipLaunchKernelGGL((attn_bwd128_kernel<MODE>), grid, block, 2 * STAGE, st, p);
     return 0;
 }

@@ -589,6 +589,10 @@ def attention_bwd(q, k, v, o, d_o, lse, *, B, Lq, Lk, Lk_rows, heads, head_dim, 
     a.B, a.heads, a.head_dim = B, heads, head_dim
     a.accumulate_dq, a.accumulate_dkv = int(accumulate_dq), int(accumulate_dkv)
     a.scale = scale if scale is not None else 1.0 / math.sqrt(head_dim)
+    ws = None
+    if Lk_rows * 8 <= Lq:     # few keys against many queries: let the dk/dv passes split the query loop
+        ws = torch.empty(B * Lk_rows * C, device=q.device, dtype=torch.float32)
+        a.ws, a.ws_elems = ws.data_ptr(), ws.numel()
     check(_lib.load().m4d_attention_bwd(dt_code(q.dtype), a, _stream()), "m4d_attention_bwd")
 
 

@@ -142,7 +142,7 @@ def test_rmsnorm_rope_bwd(dtype, C, hd):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("hd,heads,Lq,Lk,Lk_rows", [(32, 4, 200, 200, 200), (64, 2, 136, 77, 80), (128, 2, 304, 257, 264),
-                                                     (128, 3, 64, 1000, 1000)])
+                                                     (128, 3, 64, 1000, 1000), (128, 2, 2304, 257, 264)])
 def test_attention_lse_and_bwd(dtype, hd, heads, Lq, Lk, Lk_rows):
     from more4d_amd import ops
     from more4d_amd.ops import KV

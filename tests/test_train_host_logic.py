@@ -112,3 +112,31 @@ def test_data_parallel_training_step_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert err < 1e-3 and total > 0 and moved > 0 and diverge == 0.0
+
+
+def test_train_step_host_logic(monkeypatch):
+    """train_step(): noising, thresholded loss, adaptive clip threshold, fused-clip AdamW wiring (torch stand-ins)."""
+    from more4d_amd import training
+    from more4d_amd.models import WanTransformer4DModel
+    from more4d_amd.optim import AdamW
+    cpu_ops.install(monkeypatch)
+    assert training.linear_decay(5.0, 1.0, 100, 50) == 3.0 and training.linear_decay(5.0, 1.0, 100, 200) == 1.0
+    assert training.adaptive_max_grad_norm(1.0, 0.05, 5.0, 1000, 0) == 0.25                 # warm-up: 5 x 0.05
+    assert abs(training.adaptive_max_grad_norm(1.0, 0.05, 5.0, 1000, 2000) - 0.05 / 10) < 1e-12   # 20x over -> /10
+    pred, tgt = torch.tensor([0.0, 100.0, 1.0]), torch.tensor([0.0, 0.0, 0.0])
+    assert abs(float(training.custom_mse_loss(pred, tgt)) - 1.0 / 3) < 1e-7                 # the 100-error is masked
+    z = load_npz("dit_tiny.npz")
+    m = WanTransformer4DModel(**TINY)
+    m.load_state_dict(fill(load_keys("dit_tiny_keys.json"), 1234))
+    m.train()
+    opt = AdamW(m.parameters(), lr=1e-3, weight_decay=3e-2, eps=1e-10)
+    g = torch.Generator().manual_seed(3)
+    lat, noise = torch.randn(2, 16, 2, 16, 16, generator=g), torch.randn(2, 16, 2, 16, 16, generator=g)
+    sig = torch.tensor([0.7, 0.2])
+    kw = dict(context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"], y=z["y"],
+              full_ref=z["full_ref"])
+    losses = [float(training.train_step(m, opt, latents=lat, noise=noise, sigmas=sig, timesteps=sig * 1000,
+                                        forward_kwargs=kw, global_step=i)[0]) for i in range(3)]
+    assert losses[2] < losses[0]
+    noisy, target = training.add_noise(lat, noise, sig)
+    assert torch.allclose(noisy[0], 0.3 * lat[0] + 0.7 * noise[0]) and torch.equal(target, noise - lat)
