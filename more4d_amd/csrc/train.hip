@@ -160,9 +160,41 @@ struct LnBwdArgs {
     int C, B; float eps;
 };
 
+// column partials of the 4 waves of a workgroup are summed in LDS (wave after wave), then ONE wave issues the global
+// atomics: 4x fewer atomics than per-wave flushing (they dominated the first version of these kernels)
+template <int MAXV>
+M4D_DEV void flush_partials(const f32x4 (&part)[MAXV], float* lds, float* out, int nv, int lt, int wv) {
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c4 = lt + i * 64;
+                if (c4 < nv) {
+                    f32x4* q = reinterpret_cast<f32x4*>(lds) + c4;
+                    *q = w == 0 ? part[i] : *q + part[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = lt + i * 64;
+            if (c4 < nv) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(lds)[c4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(out + c4 * 4 + e, v[e]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
 template <typename TD, int MAXV>
 __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
     constexpr int G = 64;
+    extern __shared__ __attribute__((aligned(16))) float red_lds[];   // C floats
     const int lt = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sample = blockIdx.y;
     const int C = p.C, nv = C >> 2;
@@ -174,7 +206,8 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
         const int64_t row = (int64_t)sample * p.rows_per_sample + l;
         const float* xr = p.x + row * C;
         const TD* dr = (const TD*)p.dy + row * C;
-        f32x4 v[MAXV], g[MAXV];
+        float* dxr = p.dx + row * C;
+        f32x4 v[MAXV], g[MAXV], dxo[MAXV];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -182,6 +215,7 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
             if (c4 < nv) {
                 v[i] = load4(xr + c4 * 4);
                 g[i] = load4(dr + c4 * 4);
+                dxo[i] = load4(dxr + c4 * 4);     // issued with the other loads: one memory round trip per row
                 s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
             }
         }
@@ -214,30 +248,15 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
         }
         m1 = wave_sum(m1) / C;
         m2 = wave_sum(m2) / C;
-        float* dxr = p.dx + row * C;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) {
-                f32x4 d = (g[i] - m1 - v[i] * m2) * rstd;
-                store4(dxr + c4 * 4, load4(dxr + c4 * 4) + d);
-            }
+            if (c4 < nv) store4(dxr + c4 * 4, dxo[i] + (g[i] - m1 - v[i] * m2) * rstd);
         }
     }
     if (p.dshift) {
-        float* o1 = p.dshift + (int64_t)sample * p.red_stride;
-        float* o2 = p.dscale + (int64_t)sample * p.red_stride;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lt + i * G;
-            if (c4 < nv) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    atomicAdd(o1 + c4 * 4 + e, ps[i][e]);
-                    atomicAdd(o2 + c4 * 4 + e, pq[i][e]);
-                }
-            }
-        }
+        flush_partials<MAXV>(ps, red_lds, p.dshift + (int64_t)sample * p.red_stride, nv, lt, wv);
+        flush_partials<MAXV>(pq, red_lds, p.dscale + (int64_t)sample * p.red_stride, nv, lt, wv);
     }
 }
 
@@ -253,6 +272,7 @@ struct RmsBwdArgs {
 
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float red_lds[];   // C floats
     const int lt = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int which = blockIdx.y;
     const int C = p.C, nv = C >> 2;
@@ -311,15 +331,7 @@ __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
             if (c4 < nv) store4(dr + c4 * 4, (g[i] - v[i] * m2) * inv);
         }
     }
-    float* o = p.dw[which];
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c4 = lt + i * 64;
-        if (c4 < nv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(o + c4 * 4 + e, pw[i][e]);
-        }
-    }
+    flush_partials<MAXV>(pw, red_lds, p.dw[which], nv, lt, wv);
 }
 
 // ------------------------------------------------------------------ sum of squares (global gradient norm)
@@ -465,11 +477,12 @@ extern "C" int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* 
     M4D_CHECK_ARG((dshift == nullptr) == (dscale == nullptr), "ln_modulate_bwd: dshift and dscale come together");
     LnBwdArgs p{x, dy, dx, scale, ln_w, dshift, dscale, rows_per_sample, mod_stride, red_stride, C, B, eps};
     int64_t nb = (rows_per_sample + 3) / 4;
-    const int64_t cap = (1024 + B - 1) / B;     // ~4 waves per SIMD chip-wide; more only adds atomics
+    const int64_t cap = (512 + B - 1) / B;      // two workgroups per CU chip-wide; more only adds atomics
     if (nb > cap) nb = cap;
     dim3 grid((unsigned)nb, (unsigned)B), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define LNB(TD, MV) hipLaunchKernelGGL((ln_bwd_kernel<TD, MV>), grid, block, 0, st, p)
+    const size_t lds = (size_t)C * sizeof(float);
+#define LNB(TD, MV) hipLaunchKernelGGL((ln_bwd_kernel<TD, MV>), grid, block, lds, st, p)
     const bool bf = dy_dt == M4D_BF16;
     if (C <= 2048) { if (bf) LNB(bf16_t, 8); else LNB(float, 8); }
     else if (C <= 5120) { if (bf) LNB(bf16_t, 20); else LNB(float, 20); }
@@ -494,10 +507,11 @@ extern "C" int m4d_rmsnorm_rope_bwd(m4d_dtype dt, void* dy0, void* dy1, int64_t 
     p.ld_dy = ld_dy; p.ld_x = ld_x; p.rows = rows; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows;
     p.rope_len = rope_len; p.pos_offset = pos_offset; p.C = C; p.head_dim = head_dim > 0 ? head_dim : 4; p.eps = eps;
     int64_t nb = (rows + 3) / 4;
-    if (nb > 512) nb = 512;
+    if (nb > 256) nb = 256;
     dim3 grid((unsigned)nb, dy1 ? 2u : 1u), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define RMB(T, MV) hipLaunchKernelGGL((rms_bwd_kernel<T, MV>), grid, block, 0, st, p)
+    const size_t lds = (size_t)C * sizeof(float);
+#define RMB(T, MV) hipLaunchKernelGGL((rms_bwd_kernel<T, MV>), grid, block, lds, st, p)
     const bool bf = dt == M4D_BF16;
     if (C <= 2048) { if (bf) RMB(bf16_t, 8); else RMB(float, 8); }
     else if (C <= 5120) { if (bf) RMB(bf16_t, 20); else RMB(float, 20); }
