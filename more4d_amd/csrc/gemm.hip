@@ -253,6 +253,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256_kernel(GemmArgs p) {
     }
 }
 
+#include "gemm_phased.h"
+
 // ============================================================================ 256x256, staggered operand rings
 // Same tile / waves / MFMA loop as gemm_bt256_kernel, but the two operands use SEPARATE LDS rings of different depth:
 // A (activations) 3 slots, W 2 slots = 5 x 32 KiB = all 160 KiB of the CU's LDS.  Per iteration a wave issues the DMA of
@@ -475,21 +477,24 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
     // production kernel: big bf16 problems with K a multiple of the 64-wide K-tile
     const bool big = dt == M4D_BF16 && K % 64 == 0 && M >= 512 && N >= 512;
     if (big) {
-        static int variant = -1;   // M4D_GEMM_VARIANT=2 selects the ping-pong kernel (A/B measurements); default: 2-stage kernel
+        static int variant = -1;   // default 4: phased two-group kernel (gemm_phased.h); 1 two-stage, 2 ping-pong, 3 staggered rings (A/B)
         if (variant < 0) {
             const char* v = getenv("M4D_GEMM_VARIANT");
-            variant = v ? atoi(v) : 1;
+            variant = v ? atoi(v) : 4;
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)gemm_bt256pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)gemm_bt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * SLOT3);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)gemm_bt256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_BUF);
             if (e != hipSuccess) { variant = -1; m4d_set_error("gemm_bt: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -3; }
         }
         p.tiles_m = (int)((M + BM2 - 1) / BM2); p.tiles_n = (int)((N + BN2 - 1) / BN2);
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
         M4D_CHECK_ARG(nwg < (1ll << 31), "gemm_bt: too many tiles");
-        if (variant == 3) hipLaunchKernelGGL(gemm_bt256s_kernel, dim3((unsigned)nwg), dim3(512), 5 * SLOT3, st, p);
+        if (variant == 4) hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)nwg), dim3(512), 2 * P_BUF, st, p);
+        else if (variant == 3) hipLaunchKernelGGL(gemm_bt256s_kernel, dim3((unsigned)nwg), dim3(512), 5 * SLOT3, st, p);
         else if (variant == 1) hipLaunchKernelGGL(gemm_bt256_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE2_BYTES, st, p);
         else hipLaunchKernelGGL(gemm_bt256pp_kernel, dim3((unsigned)nwg), dim3(512), 4 * SLOT_BYTES, st, p);
     } else {
