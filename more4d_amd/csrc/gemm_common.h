@@ -23,9 +23,8 @@ constexpr int ROWB = 128;  // bytes of K per LDS row
 M4D_DEV int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // XCD-aware, banded tile order -> (tm, tn)
-M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn) {
+M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn, int bid) {
     const int nwg = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     constexpr int GM = 8;
@@ -37,6 +36,7 @@ M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn) {
     if (p.abl & 16) { tm = 0; tn = 0; }          // ablation: every workgroup reads the same panels (all L2 hits)
     if (p.abl & 32) { tm = blockIdx.x % p.tiles_m; tn = blockIdx.x / p.tiles_m; }   // ablation: naive order
 }
+M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn) { tile_coords(p, tm, tn, (int)blockIdx.x); }
 
 // Epilogue for one 32(n) x 32(m) accumulator tile: this lane holds column m, rows nb0 + 8*rq + 4*hi + [0,4).
 // bf16 outputs are widened to 16-byte stores: a v_permlane32_swap per dword exchanges the 4-column groups of the two
@@ -44,7 +44,7 @@ M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn) {
 // the store tail is issue-bound, half the instructions = half the tail).
 template <typename T>
 M4D_DEV void epilogue_tile(const GemmArgs& p, const f32x16& acc, int64_t m, int64_t nb0, int hi, float bias_m,
-                           const float* grow) {
+                           const float* grow, int64_t n_lo = 0) {   // columns below n_lo belong to the neighbouring tile
     const T* bias = (const T*)p.bias;
     f32x4 v[4];
 #pragma unroll
@@ -76,7 +76,7 @@ M4D_DEV void epilogue_tile(const GemmArgs& p, const f32x16& acc, int64_t m, int6
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const int64_t nb = nb0 + rq * 8 + hi * 4;
-            if (nb >= p.N) continue;
+            if (nb >= p.N || nb < n_lo) continue;
             float* r = (float*)p.out + m * p.ldc + nb;
             f32x4 x = load4(r);
             f32x4 g = {1.f, 1.f, 1.f, 1.f};

@@ -19,6 +19,93 @@
 // the redundant stagings land in slots that are never read again, which keeps the wait counts uniform.
 #pragma once
 
+// wave-uniform 64-bit value forced into SGPRs (keeps the DMA in its  vgpr_offset + sgpr_base  addressing form)
+M4D_DEV const char* uniform_ptr(const char* q) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
+// Epilogue of one 64(m) x 64(n) half of a wave's sub-tile THROUGH LDS.  The accumulator layout gives every lane its own
+// output ROW (lane = m), so direct stores touch 64 different rows per instruction (16-byte pieces of 64 cache lines:
+// measured 1.4 TB/s, 16 % of a K = 5120 GEMM).  Here the half-tile is written to a wave-private LDS region with bias /
+// activation / gate applied, then read back row-wise so that 8 (bf16) or 16 (fp32) consecutive lanes cover one
+// contiguous 128 / 256-byte row segment of the output.  16-byte chunks are XOR-swizzled by the row index.
+template <typename T>
+M4D_DEV void epilogue_half_lds(const GemmArgs& p, char* wl, const f32x16& a00, const f32x16& a01, const f32x16& a10,
+                               const f32x16& a11, int64_t m_base, int64_t n_base, int64_t m_lo, int64_t n_lo, int lane) {
+    // a[ni][mi2]: a00 = (ni 0, mi2 0), a01 = (ni 0, mi2 1), a10 = (ni 1, mi2 0), a11 = (ni 1, mi2 1)
+    const int li = lane & 31, hi = lane >> 5;
+    const T* bias = (const T*)p.bias;
+    const bool f32out = p.epilogue == M4D_EPI_RESID_GATE || p.epilogue == M4D_EPI_STORE_F32;
+#pragma unroll
+    for (int mi2 = 0; mi2 < 2; ++mi2) {
+        const int r = mi2 * 32 + li;
+        const int64_t m = m_base + r;
+        const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;
+        const float* grow = (p.epilogue == M4D_EPI_RESID_GATE && p.gate) ? p.gate + (m / p.rows_per_sample) * p.gate_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const f32x16& acc = ni == 0 ? (mi2 == 0 ? a00 : a01) : (mi2 == 0 ? a10 : a11);
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int nl = ni * 32 + rq * 8 + hi * 4;
+                const int64_t nb = n_base + nl;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[rq * 4 + e];
+                if (bias) { if (p.bias_on_m) v += bm; else v += load4(bias + nb); }
+                if (p.epilogue == M4D_EPI_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (p.epilogue == M4D_EPI_GELU_ERF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if (p.epilogue == M4D_EPI_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (f32out) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
+                    if (grow) v = v * load4(grow + nb);
+                    const int ch = nl >> 2;                                   // 16 chunks of 4 floats per 256-byte row
+                    *reinterpret_cast<f32x4*>(wl + r * 256 + ((ch ^ (r & 15)) << 4)) = v;
+                } else {
+                    const int ch = nl >> 3;                                   // 8 chunks of 8 bf16 per 128-byte row
+                    store4(reinterpret_cast<T*>(wl + r * 128 + ((ch ^ (r & 7)) << 4) + (nl & 4) * 2), v);
+                }
+            }
+        }
+    }
+    // wave-private region: program order + the compiler's lgkmcnt wait order the reads after the writes
+    if (f32out) {
+        const int ch = lane & 15;
+        const int64_t nb = n_base + ch * 4;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + (lane >> 4);
+            const int64_t m = m_base + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((ch ^ (r & 15)) << 4));
+            if (m < m_lo || nb < n_lo) continue;
+            float* dst = (float*)p.out + m * p.ldc + nb;
+            if (p.epilogue == M4D_EPI_RESID_GATE) v += load4(dst);
+            store4(dst, v);
+        }
+    } else {
+        const int ch = lane & 7;
+        const int64_t nb = n_base + ch * 8;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 8 + (lane >> 3);
+            const int64_t m = m_base + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(wl + r * 128 + ((ch ^ (r & 7)) << 4));
+            if (m < m_lo || nb + 8 <= n_lo) continue;      // a chunk straddling n_lo rewrites identical values (benign)
+            *reinterpret_cast<uint4*>((T*)p.out + m * p.ldc + nb) = v;
+        }
+    }
+}
+
 constexpr int P_UNIT = 16384;
 constexpr int P_U0 = 0, P_V0 = P_UNIT, P_V1 = 2 * P_UNIT, P_U1 = 3 * P_UNIT, P_BUF = 4 * P_UNIT;   // 64 KiB per K-tile
 
@@ -26,7 +113,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
     typedef bf16_t T;
     int tm, tn;
     tile_coords(p, tm, tn);
-    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+    // edge tiles are shifted inwards (origin clamped to M-256 / N-256) so that every DMA row is in bounds and the
+    // per-lane source offset is the same for all tiles; rows / columns below (m_lo, n_lo) are left to the neighbour
+    const int64_t m_lo = (int64_t)tm * BM2, n_lo = (int64_t)tn * BN2;
+    const int64_t m0 = min(m_lo, p.M - BM2), n0 = min(n_lo, p.N - BN2);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
@@ -34,40 +124,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
     // ---- DMA sources: unit row u = (i*8 + wave)*8 + lrow, i = 0..1; lane -> (lrow, physical chunk).  Per-lane 32-bit
     // byte offsets from the (wave-uniform) tile origin keep the eight source addresses in 8 VGPRs + 2 SGPR pairs ----
     const int lrow = lane >> 3, pc = lane & 7;
-    unsigned ou0[2], ou1[2], ov0[2], ov1[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = (i * 8 + wave) * 8 + lrow;
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)dyn_smem;
+    // per-lane source offsets (bytes): unit row u = wave*8 + lrow of instruction 0; instruction 1 and the second unit
+    // of each operand differ by whole rows, which go into the (scalar) base address
+    unsigned oa, ow;
+    {
+        const int u = wave * 8 + lrow;
         const int lc = pc ^ ((u >> 1) & 7);
-        const int64_t ma = (u >> 6) * 128 + (u & 63), na = (u >> 5) * 64 + (u & 31);
-        const int64_t mlast = p.M - 1 - m0, nlast = p.N - 1 - n0;      // clamp: rows past the edge are computed, never stored
-        ou0[i] = (unsigned)((min(ma, mlast) * p.lda + lc * 8) * 2);
-        ou1[i] = (unsigned)((min(ma + 64, mlast) * p.lda + lc * 8) * 2);
-        ov0[i] = (unsigned)((min(na, nlast) * p.ldw + lc * 8) * 2);
-        ov1[i] = (unsigned)((min(na + 32, nlast) * p.ldw + lc * 8) * 2);
+        oa = (unsigned)((((u >> 6) * 128 + (u & 63)) * p.lda + lc * 8) * 2);
+        ow = (unsigned)((((u >> 5) * 64 + (u & 31)) * p.ldw + lc * 8) * 2);
     }
-    const char* baseA = (const char*)p.A + m0 * p.lda * 2;
-    const char* baseW = (const char*)p.W + n0 * p.ldw * 2;
-    const int nk = (int)(p.K / 64);
-    auto stage = [&](const char* base, const unsigned (&o)[2], int slot_off, int kt) {
+    const char* baseA = uniform_ptr((const char*)p.A + m0 * p.lda * 2);
+    const char* baseW = uniform_ptr((const char*)p.W + n0 * p.ldw * 2);
+    const int nk = (p.abl & 128) ? 2 : (int)(p.K / 64);   // ablation 128: two K-tiles only (per-tile fixed cost)
+    // one unit = two DMA instructions per lane: rows r0 + (lane's row) and r1 + (lane's row) of the operand tile
+    auto stage = [&](const char* base, int64_t ld, unsigned voff, int r0, int r1, int slot_off, int kt) {
         const int kc = kt < nk ? kt : nk - 1;
-        const char* src = base + kc * 128;
-        char* dst = dyn_smem + (kt & 1) * P_BUF + slot_off;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + o[i]), (LDS_AS void*)(dst + (i * 8 + wave) * 1024), 16, 0, 0);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (kt & 1) * P_BUF + slot_off + wave * 1024);
+        const char* s0 = uniform_ptr(base + (r0 * ld + kc * 64) * 2);
+        const char* s1 = uniform_ptr(base + (r1 * ld + kc * 64) * 2);
+        // explicit  vgpr_offset + sgpr_base  form (the builtin falls back to 64-bit VGPR addresses here)
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(s0) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 8192), "v"(voff), "s"(s1) : "memory", "m0");
     };
+#define P_STAGE_U0(KT) stage(baseA, p.lda, oa, 0, 128, P_U0, KT)
+#define P_STAGE_U1(KT) stage(baseA, p.lda, oa, 64, 192, P_U1, KT)
+#define P_STAGE_V0(KT) stage(baseW, p.ldw, ow, 0, 128, P_V0, KT)
+#define P_STAGE_V1(KT) stage(baseW, p.ldw, ow, 32, 160, P_V1, KT)
 
     f32x16 acc[2][4];  // [ni][mi]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // per-lane fragment addresses inside the CURRENT K-tile buffer (toggled by +-P_BUF after every K-tile)
-    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)dyn_smem;
     unsigned am[4], an[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -77,8 +164,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
     }
 
     // ---- prologue: K-tile 0 complete, U0 / V0 of K-tile 1 in flight ----
-    stage(baseA, ou0, P_U0, 0); stage(baseW, ov0, P_V0, 0); stage(baseW, ov1, P_V1, 0); stage(baseA, ou1, P_U1, 0);
-    stage(baseA, ou0, P_U0, 1); stage(baseW, ov0, P_V0, 1);
+    P_STAGE_U0(0); P_STAGE_V0(0); P_STAGE_V1(0); P_STAGE_U1(0);
+    P_STAGE_U0(1); P_STAGE_V0(1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();      // group 1 runs half a phase behind group 0
@@ -118,15 +205,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
 #define P_KTILE(KT, F0, F1)                                                                                \
     do {                                                                                                   \
         P_READ_M(0, 4096);               /* U0 */                                                          \
-        stage(baseW, ov1, P_V1, (KT) + 1);                                                                 \
+        P_STAGE_V1((KT) + 1);                                                                       \
         P_VM(8);                                                                                           \
         P_SYNC_IN(); P_MFMA(F0, 0, 0); P_SYNC_OUT();                                                       \
         P_READ_N(F1, 32768);             /* V1 */                                                          \
-        stage(baseA, ou1, P_U1, (KT) + 1);                                                                 \
+        P_STAGE_U1((KT) + 1);                                                                       \
         P_VM(8);                                                                                           \
         P_SYNC_IN(); P_MFMA(F1, 1, 0); P_SYNC_OUT();                                                       \
         P_READ_M(49152, 53248);          /* U1 */                                                          \
-        stage(baseA, ou0, P_U0, (KT) + 2);                                                                 \
+        P_STAGE_U0((KT) + 2);                                                                       \
         P_VM(6);                                                                                           \
         P_SYNC_IN(); P_MFMA(F1, 1, 2); P_SYNC_OUT();                                                       \
         {                                                                                                  \
@@ -134,17 +221,44 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { am[kk] += dl; an[kk] += dl; }               \
         }                                                                                                  \
         P_READ_N(F1, 16384);             /* V0 of the next K-tile (other buffer) */                        \
-        stage(baseW, ov0, P_V0, (KT) + 2);                                                                 \
+        P_STAGE_V0((KT) + 2);                                                                       \
         P_SYNC_IN(); P_MFMA(F0, 0, 2); P_SYNC_OUT();                                                       \
     } while (0)
 
     P_READ_N(fna, 16384);                // V0 of K-tile 0
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        P_KTILE(kt, fna, fnb);
-        P_KTILE(kt + 1, fnb, fna);
+    const T* bias = (const T*)p.bias;
+#define P_ZERO_ACC()                                                                                       \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                      \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                  \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;                         \
+    } while (0)
+#define P_STORE_TILE(TM0, TN0, MLO, NLO)                                                                   \
+    do {                                                                                                   \
+        if (p.abl & 256) break;       /* ablation 256: no epilogue */                                        \
+        char* wl = dyn_smem + wave * 16384;                                                                \
+        if ((p.ldc & 7) == 0 || p.epilogue == M4D_EPI_RESID_GATE || p.epilogue == M4D_EPI_STORE_F32) {     \
+            epilogue_half_lds<T>(p, wl, acc[0][0], acc[0][1], acc[1][0], acc[1][1], (TM0) + wm * 128, (TN0) + wn * 64, (MLO), (NLO), lane); \
+            epilogue_half_lds<T>(p, wl, acc[0][2], acc[0][3], acc[1][2], acc[1][3], (TM0) + wm * 128 + 64, (TN0) + wn * 64, (MLO), (NLO), lane); \
+        } else {                                                                                           \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                             \
+                const int64_t m = (TM0) + wm * 128 + mi * 32 + li;                                         \
+                if (m < (MLO)) continue;                                                                   \
+                const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;                             \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
+                    epilogue_tile<T>(p, acc[ni][mi], m, (TN0) + wn * 64 + ni * 32, hi, bm, nullptr, (NLO)); \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+    P_ZERO_ACC();
+    {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            P_KTILE(kt, fna, fnb);
+            P_KTILE(kt + 1, fnb, fna);
+        }
+        if (kt < nk) P_KTILE(kt, fna, fnb);
     }
-    if (kt < nk) P_KTILE(kt, fna, fnb);
 #undef P_KTILE
 #undef P_MFMA
 #undef P_VM
@@ -154,16 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
 #undef P_READ_M
 #undef P_DSR
     if (wm == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count of the two groups
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail stagings must land before the LDS is released
-
-    const T* bias = (const T*)p.bias;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int64_t m = m0 + wm * 128 + mi * 32 + li;
-        if (m >= p.M) continue;
-        const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;
-        const float* grow = (p.epilogue == M4D_EPI_RESID_GATE && p.gate) ? p.gate + (m / p.rows_per_sample) * p.gate_stride : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) epilogue_tile<T>(p, acc[ni][mi], m, n0 + wn * 64 + ni * 32, hi, bm, grow);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail stagings must land before the LDS is re-used
+    __builtin_amdgcn_s_barrier();                      // ... by anyone: the epilogue transposes through the same LDS
+    P_STORE_TILE(m0, n0, m_lo, n_lo);
 }
