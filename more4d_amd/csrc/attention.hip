@@ -30,6 +30,7 @@ struct AttnArgs {
     int B, heads, nq_tiles, accumulate;
     float sc;  // softmax scale * log2(e)
     float* lse;  // optional [B, heads, Lq]: log2-domain log-sum-exp of the scaled scores (training)
+    int abl;     // timing ablations of attn128p_kernel (tools only, results wrong): 1 no softmax math, 2 no M-phase stream
 };
 
 template <typename T, int D>
@@ -489,6 +490,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
     }
 }
 
+#include "attention_phased.h"
+
 template <typename T>
 int launch(const AttnArgs& p, int D, hipStream_t st) {
     dim3 grid((unsigned)((int64_t)p.nq_tiles * p.heads * p.B)), block(256);
@@ -499,7 +502,16 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         // keep the 4-wave workgroups (measured: 1000 vs 924 TF at Lk = 21840, 657 vs 678 TF at Lk = 512)
         const bool w8 = p.Lq > 1024 && keys >= 2048 && !getenv("M4D_ATTN_W4");
         AttnArgs q = p;
-        if (w8) {
+        if (w8 && p.kv.nseg == 1 && !getenv("M4D_ATTN_LOCKSTEP")) {
+            // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
+            static bool configured = false;
+            if (!configured) {
+                if (hipFuncSetAttribute((const void*)attn128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
+                configured = true;
+            }
+            q.nq_tiles = (int)((p.Lq + 255) / 256);
+            hipLaunchKernelGGL(attn128p_kernel, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(512), 4 * 32768, st, q);
+        } else if (w8) {
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             hipLaunchKernelGGL(attn128_kernel<8>, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(512), 0, st, q);
         } else {
@@ -548,6 +560,7 @@ static int attention_impl(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_l
     p.B = B; p.heads = heads; p.nq_tiles = (int)((Lq + 127) / 128); p.accumulate = accumulate;
     p.sc = scale * 1.4426950408889634f;
     p.lse = lse;
+    { static int abl = -1; if (abl < 0) { const char* v = getenv("M4D_ATTN_ABL"); abl = v ? atoi(v) : 0; } p.abl = abl; }
     int rc = dt == M4D_BF16 ? launch<bf16_t>(p, head_dim, (hipStream_t)stream) : launch<float>(p, head_dim, (hipStream_t)stream);
     if (rc) { m4d_set_error("attention: unsupported configuration"); return rc; }
     M4D_CHECK_LAUNCH("attention");

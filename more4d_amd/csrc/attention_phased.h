@@ -1,0 +1,347 @@
+// attn128p_kernel: the production forward kernel (attention.hip: attn128_kernel<8>) re-scheduled so that the softmax
+// arithmetic of one wave group hides under the MFMAs of the other.
+//
+// Measured on attn128_kernel<8> (profiles/r01e): MFMA busy 46 % of SIMD cycles although the kernel does little else —
+// per 64-key tile a wave issues 32 MFMAs (1024 matrix-pipe cycles) and ~190 VALU instructions of which 32 are
+// quarter-rate v_exp_f32 (~1100 VALU cycles), and because all 8 waves pass the per-tile barrier together, the two
+// waves of a SIMD are in their MFMA phase at the same time and in their softmax phase at the same time: the pipes take
+// turns instead of overlapping.  Here every wave alternates
+//     V(i):  softmax of tile i (VALU only)                      | barrier
+//     M(i):  O^T += V^T(i) P^T(i)  and  S^T(i+1) = K(i+1) Q^T    | barrier      (32 MFMAs back to back, raised priority)
+// and the wave group {4..7} runs exactly one barrier behind {0..3}; each SIMD hosts one wave of each group, so its
+// matrix pipe always has an M phase to run while the other wave is in its V phase.
+//
+// K / V^T tiles go through FOUR 32 KiB LDS stages by global->LDS DMA: tile i+3 is requested at the start of M(i) into
+// the stage tile i-1 left (its last reader, PV(i-1) of the late group, finished before the barrier that opened this
+// phase) and is waited for at the end of M(i+1), one barrier before QK(i+3) may start in either group.
+// The ragged last tile of the key range is peeled off and processed FIRST in lock-step (softmax is order-free), so
+// the pipelined loop only sees full DMA tiles.  Single K/V segment only (the multi-segment T-sharded call keeps
+// attn128_kernel<8>).
+#pragma once
+
+// ---- M-phase instruction stream: steps 0..15 = PV (c = J/4 key group, d = J%4 head-dim block), steps 16..31 = QK of the
+// next tile (kk = (J-16)/2, sub = (J-16)%2).  A ring of 8 fragment registers, step J consumes ring[J % 8] and re-fills
+// it with the fragment of step J + 8: eight 1 KiB LDS reads are always in flight per wave.
+template <int OFF> M4D_DEV void dsr128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N> M4D_DEV void lgkm_le() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int J> M4D_DEV void m_read(bf16x8 (&ring)[8], const unsigned (&va)[4], const unsigned (&ka)[8]) {
+    if constexpr (J < 16) dsr128<(J & 3) * 4096>(ring[J & 7], va[J >> 2]);
+    else dsr128<((J - 16) & 1) * 8192>(ring[J & 7], ka[(J - 16) >> 1]);
+}
+template <int J, int LAST> M4D_DEV void m_steps(bf16x8 (&ring)[8], const unsigned (&va)[4], const unsigned (&ka)[8],
+                                                const bf16x8 (&pf)[4], const bf16x8 (&qf)[8], f32x16 (&o)[4], f32x16 (&s)[2]) {
+    if constexpr (J < LAST) {
+        lgkm_le<(J + 8 < LAST) ? 7 : LAST - 1 - J>();
+        if constexpr (J < 16) mma32(ring[J & 7], pf[J >> 2], o[J & 3]);
+        else if constexpr (J < 18) {   // first k-step of S: C = 0 (inline constant), no 32 v_mov to clear the accumulators
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            s[J - 16] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[J & 7], qf[0], zero, 0, 0, 0);
+        } else mma32(ring[J & 7], qf[(J - 16) >> 1], s[(J - 16) & 1]);
+        if constexpr (J + 8 < LAST) m_read<J + 8>(ring, va, ka);
+        m_steps<J + 1, LAST>(ring, va, ka, pf, qf, o, s);
+    }
+}
+template <int J, int END> M4D_DEV void m_prefetch(bf16x8 (&ring)[8], const unsigned (&va)[4], const unsigned (&ka)[8]) {
+    if constexpr (J < END) { m_read<J>(ring, va, ka); m_prefetch<J + 1, END>(ring, va, ka); }
+}
+
+__global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
+    typedef bf16_t T;
+    constexpr int D = 128, KVB = 64, STAGE = 32768, VOFF = 16384, QB = 256, NST = 4;
+    extern __shared__ __attribute__((aligned(16))) char psmem[];   // NST * STAGE
+
+    const int HB = p.heads * p.B;
+    int qt, hb;
+    if ((HB & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        hb = xcd * (HB >> 3) + idx / p.nq_tiles;
+        qt = idx % p.nq_tiles;
+    } else {
+        hb = blockIdx.x / p.nq_tiles;
+        qt = blockIdx.x % p.nq_tiles;
+    }
+    const int b = hb / p.heads, h = hb % p.heads;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, hi = lane >> 5;
+    const int grp = wave >> 2;
+    const int64_t qrow = (int64_t)qt * QB + wave * 32 + li;
+    const bool qvalid = qrow < p.Lq;
+
+    bf16x8 qf[8];
+    {
+        const T* qp = (const T*)p.q + b * p.q_bs + qrow * p.q_ls + (int64_t)h * D + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (qvalid) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[kk][j] = (T)0.f;
+            }
+        }
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // absolute per-lane fragment addresses: ka = K side of the tile whose S is computed next, va = V^T side of the tile
+    // whose P is applied next; both start in stage 0 and step one stage (mod 4) per tile
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_AS char*)psmem;
+    unsigned ka[8], va[4];
+    {
+        const int kr = perm23(li);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) ka[kk] = lds0 + kr * 256 + (((kk * 2 + hi) ^ (kr & 15)) << 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) va[c] = lds0 + VOFF + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
+    }
+    const int k_r = lane >> 4, k_lc0 = lane & 15;
+    const int v_r = lane >> 3, v_pc = lane & 7;
+
+    const int64_t len = p.kv.len[0];
+    const T* kbase = (const T*)p.kv.k[0] + b * p.kv.k_bs[0] + (int64_t)h * D;
+    const T* vbase = (const T*)p.kv.vt[0] + b * p.kv.vt_bs[0] + (int64_t)h * D * p.kv.vt_ls[0];
+    const int64_t kls = p.kv.k_ls[0], vls = p.kv.vt_ls[0];
+    const int NT = (int)(len / KVB);            // full tiles, pipelined
+    const int64_t tail0 = (int64_t)NT * KVB;    // first key of the ragged tail (if any)
+
+    // DMA sources as 32-bit per-lane byte offsets from a wave-uniform base (sgpr_base + vgpr_offset addressing)
+    unsigned offk[2], offv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int blk = wave * 2 + i;
+        const int krow = blk * 4 + k_r, vrow = blk * 8 + v_r;
+        offk[i] = (unsigned)((krow * kls + (k_lc0 ^ (krow & 15)) * 8) * 2);
+        offv[i] = (unsigned)((vrow * vls + (v_pc ^ ((vrow >> 1) & 7)) * 8) * 2);
+    }
+    auto uniform_ptr = [](const char* q) {
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const char*)(((unsigned long long)hi2 << 32) | lo);
+    };
+    auto dma_tile = [&](int stage, int64_t k0) {
+        const char* kp = uniform_ptr((const char*)(kbase + k0 * kls));
+        const char* vp = uniform_ptr((const char*)(vbase + k0));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + i * 1024), "v"(offk[i]), "s"(kp) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + VOFF + i * 1024), "v"(offv[i]), "s"(vp) : "memory", "m0");
+        }
+    };
+
+#define M4D_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define M4D_LGKM(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    bf16x8 ring[8];
+    f32x16 s[2];
+    bf16x8 pf[4];
+
+    // S^T = K Q^T of the tile in stage `st` (16 MFMAs, K fragments two kk ahead)
+#define M4D_QK(B, KK, SUB, OFF, W) do { M4D_LGKM(W); mma32(B, qf[KK], s[SUB]); if ((KK) + 2 < 8) M4D_DSR(B, ka[((KK) + 2) & 7], OFF); } while (0)
+#define M4D_QK_TILE(FIRSTWAIT)                                                                                        \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int sub = 0; sub < 2; ++sub)                                                          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;                                          \
+        M4D_QK(ring[0], 0, 0, 0, 3); M4D_QK(ring[1], 0, 1, 8192, 3); M4D_QK(ring[2], 1, 0, 0, 3); M4D_QK(ring[3], 1, 1, 8192, 3);    \
+        M4D_QK(ring[0], 2, 0, 0, 3); M4D_QK(ring[1], 2, 1, 8192, 3); M4D_QK(ring[2], 3, 0, 0, 3); M4D_QK(ring[3], 3, 1, 8192, 3);    \
+        M4D_QK(ring[0], 4, 0, 0, 3); M4D_QK(ring[1], 4, 1, 8192, 3); M4D_QK(ring[2], 5, 0, 0, 3); M4D_QK(ring[3], 5, 1, 8192, 3);    \
+        M4D_QK(ring[0], 6, 0, 0, 3); M4D_QK(ring[1], 6, 1, 8192, 2); M4D_QK(ring[2], 7, 0, 0, 1); M4D_QK(ring[3], 7, 1, 8192, 0);    \
+    } while (0)
+#define M4D_QK_PREFETCH() do { M4D_DSR(ring[0], ka[0], 0); M4D_DSR(ring[1], ka[0], 8192); M4D_DSR(ring[2], ka[1], 0); M4D_DSR(ring[3], ka[1], 8192); } while (0)
+    // O^T += V^T P^T (16 MFMAs, V^T fragments four steps ahead); the last four steps start the K prefetch of the next QK
+#define M4D_PV(B, C, DD, OFF, W) do { M4D_LGKM(W); mma32(B, pf[C], o[DD]); if ((C) + 1 < 4) M4D_DSR(B, va[((C) + 1) & 3], OFF); } while (0)
+#define M4D_PV_PREFETCH() do { M4D_DSR(ring[0], va[0], 0); M4D_DSR(ring[1], va[0], 4096); M4D_DSR(ring[2], va[0], 8192); M4D_DSR(ring[3], va[0], 12288); } while (0)
+#define M4D_PV_TILE()                                                                                                 \
+    do {                                                                                                             \
+        M4D_PV(ring[0], 0, 0, 0, 3); M4D_PV(ring[1], 0, 1, 4096, 3); M4D_PV(ring[2], 0, 2, 8192, 3); M4D_PV(ring[3], 0, 3, 12288, 3);  \
+        M4D_PV(ring[0], 1, 0, 0, 3); M4D_PV(ring[1], 1, 1, 4096, 3); M4D_PV(ring[2], 1, 2, 8192, 3); M4D_PV(ring[3], 1, 3, 12288, 3);  \
+        M4D_PV(ring[0], 2, 0, 0, 3); M4D_PV(ring[1], 2, 1, 4096, 3); M4D_PV(ring[2], 2, 2, 8192, 3); M4D_PV(ring[3], 2, 3, 12288, 3);  \
+        M4D_PV(ring[0], 3, 0, 0, 3); M4D_PV(ring[1], 3, 1, 4096, 2); M4D_PV(ring[2], 3, 2, 8192, 1); M4D_PV(ring[3], 3, 3, 12288, 0);  \
+    } while (0)
+    // online softmax of s (exp2 domain) -> pf; `k_lim` masks keys >= k_lim of the tile (only the peeled ragged tile)
+    auto softmax = [&](int k_lim) {
+        if (k_lim < KVB) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (sub * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) >= k_lim) s[sub][r] = -INFINITY;
+        }
+        // row max: 16 three-operand max instead of 32 canonicalising v_max_f32 pairs
+        float mx;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]));
+#pragma unroll
+        for (int r = 3; r + 1 < 16; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][r]), "v"(s[0][r + 1]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][15]), "v"(s[1][0]));
+#pragma unroll
+        for (int r = 1; r + 1 < 16; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][r]), "v"(s[1][r + 1]));
+        mx = fmaxf(mx, s[1][15]);
+        {
+            const unsigned u = __float_as_uint(mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_run, mx * p.sc);
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        // p = exp2(s * sc - m): the multiply-subtract and the row sum run two elements per instruction (v_pk_fma_f32 /
+        // v_pk_add_f32); only the 32 v_exp_f32 are scalar
+        const f32x2 sc2 = {p.sc, p.sc}, nm2 = {-m_run, -m_run};
+        f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 x = {s[sub][r], s[sub][r + 1]};
+                x = __builtin_elementwise_fma(x, sc2, nm2);
+                x[0] = __builtin_amdgcn_exp2f(x[0]);
+                x[1] = __builtin_amdgcn_exp2f(x[1]);
+                s[sub][r] = x[0];
+                s[sub][r + 1] = x[1];
+                ps2 += x;
+            }
+        l_run += ps2[0] + ps2[1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pf[c] = pack8<T>(s[c >> 1], (c & 1) * 8);
+    };
+
+    // ---- peeled ragged tail: lock-step, stage 0, zero-filled through registers ----
+    if (tail0 < len) {
+        char* base = psmem;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + 512 * i;
+            {
+                const int row = c >> 4, ch = c & 15;
+                const int64_t key = tail0 + row;
+                const uint4 v = key < len ? *reinterpret_cast<const uint4*>(kbase + key * kls + ch * 8) : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(base + swz_off<256>(row, ch)) = v;
+            }
+            {
+                const int row = c >> 3, ch = c & 7;
+                const int64_t key = tail0 + ch * 8;
+                const T* src = vbase + row * vls + key;
+                union { uint4 u; T e[8]; } tmp;
+                tmp.u = make_uint4(0, 0, 0, 0);
+                if (key + 8 <= len) tmp.u = *reinterpret_cast<const uint4*>(src);
+                else if (key < len) {
+                    for (int j = 0; j < 8; ++j)
+                        if (key + j < len) tmp.e[j] = src[j];
+                }
+                *reinterpret_cast<uint4*>(base + VOFF + swz_off<128>(row, ch)) = tmp.u;
+            }
+        }
+        __syncthreads();
+        M4D_QK_PREFETCH();
+        M4D_QK_TILE(0);
+        M4D_PV_PREFETCH();
+        softmax((int)(len - tail0));
+        __builtin_amdgcn_sched_barrier(0);
+        M4D_PV_TILE();
+        __syncthreads();
+    }
+
+    if (NT > 0) {
+        // ---- pipeline prologue: tiles 0..2 requested, S(0) computed in lock-step, then the groups split ----
+        dma_tile(0, 0);
+        if (NT > 1) dma_tile(1, KVB);
+        if (NT > 2) dma_tile(2, 2 * KVB);
+        if (NT > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tiles 0 and 1 landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        M4D_QK_PREFETCH();
+        M4D_QK_TILE(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) ka[kk] += STAGE;                    // K side now points at tile 1 (stage 1)
+        if (grp == 1) __builtin_amdgcn_s_barrier();                        // group 1 runs one barrier behind group 0
+#define M4D_V_PHASE()                                                                                                 \
+    do {                                                                                                             \
+        m_prefetch<0, 4>(ring, va, ka);      /* V^T(i) landed long ago; (only four: the softmax needs the registers) */ \
+        if (!(p.abl & 1)) softmax(KVB);                                                                              \
+        /* pin the whole softmax (exp2, row sums, bf16 packing) in front of the barrier: without these uses the      \
+           compiler sinks the 32 v_exp_f32 behind it, i.e. into the MFMA phase this schedule exists to keep clean */  \
+        asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));                                          \
+        asm volatile("" : "+v"(l_run), "+v"(m_run));                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                \
+    } while (0)
+        int i = 0;
+        for (; i + 1 < NT; ++i) {
+            M4D_V_PHASE();
+            // ---- M(i): one stream of 32 MFMAs (PV(i) then QK(i+1)), fragments 8 steps ahead ----
+            if (i + 3 < NT) dma_tile((i + 3) & 3, (int64_t)(i + 3) * KVB);
+            __builtin_amdgcn_sched_barrier(0);
+            m_prefetch<4, 8>(ring, va, ka);
+            __builtin_amdgcn_s_setprio(1);
+            if (!(p.abl & 2)) m_steps<0, 32>(ring, va, ka, pf, qf, o, s);
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_setprio(0);
+            {   // advance the fragment addresses one stage (mod 4): va -> tile i+1, ka -> tile i+2
+                const unsigned dv = ((i + 1) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);
+                const unsigned dk = ((i + 2) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) va[c] += dv;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) ka[kk] += dk;
+            }
+            // tile i+2 must have landed before anyone starts M(i+1); tile i+3 (just requested) may stay in flight
+            if (i + 3 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---- last tile: V(NT-1), then PV only ----
+        M4D_V_PHASE();
+        m_prefetch<4, 8>(ring, va, ka);
+        __builtin_amdgcn_s_setprio(1);
+        m_steps<0, 16>(ring, va, ka, pf, qf, o, s);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+#undef M4D_V_PHASE
+        if (grp == 0) __builtin_amdgcn_s_barrier();                        // balance the barrier count
+    }
+#undef M4D_PV_TILE
+#undef M4D_PV_PREFETCH
+#undef M4D_PV
+#undef M4D_QK_PREFETCH
+#undef M4D_QK_TILE
+#undef M4D_QK
+#undef M4D_LGKM
+#undef M4D_DSR
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (p.lse && qvalid && hi == 0) p.lse[((int64_t)b * p.heads + h) * p.Lq + qrow] = m_run + log2f(l_tot);
+    if (qvalid) {
+        T* op = (T*)p.out + b * p.o_bs + qrow * p.o_ls + (int64_t)h * D + hi * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][rq * 4 + e] * inv;
+                T* dst = op + d * 32 + rq * 8;
+                if (p.accumulate) {
+                    f32x4 prev = load4(dst);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]) + prev[e];
+                }
+                store4(dst, v);
+            }
+    }
+}
