@@ -491,6 +491,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
 }
 
 #include "attention_phased.h"
+#include "attention_wide.h"
 
 template <typename T>
 int launch(const AttnArgs& p, int D, hipStream_t st) {
@@ -502,7 +503,27 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         // keep the 4-wave workgroups (measured: 1000 vs 924 TF at Lk = 21840, 657 vs 678 TF at Lk = 512)
         const bool w8 = p.Lq > 1024 && keys >= 2048 && !getenv("M4D_ATTN_W4");
         AttnArgs q = p;
-        if (w8 && p.kv.nseg == 1 && !getenv("M4D_ATTN_LOCKSTEP")) {
+        static int wide_mode = -1;
+        if (wide_mode < 0) { const char* v = getenv("M4D_ATTN_WIDE"); wide_mode = v ? atoi(v) : 0; }   // experiment, see attention_wide.h
+        if (w8 && p.kv.nseg == 1 && wide_mode) {
+            // 64 queries per wave: half the LDS traffic per MFMA, softmax interleaved into the MFMA stream (attention_wide.h)
+            static bool configured_w = false;
+            if (!configured_w) {
+                if (hipFuncSetAttribute((const void*)attn128w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
+                hipFuncSetAttribute((const void*)attn128w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                hipFuncSetAttribute((const void*)attn128w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                hipFuncSetAttribute((const void*)attn128w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                configured_w = true;
+            }
+            q.nq_tiles = (int)((p.Lq + 255) / 256);
+            const dim3 gw((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
+            switch (p.abl & 3) {   // timing ablations (tools only): 1 no softmax, 2 no MFMAs in the main loop
+                case 1: hipLaunchKernelGGL(attn128w_kernel<1>, gw, dim3(256), 4 * 32768, st, q); break;
+                case 2: hipLaunchKernelGGL(attn128w_kernel<2>, gw, dim3(256), 4 * 32768, st, q); break;
+                case 3: hipLaunchKernelGGL(attn128w_kernel<3>, gw, dim3(256), 4 * 32768, st, q); break;
+                default: hipLaunchKernelGGL(attn128w_kernel<0>, gw, dim3(256), 4 * 32768, st, q);
+            }
+        } else if (w8 && p.kv.nseg == 1 && !getenv("M4D_ATTN_LOCKSTEP")) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
             static bool configured = false;
             if (!configured) {

@@ -187,7 +187,10 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
             const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        const float m_new = fmaxf(m_run, mx * p.sc);
+        // lazy reference maximum: it only moves when the tile maximum exceeds it by more than 2^8 (probabilities stay <= 256,
+        // harmless in fp32 / bf16; O / l and the LSE do not depend on the reference) -> the O rescale almost never runs
+        const float cand = mx * p.sc;
+        const float m_new = cand > m_run + 8.f ? cand : m_run;
         if (__any(m_new > m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
