@@ -160,3 +160,39 @@ def test_teacache_and_small_kernels():
         a = m(t=z["t"].to(DEV), **args)
         b = m(t=z["t"].to(DEV) - 30, **args)
         assert torch.isfinite(b).all() and rel_err(b.cpu(), a.cpu()) < 0.5
+
+
+def test_rccl_gather_plumbing_world1():
+    """The RCCL side of the T-sharded path on the real device (world 1 is all a 1-GPU box can offer): async
+    all_gather_into_tensor of K and V^T in bf16, stream-ordered wait, segments consumed by the attention kernel,
+    head all-gather.  The multi-rank arithmetic is covered by the gloo tests."""
+    import os
+    import torch.distributed as dist
+    from more4d_amd import ops
+    from more4d_amd.dist import SequenceParallelGroup
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29611")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sp = SequenceParallelGroup()
+        B, Ls, heads, hd = 2, 264, 2, 128
+        C = heads * hd
+        g = torch.Generator().manual_seed(0)
+        q = torch.randn(B * Ls, C, generator=g).to(DEV, torch.bfloat16)
+        k = torch.randn(B * Ls, C, generator=g).to(DEV, torch.bfloat16)
+        vt = torch.randn(C, B * Ls, generator=g).to(DEV, torch.bfloat16)
+        hk = sp.gather_start(k)
+        hv = sp.gather_start(vt)
+        segs = sp.gather_finish(hk, hv, B, Ls, C, Ls - 3)
+        o = ops.attention(q, segs, B=B, Lq=Ls, heads=heads, head_dim=hd, q_bs=Ls * C, q_ls=C)
+        ref = ops.attention(q, [ops.KV(k, vt, Ls * C, C, Ls, B * Ls, Ls - 3)], B=B, Lq=Ls, heads=heads, head_dim=hd,
+                            q_bs=Ls * C, q_ls=C)
+        assert torch.equal(o, ref)
+        x = torch.randn(B, Ls, 64, generator=g).to(DEV)
+        assert torch.equal(sp.all_gather(x, dim=1), x)
+        segs2 = sp.gather_kv(k, vt, B, Ls, C, Ls)
+        assert segs2[0].len == Ls and segs2[0].k.data_ptr() != k.data_ptr()
+    finally:
+        dist.destroy_process_group()
