@@ -503,6 +503,10 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         // keep the 4-wave workgroups (measured: 1000 vs 924 TF at Lk = 21840, 657 vs 678 TF at Lk = 512)
         const bool w8 = p.Lq > 1024 && keys >= 2048 && !getenv("M4D_ATTN_W4");
         AttnArgs q = p;
+        bool same_strides = true;     // the phased kernel shares one per-lane DMA offset across segments
+        for (int i = 1; i < p.kv.nseg; ++i)
+            if (p.kv.len[i] > 0 && (p.kv.k_ls[i] != p.kv.k_ls[0] || p.kv.vt_ls[i] != p.kv.vt_ls[0])) same_strides = false;
+        if (p.kv.len[0] <= 0) same_strides = p.kv.nseg == 1;
         static int wide_mode = -1;
         if (wide_mode < 0) { const char* v = getenv("M4D_ATTN_WIDE"); wide_mode = v ? atoi(v) : 0; }   // experiment, see attention_wide.h
         if (w8 && p.kv.nseg == 1 && wide_mode) {
@@ -523,7 +527,7 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
                 case 3: hipLaunchKernelGGL(attn128w_kernel<3>, gw, dim3(256), 4 * 32768, st, q); break;
                 default: hipLaunchKernelGGL(attn128w_kernel<0>, gw, dim3(256), 4 * 32768, st, q);
             }
-        } else if (w8 && p.kv.nseg == 1 && !getenv("M4D_ATTN_LOCKSTEP")) {
+        } else if (w8 && same_strides && !getenv("M4D_ATTN_LOCKSTEP")) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
             static bool configured = false;
             if (!configured) {

@@ -104,12 +104,17 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
     const int k_r = lane >> 4, k_lc0 = lane & 15;
     const int v_r = lane >> 3, v_pc = lane & 7;
 
-    const int64_t len = p.kv.len[0];
-    const T* kbase = (const T*)p.kv.k[0] + b * p.kv.k_bs[0] + (int64_t)h * D;
-    const T* vbase = (const T*)p.kv.vt[0] + b * p.kv.vt_bs[0] + (int64_t)h * D * p.kv.vt_ls[0];
+    // K/V may arrive as several segments (one per rank of the T-sharded loop) that share their strides (host-checked).
+    // Full 64-key tiles of all segments form one pipelined tile list; each segment's ragged tail is peeled first.
     const int64_t kls = p.kv.k_ls[0], vls = p.kv.vt_ls[0];
-    const int NT = (int)(len / KVB);            // full tiles, pipelined
-    const int64_t tail0 = (int64_t)NT * KVB;    // first key of the ragged tail (if any)
+    int NT = 0;                                 // full tiles of all segments, pipelined
+    for (int sg = 0; sg < p.kv.nseg; ++sg) NT += p.kv.len[sg] > 0 ? (int)(p.kv.len[sg] / KVB) : 0;
+    auto seg_k = [&](int sg) { return (const T*)p.kv.k[sg] + b * p.kv.k_bs[sg] + (int64_t)h * D; };
+    auto seg_v = [&](int sg) { return (const T*)p.kv.vt[sg] + b * p.kv.vt_bs[sg] + (int64_t)h * D * p.kv.vt_ls[sg]; };
+    // DMA iterator over the tile list: (segment, first key); wave-uniform
+    int dseg = 0;
+    int64_t dk0 = 0;
+    while (dseg < p.kv.nseg && p.kv.len[dseg] < KVB) ++dseg;
 
     // DMA sources as 32-bit per-lane byte offsets from a wave-uniform base (sgpr_base + vgpr_offset addressing)
     unsigned offk[2], offv[2];
@@ -125,9 +130,15 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (const char*)(((unsigned long long)hi2 << 32) | lo);
     };
-    auto dma_tile = [&](int stage, int64_t k0) {
-        const char* kp = uniform_ptr((const char*)(kbase + k0 * kls));
-        const char* vp = uniform_ptr((const char*)(vbase + k0));
+    auto dma_tile = [&](int stage, int64_t /*unused*/) {          // requests the NEXT tile of the list
+        const char* kp = uniform_ptr((const char*)(seg_k(dseg) + dk0 * kls));
+        const char* vp = uniform_ptr((const char*)(seg_v(dseg) + dk0));
+        dk0 += KVB;
+        if (dk0 + KVB > p.kv.len[dseg]) {
+            dk0 = 0;
+            ++dseg;
+            while (dseg < p.kv.nseg && p.kv.len[dseg] < KVB) ++dseg;
+        }
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 2048);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -222,7 +233,13 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
     };
 
     // ---- peeled ragged tail: lock-step, stage 0, zero-filled through registers ----
-    if (tail0 < len) {
+    for (int sg = 0; sg < p.kv.nseg; ++sg) {
+        const int64_t len = p.kv.len[sg];
+        if (len <= 0) continue;
+        const int64_t tail0 = (len / KVB) * KVB;
+        if (tail0 >= len) continue;
+        const T* kbase = seg_k(sg);
+        const T* vbase = seg_v(sg);
         char* base = psmem;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {

@@ -329,3 +329,36 @@ def test_gemm_packed_weights(M, N, K):
     outT = o.gemm_bt(wp, ad, bd, bias_on_m=True) if M % 4 == 0 else None
     if outT is not None:
         assert rel_err(outT.float().cpu(), (q(w, dt) @ q(a, dt).t()) + q(b, dt)[:, None]) < BF16_TOL
+
+
+def test_attention_phased_kernel_segments_and_rescale():
+    """The production long-range kernel (attention_phased.h: Lq > 1024, >= 2048 keys, bf16, D = 128): three ragged
+    segments with garbage padding (the T-sharded call), plus late score spikes far beyond the lazy 2^8 rescale threshold."""
+    o = ops()
+    dt = torch.bfloat16
+    B, n, D, Lq = 1, 2, 128, 1280
+    C = n * D
+    lens, lp = [2730, 2736, 1000], 2736
+    qq = rnd(B, Lq, n, D, seed=1)
+    ks = [rnd(B, l, n, D, seed=10 + i) for i, l in enumerate(lens)]
+    vs = [rnd(B, l, n, D, seed=20 + i) for i, l in enumerate(lens)]
+    ks[1][0, 2000, 0] = qq[0, 5, 0] * 6.0          # row 5 / head 0: a spike ~ 2^60 over the running reference, late in segment 1
+    ks[2][0, 900, 1] = qq[0, 700, 1] * 5.0         # and one inside the last segment's full tiles
+    ks[2][0, 999, 1] = qq[0, 701, 1] * 5.0         # and one in its peeled ragged tail
+    ref = _attn_ref(q(qq, dt), q(torch.cat(ks, 1), dt), q(torch.cat(vs, 1), dt)).reshape(B, Lq, C)
+    segs = []
+    for k_, v_ in zip(ks, vs):
+        l = k_.shape[1]
+        kd = torch.full((B, lp, C), 7.0, dtype=dt)
+        kd[:, :l] = k_.reshape(B, l, C).to(dt)
+        vt = torch.full((C, B * lp), float("nan"), dtype=dt)
+        for b in range(B):
+            vt[:, b * lp:b * lp + l] = v_[b].reshape(l, C).t().to(dt)
+        segs.append(o.KV(kd.to(DEV), vt.to(DEV), lp * C, C, lp, B * lp, l))
+    lse = torch.empty(B, n, Lq, device=DEV)
+    out = o.attention(qq.reshape(B, Lq, C).to(DEV, dt).contiguous(), segs, B=B, Lq=Lq, heads=n, head_dim=D, lse=lse)
+    assert torch.isfinite(out).all()
+    assert rel_err(out.float().cpu(), ref) < BF16_TOL
+    s = torch.einsum("bqhd,bkhd->bhqk", q(qq, dt), q(torch.cat(ks, 1), dt)) / D ** 0.5
+    lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634
+    assert float((lse.cpu() - lse_ref).abs().max()) < 5e-2
