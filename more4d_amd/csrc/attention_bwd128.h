@@ -190,19 +190,33 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
                     for (int j = 0; j < 4; ++j) { dv[j] = d0[j]; dv[4 + j] = d1[j]; }
                 }
             }
+            // two elements per instruction wherever the ISA has a packed fp32 form (v_pk_fma_f32 / v_pk_mul_f32); only
+            // the exp2 is scalar.  dS = P * (G * scale - delta * scale)
             bf16x8 out;
+            const f32x2 sc2 = {p.sc, p.sc}, scale2 = {p.scale, p.scale};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float pv;
+            for (int j = 0; j < 8; j += 2) {
+                f32x2 x = {sv[rb + j], sv[rb + j + 1]};
+                f32x2 nl;
+                if constexpr (STAT_Y) nl = f32x2{-lv[j], -lv[j + 1]};
+                else nl = f32x2{-lse_x, -lse_x};
+                x = __builtin_elementwise_fma(x, sc2, nl);
+                f32x2 pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
                 if constexpr (STAT_Y) {
-                    pv = __builtin_amdgcn_exp2f(fmaf(sv[rb + j], p.sc, -lv[j]));
-                    if (!xvalid) pv = 0.f;
+                    if (!xvalid) pv = f32x2{0.f, 0.f};
                 } else {
-                    pv = __builtin_amdgcn_exp2f(fmaf(sv[rb + j], p.sc, -lse_x));
-                    if (y0 + yb + j >= p.LY) pv = 0.f;
+                    if (y0 + yb + j >= p.LY) pv[0] = 0.f;
+                    if (y0 + yb + j + 1 >= p.LY) pv[1] = 0.f;
                 }
-                if constexpr (HAS_G) pv *= (gv[rb + j] - (STAT_Y ? dv[j] : delta_x)) * p.scale;
-                out[j] = (T)pv;
+                if constexpr (HAS_G) {
+                    f32x2 nd;
+                    if constexpr (STAT_Y) nd = f32x2{-dv[j], -dv[j + 1]} * scale2;
+                    else nd = f32x2{-delta_x, -delta_x} * scale2;
+                    const f32x2 gg = {gv[rb + j], gv[rb + j + 1]};
+                    pv = pv * __builtin_elementwise_fma(gg, scale2, nd);
+                }
+                out[j] = (T)pv[0];
+                out[j + 1] = (T)pv[1];
             }
             return out;
         };
