@@ -133,10 +133,20 @@ def _block_param_names(blk):
     return [n for n, _ in blk.named_parameters()]
 
 
-def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres):
+STORE_KEYS = ("qkv_pre", "o", "lse1", "y1", "qc_pre", "yc", "pre", "y2")
+STORE_LITE = ("o", "lse1", "y2")     # best recompute time saved per stored byte: self-attention output + ffn_down output
+
+
+def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None, forward_only=False):
     """Recompute WanAttentionBlock.run on x0 keeping the intermediates, then back-propagate `dres`
     (float32 [B, Lp, C], gradient w.r.t. the block output; overwritten with the gradient w.r.t. x0).
-    Returns (de0 [B,6,C] float32, dtxt, dimg, {param name: grad})."""
+    Returns (de0 [B,6,C] float32, dtxt, dimg, {param name: grad}).
+
+    `saved` (STORE_KEYS -> tensor): outputs of the six big GEMMs and of the self-attention that the forward kept in
+    HBM ("stored" blocks, see BlockFn); they are used instead of being recomputed — only the HBM-bound LayerNorm /
+    RMSNorm / GELU passes and the small cross-attention run again.  forward_only=True runs just the forward half and
+    returns (x3, {STORE_KEYS}) — the same code path produces the stored tensors, so both modes are bit-identical."""
+    saved = saved or {}
     from .models.wan_transformer4d import _f32
     B, Lp, C = x0.shape
     R = B * Lp
@@ -156,29 +166,37 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres):
 
     e = ops.add_bcast(e0, f32(blk.modulation))                      # [B,6,C]: shift1 scale1 gate1 shift2 scale2 gate2
     de = zeros(B, 6, C)
-    dres2 = dres.view(R, C)
+    dres2 = dres.view(R, C) if dres is not None else None
 
     # ================= recompute (reference :659-684) =================
     xn1 = ops.ln_modulate(x0, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=Lp, eps=eps).view(R, C)
-    qkv_pre = torch.empty((R, 3 * C), device=dev, dtype=T)
-    for j, lin in enumerate((sa.q, sa.k, sa.v)):
-        ops.gemm_bt(xn1, lin.weight, lin.bias, out=qkv_pre[:, j * C:(j + 1) * C])
+    qkv_pre = saved.get("qkv_pre")
+    if qkv_pre is None:
+        qkv_pre = torch.empty((R, 3 * C), device=dev, dtype=T)
+        for j, lin in enumerate((sa.q, sa.k, sa.v)):
+            ops.gemm_bt(xn1, lin.weight, lin.bias, out=qkv_pre[:, j * C:(j + 1) * C])
     qkv = qkv_pre.clone()
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     rope = dict(head_dim=d, eps=sa.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
                 pos_offset=c.pos_offset)
     ops.rmsnorm_rope(q, f32(sa.norm_q.weight), k, f32(sa.norm_k.weight), **rope)
-    vt = ops.transpose(v)                                            # V^T [C, R]
-    lse1 = torch.empty((B, n, Lp), device=dev, dtype=torch.float32)
-    o = ops.attention(q, [KV(k, vt, Lp * 3 * C, 3 * C, Lp, R, c.key_len)], B=B, Lq=Lp, heads=n, head_dim=d,
-                      q_bs=Lp * 3 * C, q_ls=3 * C, lse=lse1).view(R, C)
-    y1 = ops.gemm_bt(o, sa.o.weight, sa.o.bias)
+    o, lse1 = saved.get("o"), saved.get("lse1")
+    if o is None:
+        vt = ops.transpose(v)                                        # V^T [C, R]
+        lse1 = torch.empty((B, n, Lp), device=dev, dtype=torch.float32)
+        o = ops.attention(q, [KV(k, vt, Lp * 3 * C, 3 * C, Lp, R, c.key_len)], B=B, Lq=Lp, heads=n, head_dim=d,
+                          q_bs=Lp * 3 * C, q_ls=3 * C, lse=lse1).view(R, C)
+    y1 = saved.get("y1")
+    if y1 is None:
+        y1 = ops.gemm_bt(o, sa.o.weight, sa.o.bias)
     x1 = ops.resid_gate(x0, y1, gate=e[:, 2], gate_stride=st, rows_per_sample=Lp)
     if blk.cross_attn_norm:
         xn3 = ops.ln_modulate(x1, T, ln_w=f32(blk.norm3.weight), ln_b=f32(blk.norm3.bias), eps=eps).view(R, C)
     else:
         xn3 = ops.unary(x1, T).view(R, C)
-    qc_pre = ops.gemm_bt(xn3, ca.q.weight, ca.q.bias)
+    qc_pre = saved.get("qc_pre")
+    if qc_pre is None:
+        qc_pre = ops.gemm_bt(xn3, ca.q.weight, ca.q.bias)
     qc = qc_pre.clone()
     ops.rmsnorm_rope(qc, f32(ca.norm_q.weight), head_dim=d, eps=ca.eps)
     srcs = [("txt", txt, txt_len, ca.k, ca.v, ca.norm_k)]
@@ -199,12 +217,21 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres):
                            q_bs=Lp * C, q_ls=C, lse=lse).view(R, C)
         oc = oo if oc is None else ops.add(oc, oo)
         cross.append((name, s2, Sp, valid, kl, vl, nk, k_pre, kk, vv, oo, lse))
-    yc = ops.gemm_bt(oc, ca.o.weight, ca.o.bias)
+    yc = saved.get("yc")
+    if yc is None:
+        yc = ops.gemm_bt(oc, ca.o.weight, ca.o.bias)
     x2 = ops.resid_gate(x1, yc)
     xn2 = ops.ln_modulate(x2, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=Lp, eps=eps).view(R, C)
-    pre = ops.gemm_bt(xn2, blk.ffn[0].weight, blk.ffn[0].bias)
+    pre = saved.get("pre")
+    if pre is None:
+        pre = ops.gemm_bt(xn2, blk.ffn[0].weight, blk.ffn[0].bias)
     h = ops.unary(pre, T, act=ACT_GELU_TANH)
-    y2 = ops.gemm_bt(h, blk.ffn[2].weight, blk.ffn[2].bias)
+    y2 = saved.get("y2")
+    if y2 is None:
+        y2 = ops.gemm_bt(h, blk.ffn[2].weight, blk.ffn[2].bias)
+    if forward_only:
+        x3 = ops.resid_gate(x2, y2, gate=e[:, 5], gate_stride=st, rows_per_sample=Lp)
+        return x3, dict(qkv_pre=qkv_pre, o=o, lse1=lse1, y1=y1, qc_pre=qc_pre, yc=yc, pre=pre, y2=y2)
 
     # ================= backward =================
     # ---- ffn: x3 = x2 + y2 * gate2
@@ -274,19 +301,32 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres):
 
 
 class BlockFn(Function):
-    """WanAttentionBlock with per-block recompute.  apply(x, e0, txt, img, blk, c, txt_len, img_len, *params)."""
+    """WanAttentionBlock on the tape.  apply(x, e0, txt, img, blk, c, txt_len, img_len, store, *params).
+
+    store=0: classic per-block gradient checkpointing (keep the block input, recompute everything in backward).
+    store=2: the forward additionally keeps the outputs of the six big GEMMs and of the self-attention (STORE_KEYS,
+    2.4 GB per block at L = 21 840, C = 5120) and the backward skips their recompute: fwd + bwd instead of fwd +
+    recompute + bwd.  store=1 keeps only STORE_LITE (0.45 GB per block: the self-attention and ffn_down outputs, the
+    best recompute time per byte).  `WanTransformer4DModel.activation_budget_gb` decides how many blocks get which."""
 
     @staticmethod
-    def forward(ctx, x, e0, txt, img, blk, c, txt_len, img_len, *params):
+    def forward(ctx, x, e0, txt, img, blk, c, txt_len, img_len, store, *params):
         from .models.wan_transformer4d import ContextCache
         if c.sp is not None and c.sp.world_size > 1:
             raise NotImplementedError("training uses data parallelism; sequence parallelism is the inference path")
-        out = x.detach().clone()
-        cc = ContextCache()
-        cc.txt, cc.txt_len, cc.img, cc.img_len = txt.detach(), txt_len, (img.detach() if img is not None else None), img_len
-        blk.run(out, e0.detach().contiguous(), c, cc, 0, None)
+        stash = None
+        if store:   # 2: every GEMM / attention output, 1: STORE_LITE only
+            out, stash = block_backward(blk, x.detach(), e0.detach().contiguous(), c, txt.detach(), txt_len,
+                                        img.detach() if img is not None else None, img_len, None, forward_only=True)
+            if store == 1:
+                stash = {k: stash[k] for k in STORE_LITE}
+        else:
+            out = x.detach().clone()
+            cc = ContextCache()
+            cc.txt, cc.txt_len, cc.img, cc.img_len = txt.detach(), txt_len, (img.detach() if img is not None else None), img_len
+            blk.run(out, e0.detach().contiguous(), c, cc, 0, None)
         ctx.save_for_backward(x, e0, txt, img)
-        ctx.blk, ctx.c, ctx.lens = blk, c, (txt_len, img_len)
+        ctx.blk, ctx.c, ctx.lens, ctx.stash = blk, c, (txt_len, img_len), stash
         ctx.names = _block_param_names(blk)
         return out
 
@@ -295,10 +335,12 @@ class BlockFn(Function):
         x, e0, txt, img = ctx.saved_tensors
         blk = ctx.blk
         dres = dout.contiguous().clone()
+        stash, ctx.stash = ctx.stash, None
         de, dtxt, dimg, G = block_backward(blk, x.detach(), e0.detach().contiguous(), ctx.c, txt.detach(), ctx.lens[0],
-                                           img.detach() if img is not None else None, ctx.lens[1], dres)
+                                           img.detach() if img is not None else None, ctx.lens[1], dres, saved=stash)
+        del stash
         grads = []
         for name, p in zip(ctx.names, blk.parameters()):
             g = G.get(name)
             grads.append(None if g is None else g.to(p.dtype).view(p.shape))
-        return (dres, de, dtxt, dimg, None, None, None, None, *grads)
+        return (dres, de, dtxt, dimg, None, None, None, None, None, *grads)

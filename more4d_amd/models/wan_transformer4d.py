@@ -477,6 +477,12 @@ class WanTransformer4DModel(nn.Module):
         self.sp_world_rank = 0
         self._sp = None
         self.mask_padding_keys = False   # False = the reference's SDPA branch (k_lens ignored, :222-226)
+        # training: GB of HBM the forward may spend on stored activations (None = whatever is free minus the head-room
+        # below; 0 = plain per-block gradient checkpointing like the reference)
+        self.activation_budget_gb = None
+        self.activation_headroom_gb = 95.0     # backward workspace + allocator slack (measured: beyond ~230 GB live the step time gets erratic)
+        self.last_stored_blocks = 0
+        self.last_full_blocks = 0
         self._f32cache = {}
         self._rope_cache = {}
         self.init_weights()
@@ -773,8 +779,27 @@ class WanTransformer4DModel(nn.Module):
             ctx_img, img_len = LayerNormFn.apply(a, p[4].weight, p[4].bias, None, None, p[4].eps, T), n
         cos, sin = self._rope_tables(grid, dev)
         c = _Ctx(B, L, Lp, grid, cos, sin, L, self._f32cache, key_len)
-        for blk in self.blocks:
-            xres = BlockFn.apply(xres, e0, ctx_txt, ctx_img, blk, c, self.text_len, img_len, *blk.parameters())
+        # activation policy (288 GB of HBM3E per GPU): within the budget, every block first keeps its STORE_LITE tensors
+        # (self-attention + ffn_down outputs), then blocks are upgraded to keeping all GEMM outputs; the rest recompute
+        es = xres.new_empty(0, dtype=T).element_size()
+        lite = B * Lp * 2 * C * es + B * self.num_heads * Lp * 4
+        full = B * Lp * (8 * C + self.ffn_dim) * es + B * self.num_heads * Lp * 4
+        budget = self.activation_budget_gb
+        if budget is None:
+            if dev.type == "cuda":
+                total = torch.cuda.get_device_properties(dev).total_memory
+                budget = max(0.0, (total - torch.cuda.memory_allocated(dev)) / 2 ** 30 - self.activation_headroom_gb)
+            else:
+                budget = 0.0
+        budget = max(0.0, budget) * 2 ** 30
+        nb = len(self.blocks)
+        n_lite = int(min(nb, budget // max(lite, 1)))
+        n_full = int(min(n_lite, max(0.0, budget - n_lite * lite) // max(full - lite, 1))) if n_lite == nb else 0
+        self.last_stored_blocks = n_lite
+        self.last_full_blocks = n_full
+        for i, blk in enumerate(self.blocks):
+            store = 2 if i < n_full else (1 if i < n_lite else 0)
+            xres = BlockFn.apply(xres, e0, ctx_txt, ctx_img, blk, c, self.text_len, img_len, store, *blk.parameters())
         # ---- head (:708-721) + unpatchify (:1343-1366)
         m = e.view(B, 1, C) + self.head.modulation.float()
         xn = LayerNormFn.apply(xres, None, None, m[:, 0], m[:, 1], self.head.eps, T)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import cpu_ops
-from util import check_grads, custom_mse_loss, load_keys, load_npz, rel_err
+from util import check_grads, same_grads, custom_mse_loss, load_keys, load_npz, rel_err
 from weights import fill
 
 pytestmark = pytest.mark.gpu
@@ -242,6 +242,16 @@ def test_tiny_dit_gradients_fp32():
     loss.backward()
     worst = check_grads({n: p.grad for n, p in m.named_parameters()}, zg, TOL)
     print("worst gradient error", worst)
+    assert m.last_stored_blocks == len(m.blocks)           # default policy on a 288 GB part: no recompute
+    # plain per-block gradient checkpointing (budget 0) gives the same gradients
+    ref_grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    m.activation_budget_gb = 0
+    pred2 = m(x=z["x"].to(DEV), t=z["t"].to(DEV), context=[z["ctx0"].to(DEV), z["ctx1"].to(DEV)],
+              seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"].to(DEV), y=z["y"].to(DEV), full_ref=z["full_ref"].to(DEV))
+    custom_mse_loss(pred2, zg["target"].to(DEV)).backward()
+    assert m.last_stored_blocks == 0
+    same_grads({n: p.grad for n, p in m.named_parameters()}, ref_grads)
 
 
 def test_tiny_dit_gradients_bf16_budget():

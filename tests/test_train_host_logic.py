@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import cpu_ops
-from util import check_grads, custom_mse_loss, load_keys, load_npz, rel_err
+from util import check_grads, same_grads, custom_mse_loss, load_keys, load_npz, rel_err
 from weights import fill
 
 TINY = dict(model_type="i2v", in_dim=64, dim=128, ffn_dim=512, num_heads=4, num_layers=2, text_dim=64, text_len=32,
@@ -43,6 +43,17 @@ def test_product_backward_host_logic(monkeypatch):
     loss.backward()
     worst = check_grads({n: p.grad for n, p in m.named_parameters()}, zg, 1e-3)
     print("worst gradient error", worst)
+    assert m.last_stored_blocks == 0                       # no GPU here: plain per-block recompute
+    # "stored" blocks (GEMM / attention outputs kept by the forward, no recompute): identical gradients
+    ref_grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    m.activation_budget_gb = 1e6
+    pred2 = m(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"],
+              y=z["y"], full_ref=z["full_ref"])
+    assert m.last_stored_blocks == len(m.blocks) and rel_err(pred2.detach(), pred.detach()) < 1e-6
+    custom_mse_loss(pred2, zg["target"]).backward()
+    same_grads({n: p.grad for n, p in m.named_parameters()}, ref_grads)
+    m.activation_budget_gb = 0
     # frozen parameters get no gradient and do not break the tape (train_wan.py:949-954 selects by name)
     m.zero_grad(set_to_none=True)
     for n, p in m.named_parameters():

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--fp32-state", action="store_true")
+    ap.add_argument("--act-budget", type=float, default=None, help="GB of stored activations (default: automatic; 0 = recompute)")
     ap.add_argument("--profile-ops", action="store_true", help="HIP-event time per ops.* entry point (adds syncs)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -40,6 +41,7 @@ def main():
     cfg = dict(CFG_14B)
     cfg["num_layers"] = args.layers
     model = build_model(cfg, dev, torch.bfloat16).train()
+    model.activation_budget_gb = args.act_budget
     net = model
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -111,7 +113,7 @@ def main():
     out = {"metric": "train-step seconds, 14B DiT fwd+recompute+bwd+AdamW, batch 1/GPU, 49x480x832 bf16",
            "value": dt, "unit": "s/step", "n_gpus": world, "layers": args.layers, "loss": float(loss.detach()),
            "model_tflop": model_flops / 1e12, "mfma_frac": model_flops / dt / 1e12 / MFMA_BF16_PEAK_TF,
-           "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+           "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "stored_blocks": [model.last_stored_blocks, model.last_full_blocks],
            "state_dtype": "float32" if args.fp32_state else "bfloat16"}
     if timers:
         torch.cuda.synchronize()
