@@ -236,7 +236,7 @@ def main():
             ks = kt.summary()
             gk = ks.get("gemm_bt", {})
             out["roofline"] = {
-                "kernel": "gemm_bt_kernel<bf16> (all DiT projections / FFN; flops-weighted over its launches)",
+                "kernel": "gemm_bt256p_kernel via m4d_gemm_bt (all DiT projections / FFN, bf16; flops-weighted over its launches)",
                 "bound": "mfma", "achieved": gk.get("tflops", 0.0), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                 "frac": gk.get("tflops", 0.0) / MFMA_BF16_PEAK_TF, "traffic": None,
                 "launches": gk.get("launches", 0), "avg_launch_ms": gk.get("ms", 0.0) / max(1, gk.get("launches", 1)),
@@ -244,7 +244,7 @@ def main():
             }
             ak = ks.get("attention", {})
             out["roofline_attention"] = {
-                "kernel": "attn_kernel<bf16,128>", "bound": "mfma", "achieved": ak.get("tflops", 0.0),
+                "kernel": "attn128p_kernel (self) + attn128_kernel<4> (cross) via m4d_attention", "bound": "mfma", "achieved": ak.get("tflops", 0.0),
                 "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ak.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
                 "launches": ak.get("launches", 0), "share_of_step_time": ak.get("ms", 0.0) / (dt * 1e3),
             }
