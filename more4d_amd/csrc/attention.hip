@@ -508,8 +508,8 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             if (p.kv.len[i] > 0 && (p.kv.k_ls[i] != p.kv.k_ls[0] || p.kv.vt_ls[i] != p.kv.vt_ls[0])) same_strides = false;
         if (p.kv.len[0] <= 0) same_strides = p.kv.nseg == 1;
         static int wide_mode = -1;
-        if (wide_mode < 0) { const char* v = getenv("M4D_ATTN_WIDE"); wide_mode = v ? atoi(v) : 0; }   // experiment, see attention_wide.h
-        if (w8 && p.kv.nseg == 1 && wide_mode) {
+        if (wide_mode < 0) { const char* v = getenv("M4D_ATTN_WIDE"); wide_mode = v ? atoi(v) : 0; }   // 1: 64-queries-per-wave kernel (attention_wide.h); same-box A/B: phased 1048 vs wide 1020 TF sustained
+        if (w8 && same_strides && keys >= 4 * 64 + 64 * p.kv.nseg && wide_mode) {
             // 64 queries per wave: half the LDS traffic per MFMA, softmax interleaved into the MFMA stream (attention_wide.h)
             static bool configured_w = false;
             if (!configured_w) {

@@ -115,6 +115,11 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
     int dseg = 0;
     int64_t dk0 = 0;
     while (dseg < p.kv.nseg && p.kv.len[dseg] < KVB) ++dseg;
+    // base pointers / length of the iterator's CURRENT segment live in scalars and are re-read only when it moves on
+    // (indexing the kernel-argument arrays per tile costs scalar memory loads on the critical path of every iteration)
+    const T* dkb = dseg < p.kv.nseg ? seg_k(dseg) : nullptr;
+    const T* dvb = dseg < p.kv.nseg ? seg_v(dseg) : nullptr;
+    int64_t dlen = dseg < p.kv.nseg ? p.kv.len[dseg] : 0;
 
     // DMA sources as 32-bit per-lane byte offsets from a wave-uniform base (sgpr_base + vgpr_offset addressing)
     unsigned offk[2], offv[2];
@@ -131,13 +136,14 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         return (const char*)(((unsigned long long)hi2 << 32) | lo);
     };
     auto dma_tile = [&](int stage, int64_t /*unused*/) {          // requests the NEXT tile of the list
-        const char* kp = uniform_ptr((const char*)(seg_k(dseg) + dk0 * kls));
-        const char* vp = uniform_ptr((const char*)(seg_v(dseg) + dk0));
+        const char* kp = uniform_ptr((const char*)(dkb + dk0 * kls));
+        const char* vp = uniform_ptr((const char*)(dvb + dk0));
         dk0 += KVB;
-        if (dk0 + KVB > p.kv.len[dseg]) {
+        if (dk0 + KVB > dlen) {
             dk0 = 0;
             ++dseg;
             while (dseg < p.kv.nseg && p.kv.len[dseg] < KVB) ++dseg;
+            if (dseg < p.kv.nseg) { dkb = seg_k(dseg); dvb = seg_v(dseg); dlen = p.kv.len[dseg]; }
         }
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 2048);
 #pragma unroll

@@ -266,12 +266,21 @@ __global__ __launch_bounds__(256, 1) void attn128w_kernel(AttnArgs p) {
         for (int c = 0; c < 4; ++c) w.va[c] = lds0 + VOFF + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
     }
 
-    const int64_t len = p.kv.len[0];
-    const T* kbase = (const T*)p.kv.k[0] + b * p.kv.k_bs[0] + (int64_t)h * D;
-    const T* vbase = (const T*)p.kv.vt[0] + b * p.kv.vt_bs[0] + (int64_t)h * D * p.kv.vt_ls[0];
+    // K/V may arrive as several segments (one per rank of the T-sharded loop) that share their strides (host-checked):
+    // the full 64-key tiles of all segments form one pipelined tile list, each segment's ragged tail is peeled first
     const int64_t kls = p.kv.k_ls[0], vls = p.kv.vt_ls[0];
-    const int NT = (int)(len / KVB);
-    const int64_t tail0 = (int64_t)NT * KVB;
+    int NT = 0;
+    for (int sg = 0; sg < p.kv.nseg; ++sg) NT += p.kv.len[sg] > 0 ? (int)(p.kv.len[sg] / KVB) : 0;
+    auto seg_k = [&](int sg) { return (const T*)p.kv.k[sg] + b * p.kv.k_bs[sg] + (int64_t)h * D; };
+    auto seg_v = [&](int sg) { return (const T*)p.kv.vt[sg] + b * p.kv.vt_bs[sg] + (int64_t)h * D * p.kv.vt_ls[sg]; };
+    int dseg = 0;                               // DMA iterator over the tile list (wave-uniform)
+    int64_t dk0 = 0;
+    while (dseg < p.kv.nseg && p.kv.len[dseg] < KVB) ++dseg;
+    // base pointers / length of the iterator's CURRENT segment live in scalars and are re-read only when it moves on
+    // (indexing the kernel-argument arrays per tile costs scalar memory loads on the critical path of every iteration)
+    const T* dkb = dseg < p.kv.nseg ? seg_k(dseg) : nullptr;
+    const T* dvb = dseg < p.kv.nseg ? seg_v(dseg) : nullptr;
+    int64_t dlen = dseg < p.kv.nseg ? p.kv.len[dseg] : 0;
 
     // DMA: 4 waves x 4 instructions per operand; lane -> (row in instruction block, physical 16-byte chunk)
     const int k_r = lane >> 4, k_lc0 = lane & 15, v_r = lane >> 3, v_pc = lane & 7;
@@ -289,8 +298,15 @@ __global__ __launch_bounds__(256, 1) void attn128w_kernel(AttnArgs p) {
         return (const char*)(((unsigned long long)hi2 << 32) | lo);
     };
     auto dma_tile = [&](int stage, int64_t k0) {
-        const char* kp = uniform_ptr((const char*)(kbase + k0 * kls));
-        const char* vp = uniform_ptr((const char*)(vbase + k0));
+        const char* kp = uniform_ptr((const char*)(dkb + dk0 * kls));      // the NEXT tile of the list (k0 unused)
+        const char* vp = uniform_ptr((const char*)(dvb + dk0));
+        dk0 += KVB;
+        if (dk0 + KVB > dlen) {
+            dk0 = 0;
+            ++dseg;
+            while (dseg < p.kv.nseg && p.kv.len[dseg] < KVB) ++dseg;
+            if (dseg < p.kv.nseg) { dkb = seg_k(dseg); dvb = seg_v(dseg); dlen = p.kv.len[dseg]; }
+        }
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 4096);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -299,7 +315,13 @@ __global__ __launch_bounds__(256, 1) void attn128w_kernel(AttnArgs p) {
         }
     };
     // ---- peeled ragged tail: stage 0 through registers (zero filled), plain order ----
-    if (tail0 < len) {
+    for (int sg = 0; sg < p.kv.nseg; ++sg) {
+        const int64_t len = p.kv.len[sg];
+        if (len <= 0) continue;
+        const int64_t tail0 = (len / KVB) * KVB;
+        if (tail0 >= len) continue;
+        const T* kbase = seg_k(sg);
+        const T* vbase = seg_v(sg);
         char* base = wsmem;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
