@@ -192,6 +192,10 @@ int m4d_add_bcast(const float* a, const float* bias, float* out, int64_t B, int6
  * axpby: out = a*x + b*y (residual re-use x + r, residual capture x_out - x_in);
  * rel_l1: out2 = { sum|cur - prev|, sum|prev| } over the modulated timestep embedding [B,6,C]. */
 int m4d_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, m4d_stream stream);
+/* out = a0*x0 + a1*x1 + a2*x2 + a3*x3 (float32; x1..x3 may be NULL; out may alias an input): the DPM-Solver++ multistep
+ * updates of orders 2 and 3 (fm_solvers.py:486-677) and x0 = x - sigma v (:385-388) as linear combinations. */
+int m4d_lincomb(const float* x0, float a0, const float* x1, float a1, const float* x2, float a2, const float* x3, float a3,
+                float* out, int64_t n, m4d_stream stream);
 int m4d_rel_l1(const float* prev, const float* cur, float* out2, int64_t n, m4d_stream stream);
 
 /* Bilinear resize, align_corners=False, of a channels-last map [B,Hi,Wi,C] -> [B,Ho,Wo,C]: the OmniMAE feature map

@@ -71,6 +71,8 @@ SIGNATURES = {
     "m4d_unary": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "m4d_add_bcast": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "m4d_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "m4d_lincomb": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_int64,
+                            c_void_p]),
     "m4d_rel_l1": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "m4d_bilinear_cl": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "m4d_conv_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +

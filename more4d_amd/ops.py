@@ -431,6 +431,22 @@ def axpby(x, y, a=1.0, b=1.0, out=None):
     return out
 
 
+def lincomb(terms, out=None):
+    """out = sum a_k * x_k over up to four (a_k, x_k) float32 terms; `out` may be one of the inputs."""
+    xs = [x for _, x in terms]
+    _dev(*xs, out)
+    if not 1 <= len(terms) <= 4 or any(x.dtype != torch.float32 or not x.is_contiguous() for x in xs):
+        raise ValueError("lincomb: 1..4 contiguous float32 tensors")
+    if out is None:
+        out = torch.empty_like(xs[0])
+    pad = list(terms) + [(0.0, None)] * (4 - len(terms))
+    args = []
+    for a, x in pad:
+        args += [_ptr(x), float(a)]
+    check(_lib.load().m4d_lincomb(*args, _ptr(out), xs[0].numel(), _stream()), "m4d_lincomb")
+    return out
+
+
 def rel_l1(prev, cur):
     """(|cur-prev|.mean() / |prev|.mean()) as a python float (host sync, like the reference's .cpu().item())."""
     _dev(prev, cur)

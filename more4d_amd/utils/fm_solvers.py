@@ -1,12 +1,15 @@
-"""Flow-matching sigma schedule and the order-1 solver of the 4D-STraG sampler.
+"""Flow-matching sigma schedule and the DPM-Solver++ multistep solver of the 4D-STraG sampler.
 
-Mirror of the configured path of MoRe4D/utils/fm_solvers.py: `get_sampling_sigmas` (:22-26),
-`FlowDPMSolverMultistepScheduler.set_timesteps` (:226-289) and the first-order update (:415-483, documented
-there as "equivalent to DDIM"), which for flow prediction reduces to the Euler step
-x <- x + (sigma_next - sigma) * v (checked against the reference in tests/golden/sched.npz).
-Orders 2/3 and the SDE variants are not the configured path and are not built.  The device-side update is
-fused with classifier-free guidance in one kernel (`ops.cfg_euler_`).
+Mirror of MoRe4D/utils/fm_solvers.py: `get_sampling_sigmas` (:22-26), `FlowDPMSolverMultistepScheduler.set_timesteps`
+(:226-289), the first-order update (:415-483, documented there as "equivalent to DDIM", which for flow prediction
+reduces to the Euler step x <- x + (sigma_next - sigma) * v) and the multistep second / third order
+updates (:486-677) with the order selection of `step` (:741-779; algorithm dpmsolver++, solver_type midpoint,
+lower_order_final, final_sigmas_type zero).  Checked against the reference in tests/golden/sched.npz and
+sched_multistep.npz.  The SDE variants are not built.  On the device every update is a linear combination of the
+sample and the stored data predictions (`ops.lincomb`); order 1 is fused with classifier-free guidance in one kernel
+(`ops.cfg_euler_`).
 """
+import math
 from typing import List, Optional, Union
 
 import numpy as np
@@ -38,14 +41,19 @@ class _SchedulerOutput:
 
 
 class FlowDPMSolverMultistepScheduler:
-    """Order-1 flow solver (DDIM-equivalent Euler).  Same ctor/`set_timesteps`/`step` contract as the
-    reference class for the arguments the 4D-STraG pipeline uses."""
+    """Flow DPM-Solver++ multistep solver, orders 1 (DDIM-equivalent Euler, the configured path) to 3.  Same
+    ctor / `set_timesteps` / `step` contract as the reference class for the arguments the 4D-STraG pipeline uses."""
     order = 1
 
-    def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 1, prediction_type: str = "flow_prediction",
-                 shift: Optional[float] = 1.0, use_dynamic_shifting=False, final_sigmas_type: str = "zero", **unused):
-        if solver_order != 1:
-            raise NotImplementedError("only solver_order=1 (the configured DDIM-equivalent path) is built")
+    def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 2, prediction_type: str = "flow_prediction",
+                 shift: Optional[float] = 1.0, use_dynamic_shifting=False, final_sigmas_type: str = "zero",
+                 algorithm_type: str = "dpmsolver++", solver_type: str = "midpoint", lower_order_final: bool = True,
+                 euler_at_final: bool = False, thresholding: bool = False, **unused):
+        if solver_order not in (1, 2, 3):
+            raise NotImplementedError("solver_order must be 1, 2 or 3")
+        if algorithm_type not in ("dpmsolver++", "deis") or solver_type not in ("midpoint", "logrho", "bh1", "bh2") or thresholding:
+            raise NotImplementedError("only algorithm_type dpmsolver++ / solver_type midpoint without thresholding is built")
+        self.solver_order, self.lower_order_final, self.euler_at_final = solver_order, lower_order_final, euler_at_final
         if prediction_type != "flow_prediction":
             raise NotImplementedError("prediction_type must be flow_prediction")
         if use_dynamic_shifting:
@@ -80,6 +88,9 @@ class FlowDPMSolverMultistepScheduler:
         self.timesteps = torch.from_numpy(timesteps).to(device=device, dtype=torch.int64)  # truncation, :276-277
         self.num_inference_steps = len(timesteps)
         self._step_index = None
+        self._sig64 = np.concatenate([sigmas, [0.0]]).astype(np.float32).astype(np.float64)   # the float32 table, in float64
+        self.model_outputs = []          # data predictions x0 = x - sigma v of the last <= solver_order steps (float32)
+        self.lower_order_nums = 0
 
     def _init_step_index(self, timestep):
         t = int(timestep)
@@ -92,21 +103,77 @@ class FlowDPMSolverMultistepScheduler:
     def dsigma(self, i):
         return float(self.sigmas[i + 1]) - float(self.sigmas[i])
 
+    # ---- multistep machinery: every update is  x_next = c_x * x + sum_k c_k * m_k  with host-side float64 coefficients
+    @staticmethod
+    def _lam(s):
+        if s <= 0.0:
+            return math.inf
+        return -math.inf if s >= 1.0 else math.log(1.0 - s) - math.log(s)
+
+    def _coefficients(self, i):
+        """(c_x, [c_m0, c_m1, c_m2]) of step i given how many data predictions are usable (:741-779)."""
+        n = self.num_inference_steps
+        sig = self._sig64
+        final = i == n - 1          # final_sigmas_type == "zero"
+        second = i == n - 2 and self.lower_order_final and n < 15
+        st, s0 = sig[i + 1], sig[i]
+        at = 1.0 - st
+        h = self._lam(st) - self._lam(s0)
+        e = math.expm1(-h) if math.isfinite(h) else -1.0
+        cx = st / s0
+        if self.solver_order == 1 or self.lower_order_nums < 1 or final:
+            return cx, [-at * e]
+        h0 = self._lam(s0) - self._lam(sig[i - 1])
+        r0 = h0 / h
+        if self.solver_order == 2 or self.lower_order_nums < 2 or second:
+            # x = cx x - at e m0 - 0.5 at e (m0 - m1) / r0
+            return cx, [-at * e * (1.0 + 0.5 / r0), 0.5 * at * e / r0]
+        h1 = self._lam(sig[i - 1]) - self._lam(sig[i - 2])
+        r1 = h1 / h
+        a1 = at * (e / h + 1.0)                  # coefficient of D1
+        a2 = -at * ((e + h) / h ** 2 - 0.5)      # coefficient of D2
+        # D1_0 = (m0 - m1)/r0, D1_1 = (m1 - m2)/r1, D1 = D1_0 + r0/(r0+r1) (D1_0 - D1_1), D2 = (D1_0 - D1_1)/(r0+r1)
+        w10 = a1 * (1.0 + r0 / (r0 + r1)) + a2 / (r0 + r1)      # weight of D1_0
+        w11 = -a1 * r0 / (r0 + r1) - a2 / (r0 + r1)             # weight of D1_1
+        return cx, [-at * e + w10 / r0, -w10 / r0 + w11 / r1, -w11 / r1]
+
+    def _advance(self, x32, v32, i):
+        """x32, v32: float32 sample and (guided) model output of step i -> next sample (float32)."""
+        m0 = ops.lincomb([(1.0, x32), (-float(self._sig64[i]), v32)])           # x0 = x - sigma v (:385-388)
+        self.model_outputs = (self.model_outputs + [m0])[-self.solver_order:]
+        cx, cm = self._coefficients(i)
+        terms = [(cx, x32)] + [(c, m) for c, m in zip(cm, reversed(self.model_outputs))]
+        nxt = ops.lincomb(terms)
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        return nxt
+
     def step(self, model_output, timestep, sample, generator=None, variance_noise=None, return_dict=True):
-        """prev = sample + (sigma_next - sigma) * model_output, fp32 then cast back (:760, :789)."""
+        """One solver step; fp32 arithmetic, result cast back to the model-output dtype (:760, :789)."""
         if self.num_inference_steps is None:
             raise ValueError("run set_timesteps first")
         if self._step_index is None:
             self._init_step_index(timestep)
-        ds = self.dsigma(self._step_index)
-        x = sample.float().contiguous().clone()
-        # guidance 1 with both halves = model_output gives x + ds * model_output through the fused kernel
-        v2 = torch.stack([model_output, model_output]).contiguous()
-        ops.cfg_euler_(x, v2, 1.0, ds)
+        if self.solver_order == 1:
+            ds = self.dsigma(self._step_index)
+            x = sample.float().contiguous().clone()
+            # guidance 1 with both halves = model_output gives x + ds * model_output through the fused kernel
+            v2 = torch.stack([model_output, model_output]).contiguous()
+            ops.cfg_euler_(x, v2, 1.0, ds)
+        else:
+            x = self._advance(sample.float().contiguous(), model_output.float().contiguous(), self._step_index)
         prev = x.to(model_output.dtype)
         self._step_index += 1
         return _SchedulerOutput(prev) if return_dict else (prev,)
 
     def step_cfg_(self, latents_f32, v_pair, guidance_scale, i, round_dtype=torch.float32):
-        """Fused CFG + Euler on the fp32 latent state, in place (pipeline :820-825 in one kernel)."""
-        return ops.cfg_euler_(latents_f32, v_pair, guidance_scale, self.dsigma(i), round_dtype)
+        """CFG + solver step on the fp32 latent state, in place (pipeline :820-825).  Order 1: one fused kernel."""
+        if self.solver_order == 1:
+            return ops.cfg_euler_(latents_f32, v_pair, guidance_scale, self.dsigma(i), round_dtype)
+        vu, vc = v_pair[0].float().contiguous(), v_pair[1].float().contiguous()
+        v = ops.lincomb([(1.0 - guidance_scale, vu), (guidance_scale, vc)])      # v_u + g (v_c - v_u)
+        if round_dtype != torch.float32:
+            v = v.to(round_dtype).float()
+        nxt = self._advance(latents_f32.contiguous().view(v.shape), v, i)
+        latents_f32.copy_(nxt.view(latents_f32.shape))
+        return latents_f32

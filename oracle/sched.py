@@ -45,3 +45,50 @@ def denoise_loop(model_fn, latents, timesteps, sigmas, guidance_scale):
         vu, vc = v.chunk(2)
         x = euler_step(x, cfg_combine(vu, vc, guidance_scale), sigmas[i], sigmas[i + 1]).to(v.dtype)
     return x
+
+
+def dpmpp_multistep_loop(model_fn, x, sigmas, timesteps, order):
+    """FlowDPMSolverMultistepScheduler (algorithm dpmsolver++, solver_type midpoint, lower_order_final=True,
+    final_sigmas_type zero) for solver_order 1..3, float64 coefficient arithmetic restated from
+    MoRe4D/utils/fm_solvers.py: convert_model_output :385-388 (x0 = x - sigma v), first order :415-483,
+    second :486-594, third :596-677, order selection / lower-order rules :741-779.
+    sigmas has len(timesteps) + 1 entries (last 0).  Returns the list of samples after every step."""
+    import math
+    n = len(timesteps)
+    sig = [float(s) for s in sigmas]
+
+    def lam(s):
+        if s <= 0.0:
+            return math.inf
+        return -math.inf if s >= 1.0 else math.log(1.0 - s) - math.log(s)
+
+    ms, lower, traj = [], 0, []
+    x = x.float()
+    for i in range(n):
+        v = model_fn(x, timesteps[i])
+        ms.append(x - sig[i] * v)                       # data prediction
+        ms = ms[-3:]
+        final = i == n - 1                              # final_sigmas_type == "zero" => first order on the last step
+        second = i == n - 2 and n < 15
+        st, s0 = sig[i + 1], sig[i]
+        at = 1.0 - st
+        h = lam(st) - lam(s0)
+        e = math.expm1(-h) if math.isfinite(h) else -1.0        # exp(-h) - 1
+        if order == 1 or lower < 1 or final:
+            x = (st / s0) * x - (at * e) * ms[-1]
+        elif order == 2 or lower < 2 or second:
+            h0 = lam(s0) - lam(sig[i - 1])
+            r0 = h0 / h
+            d1 = (1.0 / r0) * (ms[-1] - ms[-2])
+            x = (st / s0) * x - (at * e) * ms[-1] - 0.5 * (at * e) * d1
+        else:
+            h0, h1 = lam(s0) - lam(sig[i - 1]), lam(sig[i - 1]) - lam(sig[i - 2])
+            r0, r1 = h0 / h, h1 / h
+            d10, d11 = (1.0 / r0) * (ms[-1] - ms[-2]), (1.0 / r1) * (ms[-2] - ms[-3])
+            d1 = d10 + (r0 / (r0 + r1)) * (d10 - d11)
+            d2 = (1.0 / (r0 + r1)) * (d10 - d11)
+            x = (st / s0) * x - (at * e) * ms[-1] + (at * (e / h + 1.0)) * d1 - (at * ((e + h) / h ** 2 - 0.5)) * d2
+        if lower < order:
+            lower += 1
+        traj.append(x)
+    return traj

@@ -310,7 +310,7 @@ def bilinear_cl(x, out_hw):
 
 # ------------------------------------------------------------------ training-step ops
 NAMES += ["transpose", "colsum", "scale_cast", "resid_gate", "add", "act_bwd_", "ln_modulate_bwd", "rmsnorm_rope_bwd_",
-          "attention_bwd", "sumsq", "adamw_"]
+          "attention_bwd", "sumsq", "adamw_", "lincomb"]
 
 
 def transpose(x, out=None):
@@ -442,6 +442,14 @@ def attention_bwd(q, k, v, o, d_o, lse, *, B, Lq, Lk, Lk_rows, heads, head_dim, 
     for dst, g, acc in ((dq, gq, accumulate_dq), (dk, gk, accumulate_dkv), (dv, gv, accumulate_dkv)):
         g = g.reshape(dst.shape)
         dst.copy_((dst.float() + g).to(dst.dtype) if acc else g.to(dst.dtype))
+
+
+def lincomb(terms, out=None):
+    res = sum(float(a) * x for a, x in terms)
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
 
 
 def sumsq(x, out):

@@ -319,6 +319,31 @@ def make_sched(ref):
              sampling_sigmas=sig)
 
 
+def toy_velocity(x, t):
+    """Deterministic stand-in for the DiT inside solver fixtures (smooth in x and t)."""
+    return 0.3 * x + 0.1 * torch.sin(3.0 * x) + (float(t) / 1000.0 - 0.5)
+
+
+def make_sched_multistep(ref):
+    """DPM-Solver++ multistep orders 2 and 3 of the in-tree flow solver (fm_solvers.py:486-677, step :706-797):
+    the reference scheduler driven by a toy velocity for 8 steps (< 15: the lower-order tail rules apply) and 20 steps."""
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(1, 16, 2, 4, 4, generator=g)
+    out["x0"] = x0
+    for order in (2, 3):
+        for steps in (8, 20):
+            sch = ref.fm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=order, shift=1.0)
+            sch.set_timesteps(sigmas=ref.fm.get_sampling_sigmas(steps, 5.0))
+            x = x0.clone()
+            traj = []
+            for t in sch.timesteps:
+                x = sch.step(toy_velocity(x, t), t, x, return_dict=False)[0]
+                traj.append(x.clone())
+            out[f"o{order}_s{steps}"] = torch.stack(traj)
+    npz_save("sched_multistep.npz", **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref = _ref_import.load_reference()
@@ -335,3 +360,4 @@ if __name__ == "__main__":
         make_vae(ref)
     if what in ("sched", "all"):
         make_sched(ref)
+        make_sched_multistep(ref)

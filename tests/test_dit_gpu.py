@@ -196,3 +196,23 @@ def test_rccl_gather_plumbing_world1():
         assert segs2[0].len == Ls and segs2[0].k.data_ptr() != k.data_ptr()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("order,steps", [(2, 8), (3, 20)])
+def test_multistep_solver_gpu(order, steps):
+    """m4d_lincomb + the order 2 / 3 DPM-Solver++ updates on the device against the reference scheduler's trajectory."""
+    from more4d_amd import ops
+    from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas
+    z = load_npz("sched_multistep.npz")
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(1000, generator=g) for _ in range(4)]
+    got = ops.lincomb([(0.5, xs[0].to(DEV)), (-2.0, xs[1].to(DEV)), (3.0, xs[2].to(DEV)), (0.25, xs[3].to(DEV))])
+    assert rel_err(got.cpu(), 0.5 * xs[0] - 2.0 * xs[1] + 3.0 * xs[2] + 0.25 * xs[3]) < 1e-6
+    sch = FlowDPMSolverMultistepScheduler(solver_order=order, shift=1.0)
+    sch.set_timesteps(sigmas=get_sampling_sigmas(steps, 5.0), device=DEV)
+    x, out = z["x0"].to(DEV), []
+    for t in sch.timesteps:
+        v = 0.3 * x + 0.1 * torch.sin(3.0 * x) + (float(t) / 1000.0 - 0.5)
+        x = sch.step(v, t, x, return_dict=False)[0]
+        out.append(x.clone())
+    assert rel_err(torch.stack(out).cpu(), z[f"o{order}_s{steps}"]) < 1e-5

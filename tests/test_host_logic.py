@@ -67,7 +67,40 @@ def test_scheduler_tables_match_reference():
     sch.set_timesteps(sigmas=get_sampling_sigmas(50, 5.0))
     assert torch.equal(sch.timesteps, z["timesteps"]) and torch.equal(sch.sigmas, z["sigmas"])
     with pytest.raises(NotImplementedError):
-        FlowDPMSolverMultistepScheduler(solver_order=2)
+        FlowDPMSolverMultistepScheduler(solver_order=4)
+    with pytest.raises(NotImplementedError):
+        FlowDPMSolverMultistepScheduler(algorithm_type="sde-dpmsolver++")
+
+
+def _toy_velocity(x, t):
+    return 0.3 * x + 0.1 * torch.sin(3.0 * x) + (float(t) / 1000.0 - 0.5)
+
+
+@pytest.mark.parametrize("order,steps", [(2, 8), (2, 20), (3, 8), (3, 20)])
+def test_multistep_solver_matches_reference(monkeypatch, order, steps):
+    """DPM-Solver++ orders 2 / 3 (fm_solvers.py:486-677, :741-779): oracle and product scheduler (torch stand-ins for
+    the kernels) against trajectories produced by the reference scheduler; the fused CFG entry point agrees with step()."""
+    from oracle import sched as osch
+    from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas
+    cpu_ops.install(monkeypatch)
+    z = load_npz("sched_multistep.npz")
+    ref = z[f"o{order}_s{steps}"]
+    ts, sigmas = osch.set_timesteps(osch.sampling_sigmas(steps, 5.0))
+    traj = osch.dpmpp_multistep_loop(_toy_velocity, z["x0"], sigmas, ts, order)
+    assert rel_err(torch.stack(traj), ref) < 2e-6
+    sch = FlowDPMSolverMultistepScheduler(solver_order=order, shift=1.0)
+    sch.set_timesteps(sigmas=get_sampling_sigmas(steps, 5.0))
+    x, out = z["x0"].clone(), []
+    for t in sch.timesteps:
+        x = sch.step(_toy_velocity(x, t), t, x, return_dict=False)[0]
+        out.append(x.clone())
+    assert rel_err(torch.stack(out), ref) < 2e-6
+    sch.set_timesteps(sigmas=get_sampling_sigmas(steps, 5.0))
+    lat = z["x0"].clone()
+    for i, t in enumerate(sch.timesteps):     # guidance g with v_u = v - d, v_c = v + (1/g - 1) d... use g = 1: v_c = v
+        v = _toy_velocity(lat, t)
+        sch.step_cfg_(lat, torch.stack([torch.zeros_like(v), v]), 1.0, i)
+    assert rel_err(lat, ref[-1]) < 2e-6
 
 
 def test_rope_tables_match_oracle():
