@@ -83,18 +83,23 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvArgs p) {
     const int Tl = p.Tin << p.tsplit;
 
     uint4 ra[4], rw[4];
-    auto gload = [&](int ktile) {
-        const int64_t k = (int64_t)ktile * KT + schunk * EPC;
-        const bool kin = k < p.K;
-        int dt = 0, dh = 0, dw = 0, c = 0;
-        if (kin) {
-            const int tap = (int)(k / p.Cin);
-            c = (int)(k - (int64_t)tap * p.Cin);
-            dt = tap / khw;
-            const int r2 = tap - dt * khw;
-            dh = r2 / p.kw;
-            dw = r2 - dh * p.kw;
+    // This thread always stages the same 16-byte chunk column: its K index advances by KT per tile, so (tap, channel)
+    // and the tap's (dt, dh, dw) are carried incrementally — the per-tile integer divisions of the first version cost more
+    // VALU time than the tile's MFMAs (gload is called with ktile = 0, 1, 2, ... in order).
+    int g_c = schunk * EPC, g_dt = 0, g_dh = 0, g_dw = 0;
+    int64_t g_k = schunk * EPC;
+    auto tap_norm = [&]() {
+        while (g_c >= p.Cin) {
+            g_c -= p.Cin;
+            if (++g_dw == p.kw) { g_dw = 0; if (++g_dh == p.kh) { g_dh = 0; ++g_dt; } }
         }
+    };
+    tap_norm();
+    auto gload = [&](int ktile) {
+        const bool kin = g_k < p.K;
+        const int dt = g_dt, dh = g_dh, dw = g_dw, c = g_c;
+        g_k += KT; g_c += KT;
+        tap_norm();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
