@@ -63,9 +63,9 @@ class FlowDPMSolverMultistepScheduler:
         self.num_train_timesteps = num_train_timesteps
         self.shift = shift
         alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
-        sig = 1.0 - alphas
+        sig = torch.from_numpy(1.0 - alphas).to(dtype=torch.float32)          # float32 like the reference (:178-184)
         sig = shift * sig / (1 + (shift - 1) * sig)
-        self.sigma_min, self.sigma_max = float(sig[-1]), float(sig[0])
+        self.sigma_min, self.sigma_max = sig[-1].item(), sig[0].item()
         self.num_inference_steps = None
         self.timesteps = None
         self.sigmas = None

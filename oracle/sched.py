@@ -92,3 +92,73 @@ def dpmpp_multistep_loop(model_fn, x, sigmas, timesteps, order):
             lower += 1
         traj.append(x)
     return traj
+
+
+def unipc_loop(model_fn, x, sigmas, timesteps, order):
+    """FlowUniPCMultistepScheduler (predict_x0, solver_type bh2, lower_order_final, no disabled correctors), restated from
+    MoRe4D/utils/fm_solvers_unipc.py: step :655-739 (corrector first, then order selection, then predictor),
+    multistep_uni_p_bh_update :350-484, multistep_uni_c_bh_update :486-626.  float64 coefficients.
+    Returns the list of samples after every step."""
+    import math
+    n = len(timesteps)
+    sig = [float(s) for s in sigmas]
+
+    def lam(s):
+        if s <= 0.0:
+            return math.inf
+        return -math.inf if s >= 1.0 else math.log(1.0 - s) - math.log(s)
+
+    def coeffs(h, rks, n_rhos, simplified_half):
+        """(h_phi_1, B_h, rhos) for the bh2 update with `rks` (last one 1.0)."""
+        hh = -h
+        h_phi_1 = math.expm1(hh) if math.isfinite(hh) else -1.0
+        B_h = h_phi_1
+        K = len(rks)
+        h_phi_k = (h_phi_1 / hh - 1.0) if math.isfinite(hh) else -1.0
+        fact, R, b = 1, [], []
+        for i in range(1, K + 1):
+            R.append([rk ** (i - 1) for rk in rks])
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = (h_phi_k / hh - 1.0 / fact) if math.isfinite(hh) else -1.0 / fact
+        if simplified_half:
+            return h_phi_1, B_h, [0.5]
+        R, b = np.array(R, dtype=np.float64)[:n_rhos, :n_rhos], np.array(b, dtype=np.float64)[:n_rhos]
+        return h_phi_1, B_h, list(np.linalg.solve(R, b)) if n_rhos else []
+
+    ms, lower, last_sample, this_order, traj = [], 0, None, 1, []
+    x = x.float()
+    for i in range(n):
+        m_t = x - sig[i] * model_fn(x, timesteps[i])                       # convert_model_output (x0 prediction)
+        if i > 0 and last_sample is not None:                              # ---- corrector (UniC), order = this_order
+            st, s0 = sig[i], sig[i - 1]
+            h = lam(st) - lam(s0)
+            m0 = ms[-1]
+            rks, d1s = [], []
+            for j in range(1, this_order):
+                rk = (lam(sig[i - (j + 1)]) - lam(s0)) / h
+                rks.append(rk)
+                d1s.append((ms[-(j + 1)] - m0) / rk)
+            rks.append(1.0)
+            h_phi_1, B_h, rhos = coeffs(h, rks, len(rks), this_order == 1)
+            corr = sum(r * d for r, d in zip(rhos[:-1], d1s)) if d1s else 0
+            x = (st / s0) * last_sample - ((1.0 - st) * h_phi_1) * m0 - ((1.0 - st) * B_h) * (corr + rhos[-1] * (m_t - m0))
+        ms = (ms + [m_t])[-order:]
+        this_order = min(order, n - i, lower + 1)                          # lower_order_final + warm-up
+        last_sample = x
+        st, s0 = sig[i + 1], sig[i]                                        # ---- predictor (UniP)
+        h = lam(st) - lam(s0)
+        m0 = ms[-1]
+        rks, d1s = [], []
+        for j in range(1, this_order):
+            rk = (lam(sig[i - j]) - lam(s0)) / h
+            rks.append(rk)
+            d1s.append((ms[-(j + 1)] - m0) / rk)
+        rks.append(1.0)
+        h_phi_1, B_h, rhos = coeffs(h, rks, len(rks) - 1, this_order == 2)
+        pred = sum(r * d for r, d in zip(rhos, d1s)) if d1s else 0
+        x = (st / s0) * x - ((1.0 - st) * h_phi_1) * m0 - ((1.0 - st) * B_h) * pred
+        if lower < order:
+            lower += 1
+        traj.append(x)
+    return traj

@@ -344,6 +344,38 @@ def make_sched_multistep(ref):
     npz_save("sched_multistep.npz", **out)
 
 
+def make_sched_unipc(ref):
+    """FlowUniPCMultistepScheduler (fm_solvers_unipc.py: predictor :350-484, corrector :486-626, step :655-739), bh2,
+    predict_x0, orders 2 and 3, driven by the toy velocity; sigma tables both from get_sampling_sigmas (first sigma
+    exactly 1) and from the scheduler's own linspace (set_timesteps(num_inference_steps))."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_unipc", "/root/reference/MoRe4D/utils/fm_solvers_unipc.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(1, 16, 2, 4, 4, generator=g)
+    out["x0"] = x0
+    for order in (2, 3):
+        # (with get_sampling_sigmas the first sigma is exactly 1 => lambda = -inf and the reference itself returns NaN from
+        #  its order >= 2 corrector; UniPC is therefore pinned on the scheduler's own linspace tables)
+        for steps, mode in ((12, "lin"), (30, "lin")):
+            sch = mod.FlowUniPCMultistepScheduler(num_train_timesteps=1000, solver_order=order, shift=1.0)
+            if mode == "sig":
+                sch.set_timesteps(sigmas=ref.fm.get_sampling_sigmas(steps, 5.0))
+            else:
+                sch.set_timesteps(steps, shift=5.0)
+            x = x0.clone()
+            traj = []
+            for t in sch.timesteps:
+                x = sch.step(toy_velocity(x, t), t, x, return_dict=False)[0]
+                traj.append(x.clone())
+            out[f"o{order}_{mode}{steps}"] = torch.stack(traj)
+            out[f"o{order}_{mode}{steps}_sigmas"] = sch.sigmas
+            out[f"o{order}_{mode}{steps}_timesteps"] = sch.timesteps
+    npz_save("sched_unipc.npz", **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref = _ref_import.load_reference()
@@ -361,3 +393,4 @@ if __name__ == "__main__":
     if what in ("sched", "all"):
         make_sched(ref)
         make_sched_multistep(ref)
+        make_sched_unipc(ref)

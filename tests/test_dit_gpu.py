@@ -216,3 +216,16 @@ def test_multistep_solver_gpu(order, steps):
         x = sch.step(v, t, x, return_dict=False)[0]
         out.append(x.clone())
     assert rel_err(torch.stack(out).cpu(), z[f"o{order}_s{steps}"]) < 1e-5
+
+
+def test_unipc_solver_gpu():
+    from more4d_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    z = load_npz("sched_unipc.npz")
+    sch = FlowUniPCMultistepScheduler(solver_order=3, shift=1.0)
+    sch.set_timesteps(30, device=DEV, shift=5.0)
+    x, out = z["x0"].to(DEV), []
+    for t in sch.timesteps:
+        v = 0.3 * x + 0.1 * torch.sin(3.0 * x) + (float(t) / 1000.0 - 0.5)
+        x = sch.step(v, t, x, return_dict=False)[0]
+        out.append(x.clone())
+    assert rel_err(torch.stack(out).cpu(), z["o3_lin30"]) < 1e-5

@@ -230,3 +230,31 @@ def test_teacache_and_guidance_adapter_host_logic(monkeypatch):
         ref = g.feature_adapter(feats.view(2, 14, 14, 768).permute(0, 3, 1, 2))
         ref = F.interpolate(ref, size=(6, 9), mode="bilinear", align_corners=False).flatten(2).transpose(1, 2)
     assert rel_err(mine, ref) < 1e-5
+
+
+@pytest.mark.parametrize("order,steps", [(2, 12), (2, 30), (3, 12), (3, 30)])
+def test_unipc_solver_matches_reference(monkeypatch, order, steps):
+    """UniPC (fm_solvers_unipc.py: UniC :486-626, UniP :350-484, step :655-739): oracle and product scheduler against
+    trajectories of the reference scheduler on its own sigma table; a table starting at exactly sigma = 1 is refused."""
+    from oracle import sched as osch
+    from more4d_amd.utils.fm_solvers import get_sampling_sigmas
+    from more4d_amd.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    cpu_ops.install(monkeypatch)
+    z = load_npz("sched_unipc.npz")
+    key = f"o{order}_lin{steps}"
+    traj = osch.unipc_loop(_toy_velocity, z["x0"], z[key + "_sigmas"], z[key + "_timesteps"], order)
+    assert rel_err(torch.stack(traj), z[key]) < 2e-6
+    sch = FlowUniPCMultistepScheduler(solver_order=order, shift=1.0)
+    sch.set_timesteps(steps, shift=5.0)
+    assert torch.equal(sch.sigmas, z[key + "_sigmas"]) and torch.equal(sch.timesteps, z[key + "_timesteps"])
+    x, out = z["x0"].clone(), []
+    for t in sch.timesteps:
+        x = sch.step(_toy_velocity(x, t), t, x, return_dict=False)[0]
+        out.append(x.clone())
+    assert rel_err(torch.stack(out), z[key]) < 2e-6
+    if order == 3 and steps == 12:
+        sch.set_timesteps(sigmas=get_sampling_sigmas(8, 5.0))
+        x = z["x0"].clone()
+        with pytest.raises(FloatingPointError):
+            for t in sch.timesteps:
+                x = sch.step(_toy_velocity(x, t), t, x, return_dict=False)[0]
