@@ -258,3 +258,29 @@ def test_unipc_solver_matches_reference(monkeypatch, order, steps):
         with pytest.raises(FloatingPointError):
             for t in sch.timesteps:
                 x = sch.step(_toy_velocity(x, t), t, x, return_dict=False)[0]
+
+
+def test_flow_match_euler_restatement(monkeypatch):
+    """The diffusers default sampler is restated (parity unpinned): its tables follow the documented formula and its step
+    is the Euler update of the pinned in-tree order-1 solver."""
+    import numpy as np
+    from more4d_amd.utils.flow_match_euler import FlowMatchEulerDiscreteScheduler
+    from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler
+    cpu_ops.install(monkeypatch)
+    s = FlowMatchEulerDiscreteScheduler(num_train_timesteps=1000, shift=5.0)
+    s.set_timesteps(50)
+    raw = np.linspace(s.sigma_max * 1000, s.sigma_min * 1000, 50) / 1000
+    want = 5.0 * raw / (1 + 4.0 * raw)
+    assert np.allclose(s.sigmas[:-1].numpy(), want, rtol=1e-6) and float(s.sigmas[-1]) == 0.0
+    assert s.timesteps.dtype == torch.float32 and np.allclose(s.timesteps.numpy(), want * 1000, rtol=1e-6)
+    z = load_npz("sched.npz")
+    d = FlowDPMSolverMultistepScheduler(solver_order=1, shift=1.0)
+    d.set_timesteps(sigmas=z["sampling_sigmas"].numpy())
+    e = FlowMatchEulerDiscreteScheduler(shift=1.0)
+    e.set_timesteps(sigmas=z["sampling_sigmas"].numpy())
+    xa = d.step(z["v"], d.timesteps[0], z["x"], return_dict=False)[0]
+    xb = e.step(z["v"], e.timesteps[0], z["x"], return_dict=False)[0]
+    assert rel_err(xb, z["x1"]) < 1e-6 and rel_err(xa, xb) < 1e-6
+    noisy = e.scale_noise(z["x"], e.timesteps[3:4], z["v"])
+    sg = float(e.sigmas[3])
+    assert torch.allclose(noisy, sg * z["v"] + (1 - sg) * z["x"], atol=1e-6)
