@@ -13,6 +13,8 @@
 // wan_vae.py :138-141).  Fused into the epilogue: bias and the residual / shortcut add (:224).
 // Tiling, LDS image, fragment convention and epilogue lane layout are those of gemm_bt_kernel (gemm.hip): 128x128
 // tile, 4 waves, K-tile of 128 bytes per row, register-staged copies one tile ahead, XOR-swizzled LDS rows.
+#include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "more4d_hip.h"
 
@@ -204,6 +206,153 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvArgs p) {
     }
 }
 
+// ============================================================================ production path: bf16, stride 1, plain taps
+// 256(pixels) x 128(channels) tile, 8 waves (4 x 2, wave tile 64 x 64), K-tile 64, two 48 KiB LDS stages filled by
+// global->LDS DMA with PER-LANE source addresses: a lane's 16-byte chunk is 8 channels of one tap of one pixel, or — for
+// taps that fall outside the input, rows past M and K past the end — a 16-byte read of a zero page, so padding costs no
+// branches in the consumer.  Per K-tile a lane only advances its (tap, channel) position and looks the tap up in a
+// per-row 27-bit validity mask computed once (the first version recomputed and bounds-checked every coordinate per tile:
+// more VALU time than the tile's MFMAs).  Covers the ResidualBlock / attention / shortcut convolutions (about 85 % of the
+// VAE FLOPs); strided, up-sampling and time-split convolutions keep conv_cl_kernel.
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+__device__ __attribute__((aligned(256))) char m4d_zero_page[256];
+extern __shared__ __attribute__((aligned(16))) char conv_dyn_smem[];
+
+__global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
+    typedef bf16_t T;
+    constexpr int BM2 = 256, BN2 = 128, STAGE2 = (BM2 + BN2) * ROWB;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM2, n0 = (int64_t)tn * BN2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- DMA lane roles: one instruction = 8 rows x 8 chunks; A instruction i covers rows i*64 + wave*8 + lrow ----
+    const int lrow = lane >> 3, pc = lane & 7;
+    const int rsub = wave * 8 + lrow;                       // row inside a 64-row group
+    const int lc = pc ^ ((rsub >> 1) & 7);                  // logical chunk landing in physical chunk pc (same for all groups)
+    int rowoff[4];                                          // byte offset of (ti0, hi0, wi0) from x (may be "negative")
+    unsigned vmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + i * 64 + rsub;
+        vmask[i] = 0;
+        rowoff[i] = 0;
+        if (m < p.M) {
+            const int wo = (int)(m % p.Wo);
+            const int64_t r = m / p.Wo;
+            const int ho = (int)(r % p.Ho), to = (int)(r / p.Ho);
+            const int ti0 = to - p.pad_t, hi0 = ho - p.pad_h, wi0 = wo - p.pad_w;
+            rowoff[i] = (int)((((int64_t)ti0 * p.Hin + hi0) * p.Win + wi0) * p.xs * 2);
+            // separable validity: bits 0-7 dt, 8-15 dh, 16-23 dw (kernel extents <= 8)
+            for (int d = 0; d < p.kt; ++d) if (ti0 + d >= 0 && ti0 + d < p.Tin) vmask[i] |= 1u << d;
+            for (int d = 0; d < p.kh; ++d) if (hi0 + d >= 0 && hi0 + d < p.Hin) vmask[i] |= 1u << (8 + d);
+            for (int d = 0; d < p.kw; ++d) if (wi0 + d >= 0 && wi0 + d < p.Win) vmask[i] |= 1u << (16 + d);
+        }
+    }
+    const char* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t n = min(n0 + i * 64 + rsub, (int64_t)p.Cout - 1);
+        wrow[i] = (const char*)p.w + n * p.K * 2;
+    }
+    // K position of this lane's chunk: channel c inside tap (dt, dh, dw); advances by 64 per K-tile
+    int g_c = lc * 8, g_dt = 0, g_dh = 0, g_dw = 0;
+    int64_t g_k = lc * 8;
+    auto tap_norm = [&]() {
+        while (g_c >= p.Cin) {
+            g_c -= p.Cin;
+            if (++g_dw == p.kw) { g_dw = 0; if (++g_dh == p.kh) { g_dh = 0; ++g_dt; } }
+        }
+    };
+    tap_norm();
+    const char* zero = m4d_zero_page;
+    auto issue = [&](int stage) {
+        char* sA = conv_dyn_smem + stage * STAGE2;
+        char* sW = sA + BM2 * ROWB;
+        const bool kin = g_k < p.K;
+        const int tapoff = (int)((((int64_t)g_dt * p.Hin + g_dh) * p.Win + g_dw) * p.xs * 2) + g_c * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = kin && (((vmask[i] >> g_dt) & (vmask[i] >> (8 + g_dh)) & (vmask[i] >> (16 + g_dw))) & 1u);
+            const char* src = ok ? (const char*)p.x + (int64_t)(rowoff[i] + tapoff) : zero;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(sA + (i * 8 + wave) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* src = kin ? wrow[i] + g_k * 2 : zero;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(sW + (i * 8 + wave) * 1024), 16, 0, 0);
+        }
+        g_k += 64; g_c += 64;
+        tap_norm();
+    };
+
+    f32x16 acc[2][2];   // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (int)((p.K + 63) / 64);
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue(stage ^ 1);
+        const char* sA = conv_dyn_smem + stage * STAGE2;
+        const char* sW = sA + BM2 * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fw[2];
+            const int c0 = kk * 2 + hi;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * 64 + i * 32 + li, c0));
+                fw[i] = *reinterpret_cast<const bf16x8*>(sW + lds_off(wn * 64 + i * 32 + li, c0));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) mma32(fw[ni], fa[mi], acc[ni][mi]);
+        }
+    }
+
+    const T* bias = (const T*)p.bias;
+    const T* resid = (const T*)p.resid;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int64_t nb = n0 + wn * 64 + ni * 32 + rq * 8 + hi * 4;
+                if (nb >= p.Cout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][rq * 4 + e];
+                if (bias) v += load4(bias + nb);
+                if (resid) {
+                    const f32x4 r = load4(resid + m * p.ldr + nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]) + r[e];
+                }
+                store4((T*)p.out + m * p.ldo + nb, v);
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
@@ -229,6 +378,43 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
     p.M = (int64_t)To * Ho * Wo;
     p.K = (int64_t)kt * kh * kw * Cin;
+    // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
+    const int64_t xbytes = (int64_t)Tin * Hin * Win * x_pixel_stride * 2;
+    static int conv_variant = -1;
+    if (conv_variant < 0) { const char* v = getenv("M4D_CONV_VARIANT"); conv_variant = v ? atoi(v) : 2; }
+    const bool v2_shape = conv_variant == 2 && dt == M4D_BF16 && st == 1 && sh == 1 && sw == 1 && !ups && !tsplit && kt <= 8 &&
+                          kh <= 8 && kw <= 8 && p.M >= 1024;
+    if (v2_shape && xbytes >= (1ll << 30) && kt == 1 && pad_t == 0 && To == Tin) {
+        // 2-D convolution over many frames (the adaptors: 49 x 480 x 832 x 128): frames are independent, so launch groups of
+        // frames whose input fits the kernel's 31-bit offsets
+        const int64_t frame_bytes = (int64_t)Hin * Win * x_pixel_stride * 2;
+        const int per = (int)std::max<int64_t>(1, ((1ll << 30) - 1) / frame_bytes);
+        for (int f0 = 0; f0 < Tin; f0 += per) {
+            const int nf = std::min(per, Tin - f0);
+            const int rc = m4d_conv_cl(dt, (const char*)x + (int64_t)f0 * frame_bytes, x_pixel_stride, w, bias,
+                                       resid ? (const char*)resid + (int64_t)f0 * Ho * Wo * resid_ld * 2 : nullptr, resid_ld,
+                                       (char*)out + (int64_t)f0 * Ho * Wo * out_ld * 2, out_ld, nf, Hin, Win, Cin, Cout, kt, kh, kw,
+                                       st, sh, sw, pad_t, pad_h, pad_w, nf, Ho, Wo, ups, tsplit, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    if (v2_shape && xbytes < (1ll << 30)) {
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute((const void*)conv_cl256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * ROWB) != hipSuccess) {
+                m4d_set_error("conv_cl: cannot enable 96 KiB LDS");
+                return -3;
+            }
+            configured = true;
+        }
+        p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (Cout + 127) / 128;
+        const int64_t nwg2 = (int64_t)p.tiles_m * p.tiles_n;
+        M4D_CHECK_ARG(nwg2 < (1ll << 31), "conv_cl: too many tiles");
+        hipLaunchKernelGGL(conv_cl256_kernel, dim3((unsigned)nwg2), dim3(512), 2 * (256 + 128) * ROWB, (hipStream_t)stream, p);
+        M4D_CHECK_LAUNCH("conv_cl");
+        return 0;
+    }
     p.tiles_m = (int)((p.M + BM - 1) / BM); p.tiles_n = (Cout + BN - 1) / BN;
     const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
     M4D_CHECK_ARG(nwg < (1ll << 31), "conv_cl: too many tiles");

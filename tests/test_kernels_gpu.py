@@ -362,3 +362,26 @@ def test_attention_phased_kernel_segments_and_rescale():
     s = torch.einsum("bqhd,bkhd->bhqk", q(qq, dt), q(torch.cat(ks, 1), dt)) / D ** 0.5
     lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634
     assert float((lse.cpu() - lse_ref).abs().max()) < 5e-2
+
+
+@pytest.mark.parametrize("cin,cout,k,pad", [(96, 96, (3, 3, 3), (0, 1, 1)), (192, 384, (3, 3, 3), (0, 1, 1)),
+                                            (384, 384, (1, 1, 1), (0, 0, 0)), (128, 128, (1, 3, 3), (0, 1, 1))])
+def test_conv_cl_production_kernel(cin, cout, k, pad):
+    """conv_cl256_kernel (bf16, unit stride, M >= 1024: DMA gather with a zero page for the padding taps) against fp32 torch
+    on bf16-rounded operands: borders in H and W, the causal 2-frame tail in T, K not a multiple of 64, Cout not of 128."""
+    import torch.nn.functional as F
+    o = ops()
+    To, H, W = 4, 20, 24
+    Tin = To + k[0] - 1
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(Tin, H, W, cin, generator=g).bfloat16()
+    w = (torch.randn(cout, cin, *k, generator=g) * (cin * k[0] * k[1] * k[2]) ** -0.5).bfloat16()
+    b = torch.randn(cout, generator=g).bfloat16()
+    res = torch.randn(To * H * W, cout, generator=g).bfloat16()
+    ref = F.conv3d(x.float().permute(3, 0, 1, 2)[None], w.float(), b.float(), padding=pad)[0].permute(1, 2, 3, 0).reshape(-1, cout)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    out = o.conv_cl(x.to(DEV), wp.to(DEV), b.to(DEV), Tin=Tin, Hin=H, Win=W, Cin=cin, k=k, pad=pad, out_thw=(To, H, W))
+    assert rel_err(out.float().cpu(), ref) < BF16_TOL
+    out2 = o.conv_cl(x.to(DEV), wp.to(DEV), b.to(DEV), Tin=Tin, Hin=H, Win=W, Cin=cin, k=k, pad=pad, out_thw=(To, H, W),
+                     resid=res.to(DEV))
+    assert rel_err(out2.float().cpu(), ref.bfloat16().float() + res.float()) < BF16_TOL
