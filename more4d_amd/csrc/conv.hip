@@ -302,6 +302,14 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // per-lane LDS byte offsets of the first fragment row of each K = 16 step (the next 32 rows are +4096 B)
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)conv_dyn_smem;
+    unsigned aoff[4], woff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        aoff[kk] = lds_off(wm * 64 + li, kk * 2 + hi);
+        woff[kk] = BM2 * ROWB + lds_off(wn * 64 + li, kk * 2 + hi);
+    }
     const int nk = (int)((p.K + 63) / 64);
     issue(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -309,22 +317,33 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + 1 < nk) issue(stage ^ 1);
-        const char* sA = conv_dyn_smem + stage * STAGE2;
-        const char* sW = sA + BM2 * ROWB;
+        // fragment double buffer from inline asm with counted lgkmcnt (hipcc drains to 0 in front of every MFMA group otherwise)
+        const unsigned sb = lds_base + stage * STAGE2;
+        bf16x8 fa[2][2], fw[2][2];
+#define CV_LDFRAG(buf, kk)                                                                                           \
+        do {                                                                                                         \
+            const unsigned aa_ = sb + aoff[kk], aw_ = sb + woff[kk];                                                 \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fw[buf][0]) : "v"(aw_));                                       \
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fw[buf][1]) : "v"(aw_));                          \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[buf][0]) : "v"(aa_));                                       \
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[buf][1]) : "v"(aa_));                          \
+        } while (0)
+        CV_LDFRAG(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[2], fw[2];
-            const int c0 = kk * 2 + hi;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * 64 + i * 32 + li, c0));
-                fw[i] = *reinterpret_cast<const bf16x8*>(sW + lds_off(wn * 64 + i * 32 + li, c0));
-            }
+            if (kk == 0) { CV_LDFRAG(1, 1); }
+            else if (kk == 1) { CV_LDFRAG(0, 2); }
+            else if (kk == 2) { CV_LDFRAG(1, 3); }
+            if (kk < 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) mma32(fw[ni], fa[mi], acc[ni][mi]);
+                for (int mi = 0; mi < 2; ++mi) mma32(fw[kk & 1][ni], fa[kk & 1][mi], acc[ni][mi]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef CV_LDFRAG
     }
 
     const T* bias = (const T*)p.bias;
