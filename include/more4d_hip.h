@@ -267,6 +267,16 @@ int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* dy, float* 
                         const float* scale, int64_t mod_stride, const float* ln_w, float eps, float* dshift,
                         float* dscale, int64_t red_stride, m4d_stream stream);
 
+/* Backward of the spatial-guidance tail of m4d_ln_modulate (SpatialGuidanceModule.forward, wan_transformer4d.py:757-783:
+ * z = u*(1 + S*gate) + H*gate with u = LN(x)*(1+scale)+shift and (S | H) = g_ss[sample, l % g_period] for l < g_len).
+ *   dz T [B*rows_per_sample, C] holds dL/dz on entry and dL/du on return (rows l >= g_len are untouched: z = u there),
+ *   ready for m4d_ln_modulate_bwd;
+ *   ab float [B, g_period, 2C] = (sum_f dz*u | sum_f dz) over the rows f*g_period + pos < g_len of each position
+ *   (fully written).  dS = A*gate, dH = Bm*gate, dgate = sum_{b,pos} (A*S + Bm*H). */
+int m4d_guidance_bwd(const float* x, m4d_dtype dz_dt, void* dz, int B, int64_t rows_per_sample, int C, const float* shift,
+                     const float* scale, int64_t mod_stride, float eps, const float* g_ss, const float* g_gate,
+                     int64_t g_period, int64_t g_len, float* ab, m4d_stream stream);
+
 /* Backward of m4d_rmsnorm_rope, in place on the gradient: dy0/dy1 T [rows, C] (row stride ld_dy) hold dL/d(output) on
  * entry and dL/d(input) on return; x0/x1 are the PRE-norm inputs (row stride ld_x); dw0/dw1 float [C] accumulate the
  * WanRMSNorm weight gradients (atomic, caller initialises). */

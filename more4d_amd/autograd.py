@@ -128,6 +128,77 @@ class LayerNormFn(Function):
         return dx, None, None, d1, d2, None, None
 
 
+# ------------------------------------------------------------------ spatial-guidance feature adapter
+_BILINEAR_T = {}
+
+
+def _bilinear_matrix_t(hw, dtype, device):
+    """Transpose [196, Pp] (token axis zero-padded like _tpad) of the matrix of the 14x14 -> hw bilinear resize, obtained by
+    resizing the identity with the product's own kernel (so forward and backward use the same weights)."""
+    key = (tuple(hw), dtype, str(device))
+    m = _BILINEAR_T.get(key)
+    if m is None:
+        eye = torch.eye(196, device=device, dtype=torch.float32).view(1, 14, 14, 196)
+        m = _tpad(ops.bilinear_cl(eye, hw).view(hw[0] * hw[1], 196).to(dtype))      # [196, Pp]
+        _BILINEAR_T[key] = m
+    return m
+
+
+def _im2col3x3(x, B, D):
+    """x [B*196, D] channels-last 14x14 maps -> [B*196, 9*D] rows in the packed-weight order (kh, kw, c); data movement only."""
+    xp = torch.nn.functional.pad(x.view(B, 14, 14, D), (0, 0, 1, 1, 1, 1))
+    return torch.cat([xp[:, i:i + 14, j:j + 14] for i in range(3) for j in range(3)], dim=-1).reshape(B * 196, 9 * D)
+
+
+def _pack3x3(w, cdt):
+    return w.detach().to(cdt).permute(0, 2, 3, 1).contiguous().view(w.shape[0], -1)
+
+
+class GuidanceAdapterFn(Function):
+    """SiLU(bilinear(feature_adapter(patch))) -> T [B, h*w, 768]: Conv3x3 - SiLU - Conv3x3 on the 14x14 OmniMAE map, bilinear
+    resize to the token grid (reference wan_transformer4d.py:889-893, :1150-1152) and the SiLU every SpatialGuidanceModule
+    applies first (:746).  apply(patch [B,196,768], hw, w0, b0, w2, b2, cdt); the features themselves get no gradient
+    (the extractor is frozen, train_wan.py:952)."""
+
+    @staticmethod
+    def forward(ctx, patch, hw, w0, b0, w2, b2, cdt):
+        B, D = patch.shape[0], patch.shape[-1]
+        x0 = patch.detach().to(cdt).contiguous().view(B * 196, D)
+        kw = dict(Tin=B, Hin=14, Win=14, Cin=D, k=(1, 3, 3), pad=(0, 1, 1), out_thw=(B, 14, 14))
+        a1 = ops.conv_cl(x0, _pack3x3(w0, cdt), b0.detach().to(cdt).contiguous(), **kw)
+        s1 = ops.unary(a1, cdt, act=1)
+        a2 = ops.conv_cl(s1, _pack3x3(w2, cdt), b2.detach().to(cdt).contiguous(), **kw)
+        y = ops.bilinear_cl(a2.view(B, 14, 14, D), hw).view(B, hw[0] * hw[1], D)
+        ctx.save_for_backward(x0, a1, s1, y, w2)
+        ctx.meta = (B, D, tuple(hw), cdt, w0.dtype, w0.shape)
+        return ops.unary(y, cdt, act=1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, a1, s1, y, w2 = ctx.saved_tensors
+        B, D, hw, cdt, wdt, wshape = ctx.meta
+        P = hw[0] * hw[1]
+        d = dout.to(cdt).contiguous().clone().view(B * P, D)
+        ops.act_bwd_(d, y.view(B * P, D), 1)                         # last SiLU
+        mt = _bilinear_matrix_t(hw, cdt, d.device)                   # resize^T: [196, Pp] x [Pp, D]
+        da2 = torch.empty((B * 196, D), device=d.device, dtype=cdt)
+        for b in range(B):
+            ops.gemm_bt(mt, _tpad(d[b * P:(b + 1) * P]), out=da2[b * 196:(b + 1) * 196])
+        kw = dict(Tin=B, Hin=14, Win=14, Cin=D, k=(1, 3, 3), pad=(0, 1, 1), out_thw=(B, 14, 14))
+
+        def wgrad(dy, x):                                            # dW [Cout, kh, kw, Cin] -> reference layout [Cout, Cin, kh, kw]
+            dw = ops.gemm_bt(_tpad(dy), _tpad(_im2col3x3(x, B, D)))
+            return dw.view(D, 3, 3, D).permute(0, 3, 1, 2).to(wdt), ops.colsum(dy)[0].to(wdt)
+
+        dw2, db2 = wgrad(da2, s1)
+        # data gradient of a stride-1 pad-1 conv = the same conv with the taps flipped and in/out channels swapped
+        w2t = _pack3x3(w2.flip(2, 3).transpose(0, 1), cdt)
+        ds1 = ops.conv_cl(da2, w2t, None, **kw)
+        ops.act_bwd_(ds1, a1, 1)
+        dw0, db0 = wgrad(ds1, x0)
+        return None, None, dw0, db0, dw2, db2, None
+
+
 # ------------------------------------------------------------------ one DiT block: recompute + backward
 def _block_param_names(blk):
     return [n for n, _ in blk.named_parameters()]
@@ -137,7 +208,22 @@ STORE_KEYS = ("qkv_pre", "o", "lse1", "y1", "qc_pre", "yc", "pre", "y2")
 STORE_LITE = ("o", "lse1", "y2")     # best recompute time saved per stored byte: self-attention output + ffn_down output
 
 
-def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None, forward_only=False):
+def _guidance_site_bwd(x, dz, shift, scale, st, Lp, eps, g, mod, gfeat2, G, prefix):
+    """Gradients of one SpatialGuidanceModule application (reference :757-783) given dz = dL/d(guided LN output):
+    dz becomes dL/d(plain LN-modulate output) in place; fills G[prefix.gate / .spatial_guide.1.*]; returns the gradient
+    w.r.t. the SiLU'd guidance features [B*P, 768] (T)."""
+    B, C = x.shape[0], x.shape[-1]
+    T = gfeat2.dtype
+    ab = ops.guidance_bwd_(x, dz, B=B, rows_per_sample=Lp, shift=shift, scale=scale, mod_stride=st, eps=eps, **g).view(-1, 2 * C)
+    dg = ops.colsum(ab, g["g_ss"].view(-1, 2 * C))[0]                # sum (A*S | Bm*H)
+    G[prefix + ".gate"] = ops.add(dg[:C].contiguous(), dg[C:].contiguous())
+    dss = ops.scale_cast(ab, T, gate=torch.cat([g["g_gate"], g["g_gate"]]), gate_stride=0, rows_per_sample=ab.shape[0])
+    lin = mod.spatial_guide[1]
+    dfeat, G[prefix + ".spatial_guide.1.weight"], G[prefix + ".spatial_guide.1.bias"] = linear_bwd(gfeat2, lin.weight, dss)
+    return dfeat
+
+
+def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None, forward_only=False, guid=None):
     """Recompute WanAttentionBlock.run on x0 keeping the intermediates, then back-propagate `dres`
     (float32 [B, Lp, C], gradient w.r.t. the block output; overwritten with the gradient w.r.t. x0).
     Returns (de0 [B,6,C] float32, dtxt, dimg, {param name: grad}).
@@ -166,10 +252,16 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
 
     e = ops.add_bcast(e0, f32(blk.modulation))                      # [B,6,C]: shift1 scale1 gate1 shift2 scale2 gate2
     de = zeros(B, 6, C)
+    g1, g2, gfeat2 = {}, {}, None
+    if guid is not None and blk.spatial_guidance_self is not None:  # (SiLU'd features T [B, P, 768], period, length)
+        gfeat, period, glen = guid
+        gfeat2 = gfeat.reshape(-1, gfeat.shape[-1])
+        for gd, mod in ((g1, blk.spatial_guidance_self), (g2, blk.spatial_guidance_ffn)):
+            gd.update(g_ss=mod.table(gfeat, c.f32cache), g_gate=f32(mod.gate), g_period=period, g_len=glen)
     dres2 = dres.view(R, C) if dres is not None else None
 
     # ================= recompute (reference :659-684) =================
-    xn1 = ops.ln_modulate(x0, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=Lp, eps=eps).view(R, C)
+    xn1 = ops.ln_modulate(x0, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=Lp, eps=eps, **g1).view(R, C)
     qkv_pre = saved.get("qkv_pre")
     if qkv_pre is None:
         qkv_pre = torch.empty((R, 3 * C), device=dev, dtype=T)
@@ -221,7 +313,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     if yc is None:
         yc = ops.gemm_bt(oc, ca.o.weight, ca.o.bias)
     x2 = ops.resid_gate(x1, yc)
-    xn2 = ops.ln_modulate(x2, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=Lp, eps=eps).view(R, C)
+    xn2 = ops.ln_modulate(x2, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=Lp, eps=eps, **g2).view(R, C)
     pre = saved.get("pre")
     if pre is None:
         pre = ops.gemm_bt(xn2, blk.ffn[0].weight, blk.ffn[0].bias)
@@ -244,6 +336,10 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     del pre
     dxn2, G["ffn.0.weight"], G["ffn.0.bias"] = linear_bwd(xn2, blk.ffn[0].weight, dh)
     del dh
+    dgf = None
+    if g2:
+        dgf = _guidance_site_bwd(x2, dxn2, e[:, 3], e[:, 4], st, Lp, eps, g2, blk.spatial_guidance_ffn, gfeat2, G,
+                                 "spatial_guidance_ffn")
     ops.ln_modulate_bwd(x2, dxn2, dres, B=B, rows_per_sample=Lp, scale=e[:, 4], mod_stride=st, eps=eps,
                         dshift=de[:, 3], dscale=de[:, 4], red_stride=st)
     # ---- cross attention: x2 = x1 + yc
@@ -294,14 +390,20 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     for j, nm in enumerate(("q", "k", "v")):
         G[f"self_attn.{nm}.weight"] = dwqkv[j * C:(j + 1) * C]
         G[f"self_attn.{nm}.bias"] = dbqkv[j * C:(j + 1) * C]
+    if g1:
+        dgf = ops.add(dgf, _guidance_site_bwd(x0, dxn1, e[:, 0], e[:, 1], st, Lp, eps, g1, blk.spatial_guidance_self, gfeat2,
+                                              G, "spatial_guidance_self"))
     ops.ln_modulate_bwd(x0, dxn1, dres, B=B, rows_per_sample=Lp, scale=e[:, 1], mod_stride=st, eps=eps,
                         dshift=de[:, 0], dscale=de[:, 1], red_stride=st)
     G["modulation"] = ops.colsum(de.view(B, 6 * C))[0].view(1, 6, C)
+    if guid is not None:
+        return de, dctx.get("txt"), dctx.get("img"), G, (dgf.view(guid[0].shape) if dgf is not None else None)
     return de, dctx.get("txt"), dctx.get("img"), G
 
 
 class BlockFn(Function):
-    """WanAttentionBlock on the tape.  apply(x, e0, txt, img, blk, c, txt_len, img_len, store, *params).
+    """WanAttentionBlock on the tape.  apply(x, e0, txt, img, gfeat, blk, c, txt_len, img_len, store, gmeta, *params);
+    gfeat = SiLU'd spatial-guidance features T [B, P, 768] (None without guidance), gmeta = (period, length).
 
     store=0: classic per-block gradient checkpointing (keep the block input, recompute everything in backward).
     store=2: the forward additionally keeps the outputs of the six big GEMMs and of the self-attention (STORE_KEYS,
@@ -310,37 +412,42 @@ class BlockFn(Function):
     best recompute time per byte).  `WanTransformer4DModel.activation_budget_gb` decides how many blocks get which."""
 
     @staticmethod
-    def forward(ctx, x, e0, txt, img, blk, c, txt_len, img_len, store, *params):
+    def forward(ctx, x, e0, txt, img, gfeat, blk, c, txt_len, img_len, store, gmeta, *params):
         from .models.wan_transformer4d import ContextCache
         if c.sp is not None and c.sp.world_size > 1:
             raise NotImplementedError("training uses data parallelism; sequence parallelism is the inference path")
         stash = None
+        guid = (gfeat.detach(), gmeta[0], gmeta[1]) if gfeat is not None else None
         if store:   # 2: every GEMM / attention output, 1: STORE_LITE only
             out, stash = block_backward(blk, x.detach(), e0.detach().contiguous(), c, txt.detach(), txt_len,
-                                        img.detach() if img is not None else None, img_len, None, forward_only=True)
+                                        img.detach() if img is not None else None, img_len, None, forward_only=True,
+                                        guid=guid)
             if store == 1:
                 stash = {k: stash[k] for k in STORE_LITE}
         else:
             out = x.detach().clone()
             cc = ContextCache()
             cc.txt, cc.txt_len, cc.img, cc.img_len = txt.detach(), txt_len, (img.detach() if img is not None else None), img_len
-            blk.run(out, e0.detach().contiguous(), c, cc, 0, None)
-        ctx.save_for_backward(x, e0, txt, img)
-        ctx.blk, ctx.c, ctx.lens, ctx.stash = blk, c, (txt_len, img_len), stash
+            blk.run(out, e0.detach().contiguous(), c, cc, 0, guid)
+        ctx.save_for_backward(x, e0, txt, img, gfeat)
+        ctx.blk, ctx.c, ctx.lens, ctx.stash, ctx.gmeta = blk, c, (txt_len, img_len), stash, gmeta
         ctx.names = _block_param_names(blk)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, e0, txt, img = ctx.saved_tensors
+        x, e0, txt, img, gfeat = ctx.saved_tensors
         blk = ctx.blk
         dres = dout.contiguous().clone()
         stash, ctx.stash = ctx.stash, None
-        de, dtxt, dimg, G = block_backward(blk, x.detach(), e0.detach().contiguous(), ctx.c, txt.detach(), ctx.lens[0],
-                                           img.detach() if img is not None else None, ctx.lens[1], dres, saved=stash)
+        guid = (gfeat.detach(), ctx.gmeta[0], ctx.gmeta[1]) if gfeat is not None else None
+        res = block_backward(blk, x.detach(), e0.detach().contiguous(), ctx.c, txt.detach(), ctx.lens[0],
+                             img.detach() if img is not None else None, ctx.lens[1], dres, saved=stash, guid=guid)
+        de, dtxt, dimg, G = res[:4]
+        dgf = res[4] if guid is not None else None
         del stash
         grads = []
         for name, p in zip(ctx.names, blk.parameters()):
             g = G.get(name)
             grads.append(None if g is None else g.to(p.dtype).view(p.shape))
-        return (dres, de, dtxt, dimg, None, None, None, None, None, *grads)
+        return (dres, de, dtxt, dimg, dgf, None, None, None, None, None, None, *grads)

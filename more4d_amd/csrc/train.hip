@@ -260,6 +260,88 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
     }
 }
 
+// ------------------------------------------------------------------ spatial-guidance backward (wan_transformer4d.py:781)
+// forward (m4d_ln_modulate with g_ss): z = u * (1 + S*g) + H*g,  u = LN(x) * (1 + scale) + shift,  (S | H) = g_ss[sample,
+// l % period] for l < g_len.  Given dz this kernel rewrites it IN PLACE to du = dz * (1 + S*g) (the gradient the plain
+// LayerNorm backward then takes) and writes, per spatial position, A = sum_f dz*u and Bm = sum_f dz over the frames f that
+// share the position: dS = A*g, dH = Bm*g, dgate = sum (A*S + Bm*H) are cheap host-side combinations of (A | Bm).
+// One workgroup per (position, sample): it owns every row of its position, so no atomics.
+struct GuidBwdArgs {
+    const float* x; void* dz; const float *shift, *scale, *ss, *gate; float* ab;
+    int64_t rows_per_sample, mod_stride, period, glen;
+    int C; float eps;
+};
+
+M4D_DEV float block_sum256(float v, float* lds4) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+template <typename TD, int MAXV>
+__global__ __launch_bounds__(256) void guid_bwd_kernel(GuidBwdArgs p) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int64_t pos = blockIdx.x, sample = blockIdx.y;
+    const int C = p.C, nv = C >> 2;
+    const float* sh = p.shift + sample * p.mod_stride;
+    const float* sc = p.scale + sample * p.mod_stride;
+    const float* ssr = p.ss + (sample * p.period + pos) * 2 * C;
+    f32x4 A[MAXV], Bm[MAXV], m[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        A[i] = f32x4{0.f, 0.f, 0.f, 0.f}; Bm[i] = A[i]; m[i] = A[i];
+        const int c4 = tid + i * 256;
+        if (c4 < nv) m[i] = 1.f + load4(ssr + c4 * 4) * load4(p.gate + c4 * 4);
+    }
+    for (int64_t l = pos; l < p.glen; l += p.period) {
+        const int64_t row = sample * p.rows_per_sample + l;
+        const float* xr = p.x + row * C;
+        TD* dr = (TD*)p.dz + row * C;
+        f32x4 v[MAXV], g[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = tid + i * 256;
+            if (c4 < nv) {
+                v[i] = load4(xr + c4 * 4);
+                g[i] = load4(dr + c4 * 4);
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+        }
+        const float mean = block_sum256(s, red) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = tid + i * 256;
+            if (c4 < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(block_sum256(q, red) / C + p.eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c4 = tid + i * 256;
+            if (c4 < nv) {
+                const int c = c4 * 4;
+                const f32x4 u = (v[i] - mean) * rstd * (1.f + load4(sc + c)) + load4(sh + c);
+                A[i] += g[i] * u;
+                Bm[i] += g[i];
+                store4(dr + c, g[i] * m[i]);
+            }
+        }
+    }
+    float* abr = p.ab + (sample * p.period + pos) * 2 * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c4 = tid + i * 256;
+        if (c4 < nv) { store4(abr + c4 * 4, A[i]); store4(abr + C + c4 * 4, Bm[i]); }
+    }
+}
+
 // ------------------------------------------------------------------ RMSNorm(+RoPE) backward, in place on dy
 // forward (m4d_rmsnorm_rope): y = rot(xhat * w), xhat = x * rsqrt(mean(x^2) + eps)
 //   g = rot^T(dy);  dw[c] += g * xhat;  dx = rstd * (g*w - xhat * mean(g*w*xhat))
@@ -489,6 +571,26 @@ extern "C" int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* 
     else { if (bf) LNB(bf16_t, 32); else LNB(float, 32); }
 #undef LNB
     M4D_CHECK_LAUNCH("ln_modulate_bwd");
+    return 0;
+}
+
+extern "C" int m4d_guidance_bwd(const float* x, m4d_dtype dz_dt, void* dz, int B, int64_t rows_per_sample, int C,
+                                const float* shift, const float* scale, int64_t mod_stride, float eps, const float* g_ss,
+                                const float* g_gate, int64_t g_period, int64_t g_len, float* ab, m4d_stream stream) {
+    M4D_CHECK_ARG(DT_OK(dz_dt), "guidance_bwd: bad dtype");
+    M4D_CHECK_ARG(x && dz && shift && scale && g_ss && g_gate && ab && B > 0 && rows_per_sample > 0, "guidance_bwd: bad arguments");
+    M4D_CHECK_ARG(C % 4 == 0 && C <= 8192, "guidance_bwd: C=%d must be a multiple of 4 and <= 8192", C);
+    M4D_CHECK_ARG(g_period > 0 && g_len >= 0 && g_len <= rows_per_sample, "guidance_bwd: bad period / length");
+    GuidBwdArgs p{x, dz, shift, scale, g_ss, g_gate, ab, rows_per_sample, mod_stride, g_period, g_len, C, eps};
+    dim3 grid((unsigned)g_period, (unsigned)B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define GDB(TD, MV) hipLaunchKernelGGL((guid_bwd_kernel<TD, MV>), grid, block, 0, st, p)
+    const bool bf = dz_dt == M4D_BF16;
+    if (C <= 2048) { if (bf) GDB(bf16_t, 2); else GDB(float, 2); }
+    else if (C <= 5120) { if (bf) GDB(bf16_t, 5); else GDB(float, 5); }
+    else { if (bf) GDB(bf16_t, 8); else GDB(float, 8); }
+#undef GDB
+    M4D_CHECK_LAUNCH("guidance_bwd");
     return 0;
 }
 

@@ -252,7 +252,8 @@ class SpatialGuidanceModule(nn.Module):
     def table(self, feats_silu, f32cache):
         """feats_silu: T [B, P, 768] (SiLU already applied) -> float32 [B, P, 2*dim] = (scale | shift)."""
         lin = self.spatial_guide[1]
-        return ops.gemm_bt(feats_silu, lin.weight, lin.bias, epilogue=EPI_STORE_F32)
+        B, P, D = feats_silu.shape
+        return ops.gemm_bt(feats_silu.reshape(B * P, D), lin.weight, lin.bias, epilogue=EPI_STORE_F32).view(B, P, -1)
 
 
 class WanAttentionBlock(nn.Module):
@@ -717,14 +718,12 @@ class WanTransformer4DModel(nn.Module):
         """Differentiable forward for `train_wan.py:1939-1951` (same arguments, same result as `forward`): every node
         is a `more4d_amd.autograd` Function whose forward AND backward run in the HIP kernels; one recomputing node per
         block (the reference trains with gradient checkpointing, :1273-1291).  Data parallel only."""
-        from ..autograd import ActFn, BlockFn, LayerNormFn, LinearFn
+        from ..autograd import ActFn, BlockFn, GuidanceAdapterFn, LayerNormFn, LinearFn
         from ..ops import ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU
         if self.sp_world_size > 1:
             raise NotImplementedError("training is data parallel (DDP); sequence parallelism is the inference path")
         if self.teacache is not None:
             raise NotImplementedError("TeaCache is an inference-time approximation")
-        if first_frame_features is not None and self.use_omnimae_guidance:
-            raise NotImplementedError("spatial-guidance gradients are not built yet (DESIGN.md, out of scope this round)")
         if isinstance(context, ContextCache):
             raise ValueError("training needs the raw text embeddings (the context projections are trainable)")
         if t.dim() != 1:
@@ -797,9 +796,21 @@ class WanTransformer4DModel(nn.Module):
         n_full = int(min(n_lite, max(0.0, budget - n_lite * lite) // max(full - lite, 1))) if n_lite == nb else 0
         self.last_stored_blocks = n_lite
         self.last_full_blocks = n_full
+        # ---- spatial guidance (:1126-1156): SiLU'd [B, h*w, 768] table shared by every block, T-periodic over the tokens
+        gfeat, gmeta = None, None
+        if self.use_omnimae_guidance and first_frame_features is not None:
+            patch, cls = first_frame_features
+            if not self.use_cls_token and patch.dim() == 3 and patch.shape[1] == 196 and hasattr(self, "feature_adapter"):
+                fa = self.feature_adapter
+                gfeat = GuidanceAdapterFn.apply(patch.to(dev), (h, w), fa[0].weight, fa[0].bias, fa[2].weight, fa[2].bias, T)
+                gmeta = (h * w, (x.shape[2] // pt) * h * w)
+            else:
+                gfeat, period, glen = self._guidance_tables(first_frame_features, (h, w), x.shape[2] // pt)
+                gmeta = (period, glen)
         for i, blk in enumerate(self.blocks):
             store = 2 if i < n_full else (1 if i < n_lite else 0)
-            xres = BlockFn.apply(xres, e0, ctx_txt, ctx_img, blk, c, self.text_len, img_len, store, *blk.parameters())
+            xres = BlockFn.apply(xres, e0, ctx_txt, ctx_img, gfeat, blk, c, self.text_len, img_len, store, gmeta,
+                                 *blk.parameters())
         # ---- head (:708-721) + unpatchify (:1343-1366)
         m = e.view(B, 1, C) + self.head.modulation.float()
         xn = LayerNormFn.apply(xres, None, None, m[:, 0], m[:, 1], self.head.eps, T)

@@ -543,6 +543,20 @@ def act_bwd_(dy, pre, act):
     return dy
 
 
+def guidance_bwd_(x, dz, *, B, rows_per_sample, shift, scale, mod_stride, g_ss, g_gate, g_period, g_len, eps=1e-6):
+    """Spatial-guidance tail of ln_modulate, backward: dz (T, in place) becomes the gradient w.r.t. the un-guided
+    LN-modulate output; returns float32 [B, g_period, 2C] = (sum_f dz*u | sum_f dz) per spatial position."""
+    _dev(x, dz, shift, scale, g_ss, g_gate)
+    C = x.shape[-1]
+    if not dz.is_contiguous() or not x.is_contiguous():
+        raise ValueError("guidance_bwd_: contiguous tensors")
+    ab = torch.empty((B, g_period, 2 * C), device=x.device, dtype=torch.float32)
+    check(_lib.load().m4d_guidance_bwd(_ptr(x), dt_code(dz.dtype), _ptr(dz), B, rows_per_sample, C, _ptr(shift), _ptr(scale),
+                                       mod_stride, eps, _ptr(g_ss), _ptr(g_gate), g_period, g_len, _ptr(ab), _stream()),
+          "m4d_guidance_bwd")
+    return ab
+
+
 def ln_modulate_bwd(x, dy, dx, *, B, rows_per_sample, scale=None, mod_stride=0, ln_w=None, eps=1e-6, dshift=None,
                     dscale=None, red_stride=0):
     """dx (float32, accumulated in place) += LayerNorm-input gradient; dshift/dscale accumulate sum(dy), sum(dy*xhat)."""

@@ -205,6 +205,19 @@ def spatial_guidance(sd, p, x, feats, cls, use_cls_token):
     return x * (1 + scale * g) + shift * g
 
 
+def adapt_guidance_features(sd, patch, hw, latent_T):
+    """OmniMAE patch features [B,196,768] -> per-token guidance features [B, latent_T*h*w, 768] (:1147-1154):
+    view as a 14x14 map, feature_adapter = Conv3x3 - SiLU - Conv3x3 (:889-893), bilinear resize (align_corners=False) to
+    the token grid, repeat over the latent frames, flatten f-major."""
+    B = patch.shape[0]
+    m = patch.view(B, 14, 14, -1).permute(0, 3, 1, 2)
+    m = F.conv2d(m, sd["feature_adapter.0.weight"], sd["feature_adapter.0.bias"], padding=1)
+    m = F.conv2d(F.silu(m), sd["feature_adapter.2.weight"], sd["feature_adapter.2.bias"], padding=1)
+    m = F.interpolate(m, size=tuple(hw), mode="bilinear", align_corners=False)
+    m = m.unsqueeze(2).repeat(1, 1, latent_T, 1, 1)
+    return m.flatten(2).transpose(1, 2)
+
+
 def block_forward(sd, i, cfg, x, e0, grid, context, guidance=None, k_len=None):
     """WanAttentionBlock.forward (:633-688); e0 [B,6,dim] fp32."""
     p = f"blocks.{i}"

@@ -309,7 +309,7 @@ def bilinear_cl(x, out_hw):
 
 
 # ------------------------------------------------------------------ training-step ops
-NAMES += ["transpose", "colsum", "scale_cast", "resid_gate", "add", "act_bwd_", "ln_modulate_bwd", "rmsnorm_rope_bwd_",
+NAMES += ["transpose", "colsum", "scale_cast", "resid_gate", "add", "act_bwd_", "ln_modulate_bwd", "guidance_bwd_", "rmsnorm_rope_bwd_",
           "attention_bwd", "sumsq", "adamw_", "lincomb"]
 
 
@@ -401,6 +401,25 @@ def ln_modulate_bwd(x, dy, dx, *, B, rows_per_sample, scale=None, mod_stride=0, 
         torch.as_strided(dshift, (G, C), (max(red_stride, 1), 1), dshift.storage_offset()).add_(s1)
         torch.as_strided(dscale, (G, C), (max(red_stride, 1), 1), dscale.storage_offset()).add_(s2)
     return dx
+
+
+def guidance_bwd_(x, dz, *, B, rows_per_sample, shift, scale, mod_stride, g_ss, g_gate, g_period, g_len, eps=1e-6):
+    C = x.shape[-1]
+    rps = rows_per_sample
+    xf = x.reshape(B, rps, C).float()
+    mu = xf.mean(-1, keepdim=True)
+    xh = (xf - mu) * torch.rsqrt((xf - mu).pow(2).mean(-1, keepdim=True) + eps)
+    u = xh * (1 + _strided_rows(scale, B, mod_stride, C)[:, None]) + _strided_rows(shift, B, mod_stride, C)[:, None]
+    g = dz.reshape(B, rps, C).float()
+    n = min(g_len, rps)
+    idx = torch.arange(n) % g_period
+    ab = torch.zeros(B, g_period, 2 * C)
+    ab[:, :, :C].index_add_(1, idx, g[:, :n] * u[:, :n])
+    ab[:, :, C:].index_add_(1, idx, g[:, :n])
+    du = g.clone()
+    du[:, :n] = g[:, :n] * (1 + g_ss[:, idx, :C] * g_gate)
+    dz.copy_(du.reshape(dz.shape).to(dz.dtype))
+    return ab
 
 
 @torch.enable_grad()

@@ -117,6 +117,79 @@ def make_dit_grads(ref):
     npz_save("dit_tiny_grads.npz", **out)
 
 
+def make_dit_guid_grads(ref):
+    """Guided training step (train_wan.sh: --use_omnimae_guidance; train_wan.py:1939-1951 passes first_frame): the reference
+    forward + backward with spatial guidance on.  The OmniMAE ViT-B (needs timm/hydra, frozen, train_wan.py:952) and
+    torchvision's Normalize are absent here: a stand-in extractor returns the seeded synthetic patch / cls features stored in
+    the fixture (the product takes exactly those through first_frame_features), Normalize is restated ((x-mean)/std).
+    Everything downstream of the features — feature_adapter convs, bilinear resize, T-repeat, every SpatialGuidanceModule,
+    the blocks — is the reference's own code and autograd."""
+    import types
+    z = dict(np.load(os.path.join(HERE, "dit_tiny.npz")))
+    z = {k: torch.from_numpy(v) for k, v in z.items()}
+    B = z["x"].shape[0]
+    g = torch.Generator().manual_seed(77)
+    patch = torch.randn(B, 196, 768, generator=g)
+    cls = torch.randn(B, 768, generator=g)
+
+    class _Trunk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def forward_patch_features(self, img, mask):
+            i = self.calls % B
+            self.calls += 1
+            return patch[i:i + 1].clone(), cls[i:i + 1].clone()
+
+    class _Extractor(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk = _Trunk()
+
+    om = types.ModuleType("MoRe4D.models.omnimae")
+    om.vit_base_mae_pretraining = lambda: _Extractor()
+    sys.modules["MoRe4D.models.omnimae"] = om
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    tvt.Normalize = Normalize
+    tv.transforms = tvt
+    sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+
+    cfg = dict(TINY_DIT, use_omnimae_guidance=True)
+    with torch.enable_grad():
+        m = ref.dit.WanTransformer4DModel(**cfg).train()
+        sd = load_recipe(m, "dit_tiny_guid_keys.json", seed=4321)
+        for n_, p_ in m.named_parameters():
+            p_.requires_grad_("omnimae_extractor" not in n_)
+        target = torch.randn(z["out_ref"].shape, generator=torch.Generator().manual_seed(22))
+        first_frame = torch.rand(B, 3, 224, 224, generator=g)
+        pred = m(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"],
+                 y=z["y"], full_ref=z["full_ref"], first_frame=first_frame)
+        diff = pred.float() - target
+        loss = (torch.nn.functional.mse_loss(pred.float(), target, reduction="none") * (diff.abs() <= 50).float()).mean()
+        loss.backward()
+    assert m.omnimae_extractor.trunk.calls == B
+    out = {"target": target, "loss": loss.detach(), "pred": pred.detach(), "patch": patch, "cls": cls}
+    for name, p_ in m.named_parameters():
+        if p_.grad is None:
+            continue
+        out["norm/" + name] = p_.grad.norm()
+        out["grad/" + name] = grad_sample(p_.grad)
+    print("guided params with grad:", sum(1 for k in out if k.startswith("norm/")),
+          "gate grad norm", float(out["norm/blocks.0.spatial_guidance_self.gate"]),
+          "adapter grad norm", float(out["norm/feature_adapter.0.weight"]))
+    npz_save("dit_tiny_guid_grads.npz", **out)
+
+
 def make_dit_ops(ref):
     """Per-op vectors: sinusoid, rope (incl. padded tail), rmsnorm, LN-modulate, SDPA,
     self-attn, cross-attn, block (with and without spatial guidance), head."""
@@ -384,6 +457,8 @@ if __name__ == "__main__":
         make_dit_ops(ref)
     if what in ("grads", "all"):
         make_dit_grads(ref)
+    if what in ("guidgrads", "all"):
+        make_dit_guid_grads(ref)
     if what in ("dit14b", "all"):
         make_block_14b_width(ref)
     if what in ("loop", "all"):

@@ -222,6 +222,29 @@ def test_adamw_and_sumsq(dtype, sdtype):
     tol = 1e-6 if dtype == torch.float32 else (3e-2 if sdtype == torch.bfloat16 else 1e-2)
     assert rel_err(p.float().cpu(), ref_p.detach()) < tol
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,P,L,glen", [(128, 12, 45, 36), (5120, 7, 24, 17), (2048, 5, 16, 16)])
+def test_guidance_bwd(dtype, C, P, L, glen):
+    """m4d_guidance_bwd: dz -> du in place and the per-position (sum dz*u | sum dz) table; ragged last period, rows past
+    g_len untouched, positions without rows zero."""
+    from more4d_amd import ops
+    B = 2
+    x = torch.randn(B, L, C, generator=gen()) * 2 + 0.3
+    dz = torch.randn(B, L, C, generator=gen(1)).to(dtype)
+    e = torch.randn(B, 6, C, generator=gen(2)) * 0.3
+    ss = torch.randn(B, P, 2 * C, generator=gen(3)) * 0.5
+    gate = torch.randn(C, generator=gen(4))
+    kw = dict(B=B, rows_per_sample=L, mod_stride=6 * C, g_period=P, g_len=glen, eps=1e-6)
+    ref_dz = dz.clone()
+    ref_ab = cpu_ops.guidance_bwd_(x, ref_dz, shift=e[:, 3], scale=e[:, 4], g_ss=ss, g_gate=gate, **kw)
+    ed, got_dz = e.to(DEV), dz.to(DEV)
+    got_ab = ops.guidance_bwd_(x.to(DEV), got_dz, shift=ed[:, 3], scale=ed[:, 4], g_ss=ss.to(DEV), g_gate=gate.to(DEV), **kw)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(got_ab.cpu(), ref_ab) < 1e-5
+    assert rel_err(got_dz.float().cpu(), ref_dz.float()) < tol
+    assert torch.equal(got_dz[:, glen:].cpu(), dz[:, glen:])
+
+
 
 def tiny_model(dtype):
     from more4d_amd.models import WanTransformer4DModel
@@ -287,3 +310,33 @@ def test_train_step_reduces_loss():
         opt.zero_grad()
         losses.append(float(loss))
     assert losses[2] < losses[1] < losses[0]
+
+
+def test_guided_dit_gradients():
+    """Guided training (train_wan.sh --use_omnimae_guidance): gate / spatial_guide / feature_adapter gradients of the HIP
+    path against the reference's (tests/golden/dit_tiny_guid_grads.npz), fp32 at 1e-3 and bf16 within the bf16 budget."""
+    from more4d_amd.models import WanTransformer4DModel
+    z, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_guid_grads.npz")
+    for dtype in (torch.float32, torch.bfloat16):
+        m = WanTransformer4DModel(**dict(TINY, use_omnimae_guidance=True))
+        missing = m.load_state_dict(fill(load_keys("dit_tiny_guid_keys.json"), 4321), strict=False)
+        assert not missing.missing_keys
+        m = m.to(DEV, dtype).train()
+        kw = dict(x=z["x"].to(DEV, dtype), t=z["t"].to(DEV), context=[z["ctx0"].to(DEV), z["ctx1"].to(DEV)],
+                  seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"].to(DEV), y=z["y"].to(DEV, dtype),
+                  full_ref=z["full_ref"].to(DEV, dtype), first_frame_features=(zg["patch"].to(DEV), zg["cls"].to(DEV)))
+        for budget in (None, 0):
+            m.zero_grad(set_to_none=True)
+            m.activation_budget_gb = budget
+            pred = m(**kw)
+            custom_mse_loss(pred, zg["target"].to(DEV)).backward()
+            grads = {n: p.grad for n, p in m.named_parameters()}
+            assert grads["feature_adapter.0.weight"] is not None and grads["blocks.1.spatial_guidance_ffn.gate"] is not None
+            if dtype == torch.float32:
+                assert rel_err(pred.detach().cpu(), zg["pred"]) < TOL
+                print("worst guided gradient error", check_grads(grads, zg, TOL))
+            else:
+                check_grads(grads, zg, 0.3, norm_tol=0.08)
+        with torch.no_grad():           # inference with the same features: same prediction as the training forward
+            out = m(**kw)
+        assert rel_err(out.float().cpu(), pred.detach().float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)

@@ -151,3 +151,55 @@ def test_train_step_host_logic(monkeypatch):
     assert losses[2] < losses[0]
     noisy, target = training.add_noise(lat, noise, sig)
     assert torch.allclose(noisy[0], 0.3 * lat[0] + 0.7 * noise[0]) and torch.equal(target, noise - lat)
+
+
+GUID = dict(TINY, use_omnimae_guidance=True)
+
+
+def test_oracle_guided_gradients_match_reference():
+    """Guided training (train_wan.sh --use_omnimae_guidance): the oracle's feature adapter + spatial guidance under torch
+    autograd == the reference's loss.backward() (tests/golden/dit_tiny_guid_grads.npz, make_golden.py:make_dit_guid_grads)."""
+    from oracle import dit as odit
+    z, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_guid_grads.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in fill(load_keys("dit_tiny_guid_keys.json"), 4321).items()}
+    cfg = odit.DiTConfig(**{k: v for k, v in TINY.items() if k in odit.DiTConfig.__dataclass_fields__},
+                         use_spatial_guidance=True)
+    F_, h, w = z["x"].shape[2], z["x"].shape[3] // 2, z["x"].shape[4] // 2
+    feats = odit.adapt_guidance_features(sd, zg["patch"], (h, w), F_)
+    pred = odit.dit_forward(sd, cfg, z["x"], z["t"], [z["ctx0"], z["ctx1"]], int(z["seq_len_pad"]), clip_fea=z["clip"],
+                            y=z["y"], full_ref=z["full_ref"], guidance=(feats, zg["cls"].view(-1, 1, 768)))
+    assert rel_err(pred.detach(), zg["pred"]) < 2e-5
+    loss = custom_mse_loss(pred, zg["target"])
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if v.grad is not None}
+    assert "feature_adapter.0.weight" in grads and "blocks.1.spatial_guidance_ffn.gate" in grads
+    check_grads(grads, zg, 1e-4)
+
+
+def test_product_guided_backward_host_logic(monkeypatch):
+    """Spatial-guidance gradients of the product (autograd.py: _guidance_site_bwd, GuidanceAdapterFn) through the torch
+    stand-ins: gate, spatial_guide Linear and feature_adapter convs of every block against the reference's gradients."""
+    from more4d_amd.models import WanTransformer4DModel
+    cpu_ops.install(monkeypatch)
+    z, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_guid_grads.npz")
+    m = WanTransformer4DModel(**GUID)
+    missing = m.load_state_dict(fill(load_keys("dit_tiny_guid_keys.json"), 4321), strict=False)
+    assert not missing.missing_keys, missing.missing_keys
+    m.train()
+    kw = dict(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"],
+              y=z["y"], full_ref=z["full_ref"], first_frame_features=(zg["patch"], zg["cls"]))
+    pred = m(**kw)
+    assert rel_err(pred.detach(), zg["pred"]) < 1e-4
+    custom_mse_loss(pred, zg["target"]).backward()
+    grads = {n: p.grad for n, p in m.named_parameters()}
+    for n in ("feature_adapter.0.weight", "feature_adapter.2.bias", "blocks.0.spatial_guidance_self.gate",
+              "blocks.1.spatial_guidance_ffn.spatial_guide.1.weight"):
+        assert grads[n] is not None, n
+    worst = check_grads(grads, zg, 1e-3)
+    print("worst guided gradient error", worst)
+    # stored-activation blocks give the same gradients
+    ref_grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    m.activation_budget_gb = 1e6
+    custom_mse_loss(m(**kw), zg["target"]).backward()
+    same_grads({n: p.grad for n, p in m.named_parameters() if p.grad is not None}, ref_grads)
