@@ -431,9 +431,13 @@ class WanTransformer4DModel(nn.Module):
             raise NotImplementedError("DINO guidance is not implemented")  # as in the reference (:881)
         self.dino_dim = 768
         if use_omnimae_guidance:
-            # The OmniMAE ViT-B extractor itself is outside the hot path: callers
-            # hand its [B,196,768] patch features in through `first_frame_features`; the adapter convs stay here
-            # so released checkpoints load.
+            # frozen OmniMAE ViT-B (reference :883-886; its weights travel inside the MoRe4D transformer checkpoints as
+            # `omnimae_extractor.trunk.*`).  Callers may also hand precomputed [B,196,768] patch features in through
+            # `first_frame_features` and skip the ViT (it is step-invariant at inference).
+            from .omnimae import vit_base_mae_pretraining
+            self.omnimae_extractor = vit_base_mae_pretraining(pretrained=False)
+            for p_ in self.omnimae_extractor.parameters():
+                p_.requires_grad = False
             self.feature_adapter = nn.Sequential(nn.Conv2d(self.dino_dim, self.dino_dim, 3, padding=1), nn.SiLU(),
                                                  nn.Conv2d(self.dino_dim, self.dino_dim, 3, padding=1))
         self.dino_extractor = None
@@ -604,16 +608,16 @@ class WanTransformer4DModel(nn.Module):
 
         x [B,16,F,H,W]; t [B]; context: list of [Li, text_dim] tensors OR a ContextCache from
         `prepare_context`; clip_fea [B,257,1280]; y [B,48,F,H,W]; full_ref [B,16,H,W].
-        first_frame_features: optional (patch_feats [B,196,768], cls [B,768]) OmniMAE outputs for spatial
-        guidance (the ViT itself is out of scope; see ctor note).  Returns [B, out_dim, F, H, W] in T.
+        first_frame: [B,3,H,W] in [0,1] -> OmniMAE ViT-B patch features (reference :1126-1146); or pass the
+        features directly as first_frame_features = (patch_feats [B,196,768], cls [B,768]).  Returns
+        [B, out_dim, F, H, W] in T.
         """
         if y_camera is not None or subject_ref is not None:
             raise NotImplementedError("y_camera / subject_ref are not part of the 4D-STraG path")
         if t.dim() != 1:
             raise NotImplementedError("per-token timesteps (ti2v) are not part of the 4D-STraG path")
         if first_frame is not None and self.use_omnimae_guidance and first_frame_features is None:
-            raise NotImplementedError("pass OmniMAE outputs via first_frame_features=(patch_feats, cls); the ViT-B "
-                                      "extractor is outside the hot path (SURVEY §8f rank 3)")
+            first_frame_features = self.omnimae_extractor.trunk.forward_patch_features(first_frame, None, normalize=True)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(x, t, context, seq_len, clip_fea, y, full_ref, first_frame_features)
         T, dev = self.dtype, self.device

@@ -169,6 +169,12 @@ class WanFunControlPipeline:
                 clip_context = self.clip_image_encoder([clip_image[:, None, :, :]]).to(device, T)
             else:
                 clip_context = torch.zeros((B, 257, 1280), device=device, dtype=T)   # (:698-701)
+        if first_frame is not None and first_frame_features is None and \
+                getattr(self.transformer, "use_omnimae_guidance", False):
+            # the reference re-runs the frozen ViT inside every DiT call (:816, wan_transformer4d.py:1126-1146); its output
+            # does not depend on the step, so it is computed once per sample here
+            first_frame_features = self.transformer.omnimae_extractor.trunk.forward_patch_features(
+                first_frame[:, :, 0].to(device), None, normalize=True)
         rep = 2 if do_cfg else 1
         cc = self.transformer.prepare_context(in_prompt_embeds, torch.cat([clip_context] * rep))
         lat = denoise_latents(self.transformer, self.scheduler, lat, ts, guidance_scale, cc, y=y, full_ref=full_ref,

@@ -190,6 +190,55 @@ def make_dit_guid_grads(ref):
     npz_save("dit_tiny_guid_grads.npz", **out)
 
 
+def _load_reference_omnimae():
+    """The reference's vendored OmniMAE ViT (MoRe4D/models/omnimae.py + omnivision/models/vision_transformer.py) imports `timm`
+    (DropPath, trunc_normal_) and `hydra`, both absent: stand-in NAMES only (DropPath at rate 0 is the identity, trunc_normal_
+    is torch's; hydra is not touched on this path)."""
+    import types
+    hy = types.ModuleType("hydra")
+    sys.modules["hydra"] = hy
+    timm, tm, tl = types.ModuleType("timm"), types.ModuleType("timm.models"), types.ModuleType("timm.models.layers")
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            assert p == 0.0
+
+        def forward(self, x):
+            return x
+
+    tl.DropPath, tl.trunc_normal_ = DropPath, torch.nn.init.trunc_normal_
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl})
+    for name in ("MoRe4D.models.omnivision", "MoRe4D.models.omnivision.models", "MoRe4D.models.omnivision.utils"):
+        _ref_import._mod(name)
+    _ref_import._load("MoRe4D.models.omnivision.models.vision_transformer",
+                      "MoRe4D/models/omnivision/models/vision_transformer.py")
+    return _ref_import._load("MoRe4D.models.omnimae", "MoRe4D/models/omnimae.py")
+
+
+def make_omnimae(ref):
+    """OmniMAE ViT-B patch features: the reference's vit_base_mae_pretraining(pretrained=False) trunk with
+    the recipe weights (the fixed sinusoidal pos_embed kept as built), on a seeded 2x3x96x160 frame normalised as at
+    wan_transformer4d.py:1130-1133 -> forward_patch_features."""
+    om = _load_reference_omnimae()
+    m = om.vit_base_mae_pretraining(pretrained=False).eval()
+    pos = m.trunk.pos_embed.detach().clone()
+    load_recipe(m, None, seed=555)
+    m.trunk.pos_embed.copy_(pos)
+    import json
+    enc = {k: list(v.shape) for k, v in m.state_dict().items()
+           if k.startswith("trunk.") and not k.startswith("trunk.decoder") and k not in ("trunk.mask_token", "trunk.pos_embed")}
+    with open(os.path.join(HERE, "omnimae_keys.json"), "w") as fh:
+        json.dump(enc, fh, indent=0, sort_keys=True)
+    g = torch.Generator().manual_seed(5)
+    frame = torch.rand(2, 3, 96, 160, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    feats, cls = m.trunk.forward_patch_features((frame - mean) / std, None)
+    print("omnimae feats", tuple(feats.shape), float(feats.abs().mean()), "cls", tuple(cls.shape))
+    npz_save("omnimae.npz", frame=frame, feats=feats, cls=cls, pos_head=pos[0, :4, :8], pos_tail=pos[0, 190:196, 760:])
+
+
 def make_dit_ops(ref):
     """Per-op vectors: sinusoid, rope (incl. padded tail), rmsnorm, LN-modulate, SDPA,
     self-attn, cross-attn, block (with and without spatial guidance), head."""
@@ -457,6 +506,8 @@ if __name__ == "__main__":
         make_dit_ops(ref)
     if what in ("grads", "all"):
         make_dit_grads(ref)
+    if what in ("omnimae", "all"):
+        make_omnimae(ref)
     if what in ("guidgrads", "all"):
         make_dit_guid_grads(ref)
     if what in ("dit14b", "all"):

@@ -229,3 +229,35 @@ def test_unipc_solver_gpu():
         x = sch.step(v, t, x, return_dict=False)[0]
         out.append(x.clone())
     assert rel_err(torch.stack(out).cpu(), z["o3_lin30"]) < 1e-5
+
+
+def test_omnimae_vit_patch_features():
+    """OmniMAE ViT-B front end on the HIP kernels == the reference's VisionTransformer.forward_patch_features
+    (tests/golden/omnimae.npz): fp32 at 1e-3, bf16 within the bf16 budget; then the DiT called with `first_frame`
+    (ViT -> adapter -> guidance) equals the DiT called with the precomputed features."""
+    from more4d_amd.models import WanTransformer4DModel
+    from more4d_amd.models.omnimae import vit_base_mae_pretraining
+    z = load_npz("omnimae.npz")
+    sd = fill(load_keys("omnimae_keys.json"), 555)
+    for dtype, tol in ((torch.float32, TOL), (torch.bfloat16, 3e-2)):
+        m = vit_base_mae_pretraining(pretrained=False)
+        m.load_state_dict(sd, strict=False)
+        m = m.to(DEV, dtype).eval()
+        feats, cls = m.trunk.forward_patch_features(z["frame"].to(DEV), None, normalize=True)
+        assert feats.dtype == torch.float32 and feats.shape == (2, 196, 768)
+        err = rms_rel_err(feats.cpu(), z["feats"]) if dtype == torch.bfloat16 else rel_err(feats.cpu(), z["feats"])
+        print("omnimae", dtype, err)
+        assert err < tol and rel_err(cls.cpu(), feats[:, 0].cpu()) == 0
+    zt = load_npz("dit_tiny.npz")
+    g = WanTransformer4DModel(**dict(TINY, use_omnimae_guidance=True))
+    g.load_state_dict(fill(load_keys("dit_tiny_guid_keys.json"), 4321), strict=False)
+    g.omnimae_extractor.load_state_dict(sd, strict=False)
+    g = g.to(DEV, torch.float32).eval()
+    kw = dict(x=zt["x"].to(DEV), t=zt["t"].to(DEV), context=[zt["ctx0"].to(DEV), zt["ctx1"].to(DEV)],
+              seq_len=int(zt["seq_len_pad"]), clip_fea=zt["clip"].to(DEV), y=zt["y"].to(DEV), full_ref=zt["full_ref"].to(DEV))
+    with torch.no_grad():
+        a = g(**kw, first_frame=z["frame"].to(DEV))
+        ff = g.omnimae_extractor.trunk.forward_patch_features(z["frame"].to(DEV), None, normalize=True)
+        b = g(**kw, first_frame_features=ff)
+        c = g(**kw)
+    assert torch.equal(a, b) and rel_err(a.cpu(), c.cpu()) > 1e-4      # guidance is on and changes the prediction

@@ -284,3 +284,20 @@ def test_flow_match_euler_restatement(monkeypatch):
     noisy = e.scale_noise(z["x"], e.timesteps[3:4], z["v"])
     sg = float(e.sigmas[3])
     assert torch.allclose(noisy, sg * z["v"] + (1 - sg) * z["x"], atol=1e-6)
+
+
+def test_omnimae_vit_host_logic(monkeypatch):
+    """OmniMAE ViT-B front end (more4d_amd/models/omnimae.py): token / padding / K-V bookkeeping, packed stem, fused
+    normalisation and the reference state-dict names, against the reference ViT's output (arithmetic by the stand-ins)."""
+    from more4d_amd.models.omnimae import sinusoid_table, vit_base_mae_pretraining
+    cpu_ops.install(monkeypatch)
+    z = load_npz("omnimae.npz")
+    m = vit_base_mae_pretraining(pretrained=False)
+    assert torch.equal(m.trunk.pos_embed[0, :4, :8], z["pos_head"])
+    assert rel_err(sinusoid_table(1568, 768)[0, 190:196, 760:], z["pos_tail"]) < 1e-6
+    sd = fill(load_keys("omnimae_keys.json"), 555)
+    res = m.load_state_dict(sd, strict=False)
+    assert res.missing_keys == ["trunk.pos_embed"] and not res.unexpected_keys
+    feats, cls = m.trunk.forward_patch_features(z["frame"], None, normalize=True)
+    assert feats.shape == (2, 196, 768) and cls.shape == (2, 768)
+    assert rel_err(feats, z["feats"]) < 1e-4 and rel_err(cls, z["cls"]) < 1e-4

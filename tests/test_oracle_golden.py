@@ -91,3 +91,15 @@ def test_loop_50_steps():
 
     out = sched.denoise_loop(model_fn, z["lat"], ts, sigmas, float(z["guidance"]))
     assert rel_err(out, z["final"]) < 2e-4  # 50 chained fp32 forwards
+
+
+def test_omnimae_vit_patch_features():
+    """oracle/omnimae.py == the reference's own VisionTransformer.forward_patch_features (tests/golden/omnimae.npz)."""
+    from oracle import omnimae as oom
+    z = load_npz("omnimae.npz")
+    sd = fill(load_keys("omnimae_keys.json"), 555)
+    sd["trunk.pos_embed"] = oom.sinusoid_table(8 * 14 * 14, 768)
+    assert torch.equal(sd["trunk.pos_embed"][0, :4, :8], z["pos_head"])
+    assert rel_err(sd["trunk.pos_embed"][0, 190:196, 760:], z["pos_tail"]) < 1e-6
+    feats, cls = oom.forward_patch_features(sd, oom.normalize(z["frame"]))
+    assert rel_err(feats, z["feats"]) < 2e-5 and rel_err(cls, z["cls"]) < 2e-5

@@ -320,7 +320,7 @@ def test_guided_dit_gradients():
     for dtype in (torch.float32, torch.bfloat16):
         m = WanTransformer4DModel(**dict(TINY, use_omnimae_guidance=True))
         missing = m.load_state_dict(fill(load_keys("dit_tiny_guid_keys.json"), 4321), strict=False)
-        assert not missing.missing_keys
+        assert all(k.startswith("omnimae_extractor.") for k in missing.missing_keys)
         m = m.to(DEV, dtype).train()
         kw = dict(x=z["x"].to(DEV, dtype), t=z["t"].to(DEV), context=[z["ctx0"].to(DEV), z["ctx1"].to(DEV)],
                   seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"].to(DEV), y=z["y"].to(DEV, dtype),

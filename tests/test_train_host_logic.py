@@ -184,7 +184,7 @@ def test_product_guided_backward_host_logic(monkeypatch):
     z, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_guid_grads.npz")
     m = WanTransformer4DModel(**GUID)
     missing = m.load_state_dict(fill(load_keys("dit_tiny_guid_keys.json"), 4321), strict=False)
-    assert not missing.missing_keys, missing.missing_keys
+    assert all(k.startswith("omnimae_extractor.") for k in missing.missing_keys), missing.missing_keys
     m.train()
     kw = dict(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"],
               y=z["y"], full_ref=z["full_ref"], first_frame_features=(zg["patch"], zg["cls"]))
