@@ -862,6 +862,40 @@ class WanTransformer4DModel(nn.Module):
         y = ops.bilinear_cl(x.view(B, 14, 14, self.dino_dim), hw)
         return y.view(B, hw[0] * hw[1], self.dino_dim)
 
+    def save_pretrained(self, save_directory, max_shard_size_gb=10.0):
+        """diffusers-layout checkpoint directory (what `models[0].save_pretrained(...)` writes in the reference's save hook,
+        train_wan.py:1011, and what `from_pretrained` reads back): config.json + diffusion_pytorch_model[-0000i-of-0000n]
+        .safetensors shards (+ the shard index)."""
+        import json
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()}
+        cfg["_class_name"] = type(self).__name__
+        with open(os.path.join(save_directory, "config.json"), "w") as fh:
+            json.dump(cfg, fh, indent=2, sort_keys=True)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        limit = int(max_shard_size_gb * 2 ** 30)
+        shards, cur, size = [], {}, 0
+        for k, v in sd.items():
+            nbytes = v.numel() * v.element_size()
+            if cur and size + nbytes > limit:
+                shards.append(cur)
+                cur, size = {}, 0
+            cur[k] = v
+            size += nbytes
+        shards.append(cur)
+        if len(shards) == 1:
+            save_file(shards[0], os.path.join(save_directory, "diffusion_pytorch_model.safetensors"), metadata={"format": "pt"})
+            return
+        index = {"metadata": {"total_size": sum(v.numel() * v.element_size() for v in sd.values())}, "weight_map": {}}
+        for i, sh in enumerate(shards):
+            name = f"diffusion_pytorch_model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file(sh, os.path.join(save_directory, name), metadata={"format": "pt"})
+            index["weight_map"].update({k: name for k in sh})
+        with open(os.path.join(save_directory, "diffusion_pytorch_model.safetensors.index.json"), "w") as fh:
+            json.dump(index, fh, indent=2, sort_keys=True)
+
     def unpatchify(self, x, grid_sizes):
         """Reference-compatible helper (:1343-1366) for callers that hold head outputs: x list of [L, 64]."""
         outs = []

@@ -301,3 +301,39 @@ def test_omnimae_vit_host_logic(monkeypatch):
     feats, cls = m.trunk.forward_patch_features(z["frame"], None, normalize=True)
     assert feats.shape == (2, 196, 768) and cls.shape == (2, 768)
     assert rel_err(feats, z["feats"]) < 1e-4 and rel_err(cls, z["cls"]) < 1e-4
+
+
+def test_checkpoint_and_pointcloud_wire_formats(tmp_path):
+    """save_pretrained <-> from_pretrained (diffusers directory layout, sharded and single-file), the sampler pickle of the
+    training hooks and the point-cloud text dump."""
+    import json
+    import pickle
+    import numpy as np
+    from more4d_amd.models import WanTransformer4DModel
+    from more4d_amd.utils import io
+    m = WanTransformer4DModel(**TINY)
+    m.load_state_dict(fill(load_keys("dit_tiny_keys.json"), 1234))
+    for sub, shard_gb in (("one", 10.0), ("many", 2e-4)):
+        d = str(tmp_path / sub)
+        m.save_pretrained(d, max_shard_size_gb=shard_gb)
+        names = sorted(os.listdir(d))
+        assert "config.json" in names and (len(names) == 2) == (sub == "one")
+        assert json.load(open(os.path.join(d, "config.json")))["dim"] == TINY["dim"]
+        m2 = WanTransformer4DModel.from_pretrained(d, torch_dtype=torch.float32)
+        assert all(torch.equal(v, m2.state_dict()[k]) for k, v in m.state_dict().items())
+    io.save_sampler_state(str(tmp_path), 1000, 3)
+    assert pickle.load(open(tmp_path / "sampler_pos_start.pkl", "rb")) == [1000, 3]
+    assert io.load_sampler_state(str(tmp_path), dataloader_num_workers=4, num_processes=8) == (936, 3)
+    assert io.load_sampler_state(str(tmp_path / "one")) is None
+    g = torch.Generator().manual_seed(0)
+    recon = torch.randn(1, 3, 3, 2, 4, generator=g)
+    first = torch.randn(1, 3, 1, 2, 4, generator=g)
+    coords = io.recover_coords(recon, first)
+    assert coords.shape == (1, 3, 3, 2, 4) and torch.equal(coords[:, :, 0], first[:, :, 0])
+    assert torch.allclose(coords[:, :, 2], recon[:, :, 2] + first[:, :, 0])
+    colors = io.image_colors(torch.rand(1, 3, 2, 4, generator=g) * 2 - 1)
+    files = io.save_pointcloud_data(coords, colors, "vid", str(tmp_path), 7)
+    assert [os.path.basename(f) for f in files] == [f"vid_frame_{i:04d}.txt" for i in range(3)]
+    rows = np.loadtxt(files[1])
+    assert rows.shape == (8, 6) and np.allclose(rows[:, :3], coords[0, :, 1].permute(1, 2, 0).reshape(-1, 3).numpy())
+    assert np.array_equal(rows[:, 3:], colors[0].float().numpy())
