@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--no-ref", action="store_true", help="drop the reference-image row (L=20280)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--parallelism", choices=["auto", "sp", "cfg-sp"], default="auto",
+                    help="N>1: 'sp' = all ranks shard the tokens of the CFG pair; 'cfg-sp' = the two CFG branches on the two "
+                         "halves of the world, tokens sharded inside each half (auto: cfg-sp when N is even)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,10 +160,13 @@ def main():
     cfg["num_layers"] = args.layers
     dtype = torch.bfloat16
     model = build_model(cfg, dev, dtype)
+    branch = None
     if world > 1:
-        from more4d_amd.dist import init_sequence_parallel
-        init_sequence_parallel()
+        from more4d_amd.dist import get_cfg_parallel_rank, init_sequence_parallel
+        cfgp = args.parallelism == "cfg-sp" or (args.parallelism == "auto" and world % 2 == 0)
+        init_sequence_parallel(cfg_parallel=cfgp)
         model.enable_multi_gpus_inference()
+        branch = get_cfg_parallel_rank()
 
     # synthetic 49x480x832 trajectory latents: [1,16,13,60,104] (+48 control channels, ref row, context)
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -177,7 +183,9 @@ def main():
     total_steps = args.warmup + args.steps
     ts, _ = retrieve_timesteps(sch, device=dev, sigmas=get_sampling_sigmas(50, 5.0))
     with torch.no_grad():
-        cc = model.prepare_context(ctx, torch.cat([clip, clip]))   # step-invariant, resident before timing
+        # step-invariant, resident before timing (CFG-parallel ranks hold their own branch only)
+        cc = model.prepare_context(ctx, torch.cat([clip, clip])) if branch is None else \
+            model.prepare_context([ctx[branch]], clip)
 
         def run(i0, n, x):
             class _S:   # scheduler view starting at step i0
@@ -227,7 +235,10 @@ def main():
                                    f"{'' if args.no_ref else ' incl. 1560 ref-row tokens'}, CFG batch 2, "
                                    "guidance + Euler fused; random-init weights",
                        "layers": args.layers, "tokens": L, "cfg_batch": 2,
-                       "parallelism": "single GPU" if world == 1 else f"sp{world} (token/T-sharded, RCCL all-gather K,V^T)"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"sp{world} (token/T-sharded, RCCL all-gather K,V^T)" if branch is None else
+                           f"cfg2 x sp{world // 2} (CFG branches on the two halves; tokens T-sharded inside a half, RCCL "
+                           "all-gather K,V^T; one velocity exchange per step)")},
             "finite": ok, "valid": args.layers == 40 and ok,
             "step_tflop": step_flops / 1e12,
             "mfma_frac_whole_step": step_flops / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TF * world),

@@ -38,6 +38,14 @@ def denoise_latents(transformer, scheduler, latents, timesteps, guidance_scale, 
     x = latents.to(device=dev, dtype=torch.float32).contiguous().clone()
     B = x.shape[0]
     rep = 2 if do_cfg else 1
+    # CFG-parallel (more4d_amd.dist.init_sequence_parallel(cfg_parallel=True)): this rank runs ONE branch at batch B and the
+    # two velocities are exchanged once per step; x stays replicated and identical on every rank
+    from ..dist import cfg_exchange, get_cfg_parallel_rank
+    branch = get_cfg_parallel_rank() if do_cfg else None
+    if branch is not None:
+        if transformer.teacache is not None or getattr(transformer, "cfg_skip_ratio", None):
+            raise NotImplementedError("TeaCache / cfg-skip together with CFG-parallel ranks")
+        rep = 1
 
     def dup(t):
         if t is None:
@@ -47,8 +55,10 @@ def denoise_latents(transformer, scheduler, latents, timesteps, guidance_scale, 
 
     y2, ref2 = dup(y), dup(full_ref)
     if isinstance(context, ContextCache):
-        cc = context
+        cc = context          # (CFG-parallel: the caller built it for this rank's branch only)
     else:
+        if branch is not None:
+            context = list(context)[branch * B:(branch + 1) * B]
         clip2 = dup(clip_fea)
         cc = transformer.prepare_context(context, clip2)
     if seq_len is None:
@@ -60,10 +70,12 @@ def denoise_latents(transformer, scheduler, latents, timesteps, guidance_scale, 
         ffeat = tuple(torch.cat([u] * rep) for u in first_frame_features)
     for i, t in enumerate(timesteps):
         transformer.current_steps = i
-        xin = torch.cat([x] * rep) if do_cfg else x
+        xin = torch.cat([x] * rep) if rep > 1 else x
         tt = t.to(dev).expand(xin.shape[0])
         v = transformer(x=xin.to(T) if T != torch.float32 else xin, t=tt, context=cc, seq_len=seq_len, y=y2,
                         full_ref=ref2, first_frame_features=ffeat)
+        if branch is not None:
+            v = cfg_exchange(v)
         if do_cfg:
             scheduler.step_cfg_(x, v.contiguous(), guidance_scale, i, round_dtype=T)
         else:

@@ -191,6 +191,58 @@ def test_sequence_parallel_equals_single_rank(world):
     assert err < 1e-4
 
 
+def _cfgp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import more4d_amd.ops as real
+        for n in cpu_ops.NAMES:
+            setattr(real, n, getattr(cpu_ops, n))
+        from more4d_amd.dist import get_cfg_parallel_rank, init_sequence_parallel
+        from more4d_amd.models import WanTransformer4DModel
+        from more4d_amd.pipeline import denoise_latents
+        from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+        z = load_npz("loop_tiny.npz")
+        m = WanTransformer4DModel(**TINY)
+        m.load_state_dict(fill(load_keys("dit_tiny_keys.json"), 1234))
+        m.eval()
+
+        def loop():
+            sch = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+            ts, _ = retrieve_timesteps(sch, sigmas=get_sampling_sigmas(int(z["steps"]), float(z["shift"])))
+            with torch.no_grad():
+                return denoise_latents(m, sch, z["lat"], ts[:4], float(z["guidance"]), [z["ctx_u"], z["ctx_c"]],
+                                       clip_fea=z["clip"], y=z["y"], full_ref=z["full_ref"], seq_len=256)
+        single = loop()                                  # CFG batched on one rank, no groups yet
+        init_sequence_parallel(cfg_parallel=True)
+        m.enable_multi_gpus_inference()
+        assert get_cfg_parallel_rank() == rank // (world // 2) and m.sp_world_size == world // 2
+        multi = loop()
+        q.put((rank, float(rel_err(multi, single))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg_parallel_loop_equals_single_rank(world):
+    """CFG-parallel x token-sharded denoise loop under gloo (world 2 = one branch per rank, no per-layer collective; world 4
+    = 2 branches x 2 token shards): every rank ends with the latents of the single-rank loop."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + world + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_cfgp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    errs = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(errs) == list(range(world)) and max(errs.values()) < 1e-5, errs
+
+
 def test_teacache_and_guidance_adapter_host_logic(monkeypatch):
     """TeaCache: threshold 0 must reproduce the plain forward; a huge threshold must re-use the residual (second call
     == first call + nothing recomputed).  Guidance adapter: conv-SiLU-conv + bilinear resize equals torch's."""
