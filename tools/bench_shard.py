@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Per-rank compute time of the N-GPU denoise step on ONE GPU: the sequence-parallel group is replaced by a stand-in whose
+"all-gather" replicates the local shard (same shapes, same kernels, no xGMI traffic).  step_time(1 GPU) / (N * this) is the
+scaling the compute alone allows; the difference to the driver's measured N-GPU number is communication + skew.
+    python tools/bench_shard.py --world 8 --mode cfg-sp|sp [--steps 2]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import CFG_14B, build_model  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--mode", choices=["sp", "cfg-sp"], default="cfg-sp")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=40)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    from more4d_amd.dist import SequenceParallelGroup
+    from more4d_amd.ops import KV
+
+    spw = args.world // 2 if args.mode == "cfg-sp" else args.world
+    B = 1 if args.mode == "cfg-sp" else 2
+
+    class FakeSP(SequenceParallelGroup):
+        def __init__(self):
+            self.group, self.world_size, self.rank = None, spw, 0
+
+        def all_gather(self, x, dim=1):
+            return torch.cat([x] * self.world_size, dim=dim)
+
+        def gather_start(self, x):
+            x = x.contiguous()
+            buf = torch.empty((self.world_size,) + tuple(x.shape), device=x.device, dtype=x.dtype)
+            buf.copy_(x.unsqueeze(0).expand_as(buf))     # every peer slot = a copy of the local shard (real values: power)
+            return buf, None, x
+
+    cfg = dict(CFG_14B)
+    cfg["num_layers"] = args.layers
+    model = build_model(cfg, dev, torch.bfloat16)
+    if spw > 1:
+        model.sp_world_size, model.sp_world_rank, model._sp = spw, 0, FakeSP()
+    g = torch.Generator(device=dev).manual_seed(1234)
+    F_, H_, W_ = 13, 60, 104
+    x = torch.randn(B, 16, F_, H_, W_, generator=g, device=dev).bfloat16()
+    y = torch.randn(B, 48, F_, H_, W_, generator=g, device=dev).bfloat16()
+    full_ref = torch.randn(B, 16, H_, W_, generator=g, device=dev).bfloat16()
+    ctx = [torch.randn(512, 4096, generator=g, device=dev) for _ in range(B)]
+    clip = torch.randn(B, 257, 1280, generator=g, device=dev)
+    Lv = F_ * (H_ // 2) * (W_ // 2)
+    t = torch.full((B,), 500.0, device=dev)
+    with torch.no_grad():
+        cc = model.prepare_context(ctx, clip)
+        for _ in range(args.warmup):
+            model(x=x, t=t, context=cc, seq_len=Lv, y=y, full_ref=full_ref)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(x=x, t=t, context=cc, seq_len=Lv, y=y, full_ref=full_ref)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"world": args.world, "mode": args.mode, "sp_world": spw, "batch_per_rank": B,
+                      "rank_ms_per_step": dt * 1e3, "finite": bool(torch.isfinite(out.float()).all())}))
+
+
+if __name__ == "__main__":
+    main()
