@@ -125,6 +125,32 @@ def cpu_baseline(cfg, L, seconds_hint=30):
                        f"x{cfg['num_layers']} layers x2 CFG => {step_s:.0f} s/step")
 
 
+def secondary_figures(model, cfg, dev):
+    """The other figures BASELINE.json's metric names, measured after (never inside) the timed region on the same GPU:
+    VAE + adaptor round trip at 49x480x832 (configs[2]) and one 14B train step at batch 1 (configs[4] per-GPU work).  Each is
+    best-effort: a failure is reported, it never sinks the headline measurement."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    out = {}
+    try:
+        import bench_vae
+        r = bench_vae.run(49, 480, 832, iters=2, dev=dev, verbose=False)
+        out["vae_roundtrip"] = {"ms": r["roundtrip_ms"], "parts_ms": r["ms"], "tflops": r["tflops"], "finite": r["finite"],
+                                "workload": "enc-adaptor + encode + decode + dec-adaptor, 49x480x832x3 trajectories, bf16"}
+    except Exception as ex:
+        out["vae_roundtrip"] = {"error": repr(ex)}
+    torch.cuda.empty_cache()
+    try:
+        import bench_train
+        r = bench_train.run_train(model, cfg, dev, steps=2, warmup=1)
+        out["train_step"] = {"s_per_step": r["value"], "mfma_frac": r["mfma_frac"], "max_mem_gb": r["max_mem_gb"],
+                             "stored_blocks": r["stored_blocks"],
+                             "workload": "14B DiT fwd + bwd (+ recompute where activations are not stored) + clip + AdamW, batch 1, "
+                                         "L=21840, bf16 params and optimizer state"}
+    except Exception as ex:
+        out["train_step"] = {"error": repr(ex)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +160,8 @@ def main():
     ap.add_argument("--no-ref", action="store_true", help="drop the reference-image row (L=20280)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary BASELINE.json figures (VAE round trip, train step) measured after the timed region")
     ap.add_argument("--parallelism", choices=["auto", "sp", "cfg-sp"], default="auto",
                     help="N>1: 'sp' = all ranks shard the tokens of the CFG pair; 'cfg-sp' = the two CFG branches on the two "
                          "halves of the world, tokens sharded inside each half (auto: cfg-sp when N is even)")
@@ -205,8 +233,7 @@ def main():
             def attn_flops(q, segs, *aa, **kk):
                 klen = sum(max(0, s.len) for s in segs)
                 return 4 * kk["B"] * kk["Lq"] * klen * kk["heads"] * kk["head_dim"]
-            kt.wrap(ops, "gemm_bt", gemm_flops)
-            kt.wrap(ops, "attention", attn_flops)
+            originals = {"gemm_bt": kt.wrap(ops, "gemm_bt", gemm_flops), "attention": kt.wrap(ops, "attention", attn_flops)}
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -216,6 +243,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if kt is not None:
+            for name, fn in originals.items():
+                setattr(ops, name, fn)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -259,6 +289,8 @@ def main():
                 "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ak.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
                 "launches": ak.get("launches", 0), "share_of_step_time": ak.get("ms", 0.0) / (dt * 1e3),
             }
+        if world == 1 and not args.no_secondary and args.layers == 40:
+            out["secondary"] = secondary_figures(model, cfg, dev)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, L)

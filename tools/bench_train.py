@@ -17,38 +17,22 @@ sys.path.insert(0, ROOT)
 from bench import CFG_14B, MFMA_BF16_PEAK_TF, build_model, flops_per_forward  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--layers", type=int, default=40)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--fp32-state", action="store_true")
-    ap.add_argument("--act-budget", type=float, default=None, help="GB of stored activations (default: automatic; 0 = recompute)")
-    ap.add_argument("--profile-ops", action="store_true", help="HIP-event time per ops.* entry point (adds syncs)")
-    args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
+def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=None, profile_ops=False, world=1, rank=0,
+              local_rank=0):
+    """Time `steps` training steps of `model` (already on `dev`, bf16): fwd + (recompute) + bwd + clip + AdamW."""
     from more4d_amd import ops
     from more4d_amd.optim import AdamW, clip_grad_norm_
-    cfg = dict(CFG_14B)
-    cfg["num_layers"] = args.layers
-    model = build_model(cfg, dev, torch.bfloat16).train()
-    model.activation_budget_gb = args.act_budget
+    model = model.train()
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+    model.activation_budget_gb = act_budget
     net = model
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel as DDP
         net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True,
                   bucket_cap_mb=512)
     opt = AdamW(model.parameters(), lr=2e-5, weight_decay=3e-2, eps=1e-10,
-                state_dtype=torch.float32 if args.fp32_state else None)
+                state_dtype=torch.float32 if fp32_state else None)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     F_, H_, W_ = 13, 60, 104
@@ -66,7 +50,7 @@ def main():
     t = torch.tensor([sigma * 1000.0], device=dev)
 
     timers = {}
-    if args.profile_ops:
+    if profile_ops:
         for name in ("gemm_bt", "attention", "attention_bwd", "transpose", "ln_modulate", "ln_modulate_bwd", "rmsnorm_rope",
                      "rmsnorm_rope_bwd_", "colsum", "scale_cast", "resid_gate", "act_bwd_", "unary", "add", "adamw_", "sumsq"):
             orig = getattr(ops, name)
@@ -94,31 +78,58 @@ def main():
         opt.zero_grad(set_to_none=False)
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     timers.clear()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
     gf, af = flops_per_forward(cfg, L, 1)
     # fwd + recompute + bwd: GEMMs 1 + 1 + 2, attention 1 + 1 + 2.5 (five matmuls per pair instead of two)
     model_flops = 4 * gf + 4.5 * af
     out = {"metric": "train-step seconds, 14B DiT fwd+recompute+bwd+AdamW, batch 1/GPU, 49x480x832 bf16",
-           "value": dt, "unit": "s/step", "n_gpus": world, "layers": args.layers, "loss": float(loss.detach()),
+           "value": dt, "unit": "s/step", "n_gpus": world, "layers": cfg["num_layers"], "loss": float(loss.detach()),
            "model_tflop": model_flops / 1e12, "mfma_frac": model_flops / dt / 1e12 / MFMA_BF16_PEAK_TF,
            "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "stored_blocks": [model.last_stored_blocks, model.last_full_blocks],
-           "state_dtype": "float32" if args.fp32_state else "bfloat16"}
+           "state_dtype": "float32" if fp32_state else "bfloat16"}
     if timers:
         torch.cuda.synchronize()
-        out["ops_ms_per_step"] = {k: round(sum(s.elapsed_time(e) for s, e in v) / args.steps, 2) for k, v in
+        out["ops_ms_per_step"] = {k: round(sum(s.elapsed_time(e) for s, e in v) / steps, 2) for k, v in
                                   sorted(timers.items(), key=lambda kv: -sum(s.elapsed_time(e) for s, e in kv[1]))}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--fp32-state", action="store_true")
+    ap.add_argument("--act-budget", type=float, default=None, help="GB of stored activations (default: automatic; 0 = recompute)")
+    ap.add_argument("--profile-ops", action="store_true", help="HIP-event time per ops.* entry point (adds syncs)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(CFG_14B)
+    cfg["num_layers"] = args.layers
+    model = build_model(cfg, dev, torch.bfloat16)
+    out = run_train(model, cfg, dev, steps=args.steps, warmup=args.warmup, fp32_state=args.fp32_state,
+                    act_budget=args.act_budget, profile_ops=args.profile_ops, world=world, rank=rank, local_rank=local_rank)
     if rank == 0:
         print(json.dumps(out))
 
