@@ -671,7 +671,11 @@ class WanTransformer4DModel(nn.Module):
         else:
             c = _Ctx(B, L, Lp, grid, cos, sin, L, self._f32cache, key_len)
         if guid is not None and sp is not None:
-            raise NotImplementedError("spatial guidance with sequence parallelism")
+            # token l of this rank is global token pos_offset + l: the T-periodic guidance table is rotated to start at this
+            # rank's first position and its length is what remains of the guided range (one roll of [B, P, 768] per forward)
+            feats_silu, period, glen = guid
+            guid = (torch.roll(feats_silu, shifts=-(c.pos_offset % period), dims=1).contiguous(), period,
+                    max(0, min(c.Lp, glen - c.pos_offset)))
         # ---- TeaCache (reference :1201-1270): skip the blocks when the accumulated, rescaled relative-L1 change of the
         # modulated timestep embedding stays under the threshold, re-using the previous residual of the token stream
         should_calc = True

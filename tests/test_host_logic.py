@@ -191,6 +191,51 @@ def test_sequence_parallel_equals_single_rank(world):
     assert err < 1e-4
 
 
+def _sp_guid_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import more4d_amd.ops as real
+        for n in cpu_ops.NAMES:
+            setattr(real, n, getattr(cpu_ops, n))
+        from more4d_amd.dist import init_sequence_parallel
+        from more4d_amd.models import WanTransformer4DModel
+        z, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_guid_grads.npz")
+        m = WanTransformer4DModel(**dict(TINY, use_omnimae_guidance=True))
+        m.load_state_dict(fill(load_keys("dit_tiny_guid_keys.json"), 4321), strict=False)
+        m.eval()
+        kw = dict(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"],
+                  y=z["y"], full_ref=z["full_ref"], first_frame_features=(zg["patch"], zg["cls"]))
+        with torch.no_grad():
+            single = m(**kw)
+            init_sequence_parallel()
+            m.enable_multi_gpus_inference()
+            multi = m(**kw)
+        q.put((rank, float(rel_err(multi, single)), float(rel_err(single, zg["pred"]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sequence_parallel_with_spatial_guidance(world):
+    """Token-sharded forward WITH spatial guidance (the released 4D-STraG config): each rank rotates the T-periodic guidance
+    table to its first global token; N ranks == 1 rank == the reference's guided prediction."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + world + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_sp_guid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(e_multi < 1e-5 and e_ref < 1e-4 for _, e_multi, e_ref in res), res
+
+
 def _cfgp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
