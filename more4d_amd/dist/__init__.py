@@ -95,12 +95,16 @@ def init_sequence_parallel(group=None, cfg_parallel=False):
         if W % 2:
             raise ValueError("cfg_parallel needs an even world size")
         half = W // 2
-        mine = None
-        for b in range(2):      # every rank must take part in the creation of every group
-            g = dist.new_group(list(range(b * half, (b + 1) * half)))
-            if dist.get_rank() // half == b:
-                mine = g
-        _SP_GROUP = SequenceParallelGroup(mine)
+        if half == 1:           # one rank per branch: nothing to shard, no group to build
+            _SP_GROUP = SequenceParallelGroup.__new__(SequenceParallelGroup)
+            _SP_GROUP.group, _SP_GROUP.world_size, _SP_GROUP.rank = None, 1, 0
+        else:
+            mine = None
+            for b in range(2):  # every rank must take part in the creation of every group
+                g = dist.new_group(list(range(b * half, (b + 1) * half)))
+                if dist.get_rank() // half == b:
+                    mine = g
+            _SP_GROUP = SequenceParallelGroup(mine)
         _CFG = (dist.get_rank() // half, W)
         return _SP_GROUP
     _SP_GROUP = SequenceParallelGroup(group)
