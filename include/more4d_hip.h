@@ -188,6 +188,15 @@ int m4d_cl_to_ncthw(m4d_dtype src_dt, const void* src, int64_t src_pixel_stride,
  * WanAttentionBlock (:659) and Head (:718). */
 int m4d_add_bcast(const float* a, const float* bias, float* out, int64_t B, int64_t n, m4d_stream stream);
 
+/* Merge two m4d_attention_lse results of the SAME queries over DISJOINT key sets (T-sharded denoising: the local K/V shard is
+ * attended while the peers' shards are still on the xGMI links, more4d_amd/dist): in place,
+ *   o_a <- 2^(lse_a - lse) o_a + 2^(lse_b - lse) o_b,   lse_a <- lse = log2(2^lse_a + 2^lse_b)
+ * o_* T [B, L, heads*head_dim] (batch / row strides in elements), lse_* float [B, heads, L] in the log2 domain; a side
+ * without any valid key (lse = -inf) gets weight 0.  Equals one softmax over the union of the keys (reference attention(),
+ * wan_transformer4d.py:66-236, over the all-gathered K/V :1187-1198). */
+int m4d_attn_merge(m4d_dtype dt, void* o_a, int64_t oa_bs, int64_t oa_ls, float* lse_a, const void* o_b, int64_t ob_bs,
+                   int64_t ob_ls, const float* lse_b, int B, int64_t L, int heads, int head_dim, m4d_stream stream);
+
 /* TeaCache step skipping (cache_utils.py:19-74, wan_transformer4d.py:1201-1270), all float32:
  * axpby: out = a*x + b*y (residual re-use x + r, residual capture x_out - x_in);
  * rel_l1: out2 = { sum|cur - prev|, sum|prev| } over the modulated timestep embedding [B,6,C]. */

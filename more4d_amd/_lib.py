@@ -57,6 +57,8 @@ SIGNATURES = {
     "m4d_act_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "m4d_ln_modulate_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64,
                                     c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m4d_attn_merge": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int64,
+                               c_int, c_int, c_void_p]),
     "m4d_guidance_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_float,
                                  c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "m4d_rmsnorm_rope_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

@@ -277,6 +277,43 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs p) {
     }
 }
 
+// Merge two partial attention results over disjoint key sets (same queries): o_a <- wa*o_a + wb*o_b, lse_a <- lse with
+// lse = log2(2^lse_a + 2^lse_b) (log2 domain, as m4d_attention_lse writes it), wa = 2^(lse_a - lse), wb = 2^(lse_b - lse).
+// A side with no valid key has lse = -inf and weight 0.  16 bytes per thread; the two weights of a (row, head) are recomputed
+// by the 16 / 32 threads that share them (broadcast loads).
+struct MergeArgs { void* oa; const void* ob; float* la; const float* lb; int64_t oa_bs, oa_ls, ob_bs, ob_ls, L; int B, heads, D; };
+template <typename T, int EPV>
+__global__ __launch_bounds__(256) void attn_merge_kernel(MergeArgs p) {
+    const int vpr = p.heads * p.D / EPV;                    // vectors per row
+    const int64_t total = (int64_t)p.B * p.L * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const int64_t l = r % p.L;
+        const int b = (int)(r / p.L);
+        const int c = v * EPV, h = c / p.D;
+        const int64_t si = ((int64_t)b * p.heads + h) * p.L + l;
+        const float la = p.la[si], lb = p.lb[si];
+        const float mx = fmaxf(la, lb);
+        float wa = 0.f, wb = 0.f, lt = -INFINITY;
+        if (mx > -INFINITY) {
+            const float ea = __builtin_amdgcn_exp2f(la - mx), eb = __builtin_amdgcn_exp2f(lb - mx);
+            const float inv = 1.f / (ea + eb);
+            wa = ea * inv; wb = eb * inv;
+            lt = mx + log2f(ea + eb);
+        }
+        T* pa = (T*)p.oa + b * p.oa_bs + l * p.oa_ls + c;
+        const T* pb = (const T*)p.ob + b * p.ob_bs + l * p.ob_ls + c;
+        float xa[EPV], xb[EPV];
+        load_vec<T, EPV>(pa, xa);
+        load_vec<T, EPV>(pb, xb);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) xa[e] = wa * xa[e] + wb * xb[e];
+        store_vec<T, EPV>(pa, xa);
+        if (c % p.D == 0) p.la[si] = lt;     // one writer per (row, head); every reader of la[si] belongs to this wave-front
+    }
+}
+
 // out[0] = sum|cur - prev|, out[1] = sum|prev| (one workgroup; TeaCache's relative-L1 on the [B,6,C] modulation, cache_utils.py)
 __global__ __launch_bounds__(1024) void rel_l1_kernel(const float* prev, const float* cur, float* out, int64_t n) {
     __shared__ float rd[16], rp[16];
@@ -468,6 +505,22 @@ extern "C" int m4d_lincomb(const float* x0, float a0, const float* x1, float a1,
     p.out = out; p.n = n;
     hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p);
     M4D_CHECK_LAUNCH("lincomb");
+    return 0;
+}
+
+extern "C" int m4d_attn_merge(m4d_dtype dt, void* o_a, int64_t oa_bs, int64_t oa_ls, float* lse_a, const void* o_b, int64_t ob_bs,
+                              int64_t ob_ls, const float* lse_b, int B, int64_t L, int heads, int head_dim, m4d_stream stream) {
+    M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "attn_merge: bad dtype");
+    M4D_CHECK_ARG(o_a && o_b && lse_a && lse_b && B > 0 && L > 0 && heads > 0, "attn_merge: bad arguments");
+    const int epv = dt == M4D_BF16 ? 8 : 4;
+    M4D_CHECK_ARG(head_dim == 32 || head_dim == 64 || head_dim == 128, "attn_merge: head_dim must be 32, 64 or 128");   // one head's vectors sit in one wave
+    M4D_CHECK_ARG(head_dim % epv == 0 && oa_ls % epv == 0 && ob_ls % epv == 0 && oa_bs % epv == 0 && ob_bs % epv == 0 &&
+                  ((uintptr_t)o_a % 16) == 0 && ((uintptr_t)o_b % 16) == 0, "attn_merge: rows must be 16-byte aligned");
+    MergeArgs p{o_a, o_b, lse_a, lse_b, oa_bs, oa_ls, ob_bs, ob_ls, L, B, heads, head_dim};
+    dim3 grid(grid_for((int64_t)B * L * heads * head_dim / epv)), block(256);
+    if (dt == M4D_BF16) hipLaunchKernelGGL((attn_merge_kernel<bf16_t, 8>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_merge_kernel<float, 4>), grid, block, 0, (hipStream_t)stream, p);
+    M4D_CHECK_LAUNCH("attn_merge");
     return 0;
 }
 

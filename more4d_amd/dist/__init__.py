@@ -8,6 +8,8 @@ op but self-attention is token-local; per layer each rank all-gathers K [B, Ls, 
 the attention kernel one K/V *segment per rank* (no concat copy).  The final head output is all-gathered
 along tokens (:1320-1321).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -18,6 +20,10 @@ _CFG = None     # (cfg_rank, world group size) when the two CFG branches run on 
 
 
 class SequenceParallelGroup:
+    # self-attention attends the local K/V shard first (overlapping the all-gather) and merges the remote part afterwards
+    # (m4d_attn_merge); M4D_SP_LOCAL_FIRST=0 restores the single attention call over all gathered segments
+    local_first = os.environ.get("M4D_SP_LOCAL_FIRST", "1") != "0"
+
     def __init__(self, group=None):
         self.group = group
         self.world_size = dist.get_world_size(group)

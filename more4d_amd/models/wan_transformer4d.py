@@ -143,8 +143,28 @@ class WanSelfAttention(nn.Module):
             hv = c.sp.gather_start(vt)
             q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
             ops.rmsnorm_rope(q, wq, **rope)
-            segs = c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)
-        o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
+            if c.sp.local_first:
+                # attend the LOCAL shard while the peers' shards are still on the links, then the gathered remote shards,
+                # and merge the two partial softmaxes through their log-sum-exps (== one softmax over all keys)
+                r = c.sp.rank
+                n_loc = max(0, min(Lp, c.key_len - r * Lp))
+                kw = dict(B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
+                o = None
+                if n_loc > 0:
+                    lse = torch.empty((B, n, Lp), device=q.device, dtype=torch.float32)
+                    o = ops.attention(q, [KV(k, vt, Lp * C, C, Lp, B * Lp, n_loc)], lse=lse, **kw)
+                rem = [s for i, s in enumerate(c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)) if i != r and s.len > 0]
+                if o is None:           # this rank holds only padding rows: nothing local to attend
+                    o = ops.attention(q, rem, **kw)
+                elif rem:
+                    lse_r = torch.empty_like(lse)
+                    o_r = ops.attention(q, rem, lse=lse_r, **kw)
+                    ops.attn_merge_(o, lse, o_r, lse_r, B=B, L=Lp, heads=n, head_dim=d)
+                segs = None
+            else:
+                segs = c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)
+        if segs is not None:
+            o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
         ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=gate,
                     gate_stride=gate_stride, rows_per_sample=Lp)
         return xres

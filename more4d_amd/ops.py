@@ -230,6 +230,21 @@ def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None
     return out
 
 
+def attn_merge_(o_a, lse_a, o_b, lse_b, *, B, L, heads, head_dim):
+    """In place: o_a, lse_a <- the attention over the union of two disjoint key sets, from the partial results (o_a, lse_a) and
+    (o_b, lse_b) of `attention(..., lse=...)` on the same queries.  o_*: [B, L, heads*head_dim] (row-strided)."""
+    _dev(o_a, lse_a, o_b, lse_b)
+    if o_a.dtype != o_b.dtype or lse_a.dtype != torch.float32 or lse_b.dtype != torch.float32:
+        raise TypeError("attn_merge_: outputs share a dtype, lse tensors are float32")
+    if not (lse_a.is_contiguous() and lse_b.is_contiguous()) or lse_a.numel() != B * heads * L or lse_b.numel() != B * heads * L:
+        raise ValueError("attn_merge_: lse must be contiguous [B, heads, L]")
+    oa3, ob3 = o_a.view(B, L, heads * head_dim), o_b.view(B, L, heads * head_dim)
+    check(_lib.load().m4d_attn_merge(dt_code(o_a.dtype), _ptr(oa3), oa3.stride(0), oa3.stride(1), _ptr(lse_a), _ptr(ob3),
+                                     ob3.stride(0), ob3.stride(1), _ptr(lse_b), B, L, heads, head_dim, _stream()),
+          "m4d_attn_merge")
+    return o_a
+
+
 def patchify(src0, src1, patch, out_dtype):
     """[B,c0,F,H,W] (+ [B,c1,F,H,W]) -> [B, f*h*w, (c0+c1)*pt*ph*pw]."""
     _dev(src0, src1)

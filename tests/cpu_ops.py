@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from more4d_amd.ops import (EPI_GELU_ERF, EPI_GELU_TANH, EPI_RESID_GATE, EPI_SILU, EPI_STORE,  # noqa: F401
                             EPI_STORE_F32, KV, _rows2d)
 
-NAMES = ["gemm_bt", "ln_modulate", "rmsnorm_rope", "attention", "patchify", "unpatchify", "cfg_euler_", "unary",
+NAMES = ["gemm_bt", "ln_modulate", "rmsnorm_rope", "attention", "attn_merge_", "patchify", "unpatchify", "cfg_euler_", "unary",
          "add_bcast"]
 
 
@@ -147,6 +147,18 @@ def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None
     else:
         out.copy_(o)
     return out
+
+
+def attn_merge_(o_a, lse_a, o_b, lse_b, *, B, L, heads, head_dim):
+    la, lb = lse_a.view(B, heads, L), lse_b.view(B, heads, L)
+    lt = torch.logaddexp(la * math.log(2.0), lb * math.log(2.0)) / math.log(2.0)
+    wa = torch.where(torch.isinf(lt), torch.zeros_like(lt), torch.exp2(la - lt)).permute(0, 2, 1).unsqueeze(-1)
+    wb = torch.where(torch.isinf(lt), torch.zeros_like(lt), torch.exp2(lb - lt)).permute(0, 2, 1).unsqueeze(-1)
+    a = o_a.view(B, L, heads, head_dim).float()
+    b = o_b.view(B, L, heads, head_dim).float()
+    o_a.view(B, L, heads, head_dim).copy_((wa * a + wb * b).to(o_a.dtype))
+    lse_a.view(B, heads, L).copy_(lt)
+    return o_a
 
 
 def patchify(src0, src1, patch, out_dtype):

@@ -261,3 +261,57 @@ def test_omnimae_vit_patch_features():
         b = g(**kw, first_frame_features=ff)
         c = g(**kw)
     assert torch.equal(a, b) and rel_err(a.cpu(), c.cpu()) > 1e-4      # guidance is on and changes the prediction
+
+
+def test_token_sharded_local_first_schedule_single_gpu():
+    """The T-sharded forward's local-first self-attention (local shard, then the gathered remote shards, merged through their
+    log-sum-exps) on ONE GPU: a stand-in group whose all-gather hands every rank slot the right shard of a reference run."""
+    from more4d_amd.dist import SequenceParallelGroup
+    from more4d_amd.models.wan_transformer4d import WanSelfAttention, _Ctx, build_rope_tables, rope_params
+    torch.manual_seed(0)
+    B, W, Ls, C, heads = 2, 4, 264, 256, 2
+    d = C // heads
+    L = W * Ls - 19                                       # the last shard is ragged: 19 pad keys masked
+    sa = WanSelfAttention(C, heads).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in sa.parameters():
+            p_.normal_(0, 0.05)
+        sa.norm_q.weight.add_(1.0)
+        sa.norm_k.weight.add_(1.0)
+    freqs = torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)), rope_params(1024, 2 * (d // 6))], dim=1)
+    grid = (W, 12, 22)
+    cos, sin = build_rope_tables(freqs, grid, d, DEV)
+    xn = torch.randn(B, W * Ls, C, device=DEV)
+    gate = torch.ones(B, C, device=DEV)
+    with torch.no_grad():
+        full = torch.zeros(B, W * Ls, C, device=DEV)
+        sa.run(xn, full, gate, C, _Ctx(B, L, W * Ls, grid, cos, sin, L, {}, L))
+
+        class Stub(SequenceParallelGroup):
+            def __init__(self, rank, shards):
+                self.group, self.world_size, self.rank, self.shards, self.calls = None, W, rank, shards, 0
+
+            def gather_start(self, x):
+                buf = torch.stack(self.shards[self.calls])
+                assert torch.equal(buf[self.rank], x)      # this rank's K / V^T are exactly what the peers would receive
+                self.calls += 1
+                return buf, None, x
+
+        # per-rank K and V^T shards from independent single-rank evaluations of the projections
+        shards = [[], []]
+        for r in range(W):
+            xr = xn[:, r * Ls:(r + 1) * Ls].contiguous()
+            from more4d_amd import ops
+            k = ops.gemm_bt(xr.view(-1, C), sa.k.weight, sa.k.bias)
+            ops.rmsnorm_rope(k, sa.norm_k.weight.float(), head_dim=d, eps=sa.eps, cos=cos, sin=sin, rows_per_sample=Ls,
+                             rope_len=max(0, min(Ls, L - r * Ls)), pos_offset=r * Ls)
+            shards[0].append(k)
+            shards[1].append(ops.gemm_bt(sa.v.weight, xr.view(-1, C), sa.v.bias, bias_on_m=True))
+        for local_first in (True, False):
+            for r in range(W):
+                sp = Stub(r, shards)
+                sp.local_first = local_first
+                out = torch.zeros(B, Ls, C, device=DEV)
+                c = _Ctx(B, L, Ls, grid, cos, sin, max(0, min(Ls, L - r * Ls)), {}, L, sp, r * Ls)
+                sa.run(xn[:, r * Ls:(r + 1) * Ls].contiguous(), out, gate, C, c)
+                assert rel_err(out.cpu(), full[:, r * Ls:(r + 1) * Ls].cpu()) < 1e-5, (local_first, r)

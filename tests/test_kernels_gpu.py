@@ -385,3 +385,33 @@ def test_conv_cl_production_kernel(cin, cout, k, pad):
     out2 = o.conv_cl(x.to(DEV), wp.to(DEV), b.to(DEV), Tin=Tin, Hin=H, Win=W, Cin=cin, k=k, pad=pad, out_thw=(To, H, W),
                      resid=res.to(DEV))
     assert rel_err(out2.float().cpu(), ref.bfloat16().float() + res.float()) < BF16_TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hd,heads,Lq,La,Lb", [(128, 2, 264, 200, 328), (64, 3, 40, 0, 72), (128, 4, 2304, 2304, 4608)])
+def test_attn_merge_equals_joint_softmax(dtype, hd, heads, Lq, La, Lb):
+    """m4d_attn_merge: attention over key set A merged with attention over key set B == one attention over A u B (the local-
+    first schedule of the T-sharded self-attention); an empty side (lse = -inf) contributes nothing."""
+    from more4d_amd import ops
+    from more4d_amd.ops import KV
+    B, C = 2, heads * hd
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B * Lq, C, generator=g).to(dtype).to(DEV)
+    rows_a, rows_b = max(La, 8), Lb
+    ka, kb = (torch.randn(B * r, C, generator=g).to(dtype).to(DEV) for r in (rows_a, rows_b))
+    va, vb = (torch.randn(C, B * r, generator=g).to(dtype).to(DEV) for r in (rows_a, rows_b))
+    sa = KV(ka, va, rows_a * C, C, rows_a, B * rows_a, La)
+    sb = KV(kb, vb, rows_b * C, C, rows_b, B * rows_b, Lb)
+    kw = dict(B=B, Lq=Lq, heads=heads, head_dim=hd, q_bs=Lq * C, q_ls=C)
+    lse_j = torch.empty(B, heads, Lq, device=DEV)
+    joint = ops.attention(q, [sa, sb], lse=lse_j, **kw)
+    la, lb = torch.empty_like(lse_j), torch.empty_like(lse_j)
+    if La == 0:        # an empty side: what a rank without valid local keys contributes (the ABI rejects key-less calls)
+        oa, la = torch.zeros_like(joint), torch.full_like(lse_j, -float("inf"))
+    else:
+        oa = ops.attention(q, [sa], lse=la, **kw)
+    ob = ops.attention(q, [sb], lse=lb, **kw)
+    ops.attn_merge_(oa, la, ob, lb, B=B, L=Lq, heads=heads, head_dim=hd)
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(oa.float().cpu(), joint.float().cpu()) < tol
+    assert rel_err(la.cpu(), lse_j.cpu()) < 1e-5
