@@ -188,7 +188,12 @@ class WanFunControlPipeline:
             first_frame_features = self.transformer.omnimae_extractor.trunk.forward_patch_features(
                 first_frame[:, :, 0].to(device), None, normalize=True)
         rep = 2 if do_cfg else 1
-        cc = self.transformer.prepare_context(in_prompt_embeds, torch.cat([clip_context] * rep))
+        from ..dist import get_cfg_parallel_rank
+        branch = get_cfg_parallel_rank() if do_cfg else None
+        if branch is None:
+            cc = self.transformer.prepare_context(in_prompt_embeds, torch.cat([clip_context] * rep))
+        else:       # CFG-parallel ranks embed (and cache the cross-attention K/V of) their own branch only
+            cc = self.transformer.prepare_context(in_prompt_embeds[branch * B:(branch + 1) * B], clip_context)
         lat = denoise_latents(self.transformer, self.scheduler, lat, ts, guidance_scale, cc, y=y, full_ref=full_ref,
                               first_frame_features=first_frame_features)
         if output_type == "latent":
