@@ -66,10 +66,11 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = model(x=x, t=t, context=cc, seq_len=Lv, y=y, full_ref=full_ref)
+        t_host = (time.perf_counter() - t0) / args.steps       # host time to ENQUEUE a step (must stay below the GPU time)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"world": args.world, "mode": args.mode, "sp_world": spw, "batch_per_rank": B,
-                      "rank_ms_per_step": dt * 1e3, "finite": bool(torch.isfinite(out.float()).all())}))
+                      "rank_ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": t_host * 1e3, "finite": bool(torch.isfinite(out.float()).all())}))
 
 
 if __name__ == "__main__":
