@@ -18,7 +18,7 @@ from bench import CFG_14B, MFMA_BF16_PEAK_TF, build_model, flops_per_forward  # 
 
 
 def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=None, profile_ops=False, world=1, rank=0,
-              local_rank=0):
+              local_rank=0, guidance=False):
     """Time `steps` training steps of `model` (already on `dev`, bf16): fwd + (recompute) + bwd + clip + AdamW."""
     from more4d_amd import ops
     from more4d_amd.optim import AdamW, clip_grad_norm_
@@ -48,11 +48,15 @@ def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=N
     noisy = ((1 - sigma) * lat + sigma * noise).bfloat16()      # train_wan.py:1926
     target = noise - lat                                        # :1929
     t = torch.tensor([sigma * 1000.0], device=dev)
+    extra = {}
+    if guidance:    # the released recipe (--use_omnimae_guidance): precomputed OmniMAE patch features, ViT frozen
+        extra["first_frame_features"] = (torch.randn(1, 196, 768, generator=g, device=dev), torch.randn(1, 768, generator=g, device=dev))
 
     timers = {}
     if profile_ops:
         for name in ("gemm_bt", "attention", "attention_bwd", "transpose", "ln_modulate", "ln_modulate_bwd", "rmsnorm_rope",
-                     "rmsnorm_rope_bwd_", "colsum", "scale_cast", "resid_gate", "act_bwd_", "unary", "add", "adamw_", "sumsq"):
+                     "rmsnorm_rope_bwd_", "colsum", "scale_cast", "resid_gate", "act_bwd_", "unary", "add", "adamw_", "sumsq", "guidance_bwd_",
+                     "conv_cl", "bilinear_cl", "add_bcast"):
             orig = getattr(ops, name)
 
             def wrapped(*a, _o=orig, _n=name, **k):
@@ -69,7 +73,7 @@ def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=N
         wt.ops = ops
 
     def step():
-        pred = net(x=noisy, t=t, context=ctx, seq_len=Lv, clip_fea=clip, y=y, full_ref=full_ref)
+        pred = net(x=noisy, t=t, context=ctx, seq_len=Lv, clip_fea=clip, y=y, full_ref=full_ref, **extra)
         diff = pred.float() - target
         loss = (diff * diff * (diff.abs() <= 50).float()).mean()            # custom_mse_loss :1953-1963
         loss.backward()
@@ -114,6 +118,7 @@ def main():
     ap.add_argument("--fp32-state", action="store_true")
     ap.add_argument("--act-budget", type=float, default=None, help="GB of stored activations (default: automatic; 0 = recompute)")
     ap.add_argument("--profile-ops", action="store_true", help="HIP-event time per ops.* entry point (adds syncs)")
+    ap.add_argument("--guidance", action="store_true", help="train with spatial guidance on (use_omnimae_guidance, random-init gates)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,9 +132,13 @@ def main():
 
     cfg = dict(CFG_14B)
     cfg["num_layers"] = args.layers
+    if args.guidance:
+        cfg["use_omnimae_guidance"] = True
     model = build_model(cfg, dev, torch.bfloat16)
     out = run_train(model, cfg, dev, steps=args.steps, warmup=args.warmup, fp32_state=args.fp32_state,
-                    act_budget=args.act_budget, profile_ops=args.profile_ops, world=world, rank=rank, local_rank=local_rank)
+                    act_budget=args.act_budget, profile_ops=args.profile_ops, world=world, rank=rank, local_rank=local_rank,
+                    guidance=args.guidance)
+    out["guidance"] = args.guidance
     if rank == 0:
         print(json.dumps(out))
 
