@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--no-ref", action="store_true", help="drop the reference-image row (L=20280)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--guidance", action="store_true",
+                    help="spatial guidance on (use_omnimae_guidance=True, synthetic OmniMAE patch features): the released 4D-STraG "
+                         "checkpoint's configuration; the headline number is quoted without it (SURVEY 8d config 2)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary BASELINE.json figures (VAE round trip, train step) measured after the timed region")
     ap.add_argument("--parallelism", choices=["auto", "sp", "cfg-sp"], default="auto",
@@ -186,6 +189,8 @@ def main():
 
     cfg = dict(CFG_14B)
     cfg["num_layers"] = args.layers
+    if args.guidance:
+        cfg["use_omnimae_guidance"] = True
     dtype = torch.bfloat16
     model = build_model(cfg, dev, dtype)
     branch = None
@@ -204,6 +209,7 @@ def main():
     full_ref = None if args.no_ref else torch.randn(1, 16, H_, W_, generator=g, device=dev)
     ctx = [torch.randn(512, 4096, generator=g, device=dev), torch.randn(77, 4096, generator=g, device=dev)]
     clip = torch.randn(1, 257, 1280, generator=g, device=dev)
+    ffeat = (torch.randn(1, 196, 768, generator=g, device=dev), torch.randn(1, 768, generator=g, device=dev)) if args.guidance else None
     Lv = F_ * (H_ // 2) * (W_ // 2)
     L = Lv + (0 if args.no_ref else (H_ // 2) * (W_ // 2))
 
@@ -220,7 +226,8 @@ def main():
                 @staticmethod
                 def step_cfg_(lat_, v, gs, i, round_dtype=torch.float32):
                     return sch.step_cfg_(lat_, v, gs, i0 + i, round_dtype)
-            return denoise_latents(model, _S, x, ts[i0:i0 + n], 6.0, cc, y=y, full_ref=full_ref, seq_len=Lv)
+            return denoise_latents(model, _S, x, ts[i0:i0 + n], 6.0, cc, y=y, full_ref=full_ref, seq_len=Lv,
+                                   first_frame_features=ffeat)
 
         x = run(0, args.warmup, lat) if args.warmup else lat
         kt = None
@@ -264,7 +271,7 @@ def main():
                                    f"latent 1x16x13x60x104 (49x480x832 px), L={L} tokens"
                                    f"{'' if args.no_ref else ' incl. 1560 ref-row tokens'}, CFG batch 2, "
                                    "guidance + Euler fused; random-init weights",
-                       "layers": args.layers, "tokens": L, "cfg_batch": 2,
+                       "layers": args.layers, "tokens": L, "cfg_batch": 2, "spatial_guidance": bool(args.guidance),
                        "parallelism": "single GPU" if world == 1 else (
                            f"sp{world} (token/T-sharded, RCCL all-gather K,V^T)" if branch is None else
                            f"cfg2 x sp{world // 2} (CFG branches on the two halves; tokens T-sharded inside a half, RCCL "
