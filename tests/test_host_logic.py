@@ -434,3 +434,18 @@ def test_checkpoint_and_pointcloud_wire_formats(tmp_path):
     rows = np.loadtxt(files[1])
     assert rows.shape == (8, 6) and np.allclose(rows[:, :3], coords[0, :, 1].permute(1, 2, 0).reshape(-1, 3).numpy())
     assert np.array_equal(rows[:, 3:], colors[0].float().numpy())
+
+
+def test_bench_flop_accounting_matches_survey():
+    """bench.py's algorithmic FLOPs == SURVEY §8d: F(L) = 40 [12 L d^2 + 4 L^2 d + 4 L d ffn + 4 L 769 d] + embed =
+    837.9 TFLOP (L = 20 280) / 930.0 TFLOP (L = 21 840) per forward, cached context K/V excluded (0.35 %)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for L, want in ((20280, 837.9e12), (21840, 930.0e12)):
+        g, a = bench.flops_per_forward(bench.CFG_14B, L, 1)
+        assert abs((g + a) - want) / want < 6e-3, (L, (g + a) / 1e12)
+    g2, a2 = bench.flops_per_forward(bench.CFG_14B, 21840, 2)
+    assert abs((g2 + a2) / 1e12 - 1853.4) < 1.0
+    assert bench.MFMA_BF16_PEAK_TF == 2500.0
