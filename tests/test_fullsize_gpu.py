@@ -169,3 +169,52 @@ def test_vae_full_size_causality():
         dec_part = vae.decode(full[:, :, :3].contiguous()).sample
     assert dec_full.shape == (1, 3, 17, 480, 832) and torch.equal(dec_part, dec_full[:, :, :9])
     assert bool(torch.isfinite(dec_full.float()).all()) and float(dec_full.float().abs().max()) <= 1.0
+
+
+def test_attention_backward_full_length_sampled():
+    """attn_bwd128 passes at L = 21 840 (B = 1, 8 of the 40 heads to bound memory): dQ on sampled queries, dK / dV on sampled
+    keys against fp32 formulas over the FULL other axis (P from the forward's LSE; dS = P (dP - delta) scale)."""
+    from more4d_amd import ops
+    from more4d_amd.ops import KV
+    heads, Cc = 8, 8 * D
+    q = torch.randn(L, Cc, generator=gen(1), device=DEV).to(BF)
+    k = torch.randn(L, Cc, generator=gen(2), device=DEV).to(BF)
+    v = torch.randn(L, Cc, generator=gen(3), device=DEV).to(BF)
+    d_o = (torch.randn(L, Cc, generator=gen(4), device=DEV) * 0.1).to(BF)
+    lse = torch.empty(1, heads, L, device=DEV)
+    o = ops.attention(q, [KV(k, ops.transpose(v), L * Cc, Cc, L, L, L)], B=1, Lq=L, heads=heads, head_dim=D, q_bs=L * Cc,
+                      q_ls=Cc, lse=lse).view(L, Cc)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attention_bwd(q, k, v, o, d_o, lse, B=1, Lq=L, Lk=L, Lk_rows=L, heads=heads, head_dim=D, dq=dq, dk=dk, dv=dv)
+    scale = 1.0 / math.sqrt(D)
+    ln2 = math.log(2.0)
+    idx = torch.tensor([0, 63, 64, 9999, 21776, 21839], device=DEV)
+    for h in (0, 5):
+        sl = slice(h * D, (h + 1) * D)
+        qf, kf, vf, of, gf = (t[:, sl].float() for t in (q, k, v, o, d_o))
+        lse_nat = lse[0, h] * ln2                                      # [L]
+        delta = (gf * of).sum(-1)                                      # [L]
+        # sampled queries: full rows of P and dS
+        P = torch.exp(qf[idx] @ kf.t() * scale - lse_nat[idx, None])   # [6, L]
+        dS = P * (gf[idx] @ vf.t() - delta[idx, None]) * scale
+        assert rel(dq[idx, sl].float(), dS @ kf) < 3e-2
+        # sampled keys: full columns
+        Pc = torch.exp(qf @ kf[idx].t() * scale - lse_nat[:, None])    # [L, 6]
+        dSc = Pc * (gf @ vf[idx].t() - delta[:, None]) * scale
+        assert rel(dv[idx, sl].float(), Pc.t() @ gf) < 3e-2
+        assert rel(dk[idx, sl].float(), dSc.t() @ qf) < 3e-2
+
+
+def test_linear_backward_full_token_axis_sampled():
+    """wgrad / dgrad / bias gradient of a Linear over all 21 840 tokens (the token axis is the GEMM K of the wgrad, zero-padded to
+    a multiple of 64): sampled entries against fp32 over the full token axis."""
+    from more4d_amd.autograd import linear_bwd
+    x = (torch.randn(L, C, generator=gen(1), device=DEV) * 0.5).to(BF)
+    w = (torch.randn(C, C, generator=gen(2), device=DEV) * C ** -0.5).to(BF)
+    dy = (torch.randn(L, C, generator=gen(3), device=DEV) * 0.1).to(BF)
+    dx, dw, db = linear_bwd(x, w, dy)
+    r = torch.tensor([0, 255, 256, 5119], device=DEV)
+    assert rel(dw[r].float(), dy[:, r].float().t() @ x.float()) < 1e-2
+    t = torch.tensor([0, 21583, 21584, 21839], device=DEV)
+    assert rel(dx[t].float(), dy[t].float() @ w.float()) < 1e-2
+    assert rel(db, dy.float().sum(0)) < 1e-4
