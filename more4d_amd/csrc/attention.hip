@@ -437,16 +437,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
-        float psum = 0.f;
+        // single-issue v_fma_f32 / v_exp_f32 / v_add_f32 as ONE volatile asm stream in a fixed order: hipcc SLP-packs the
+        // plain C into v_pk_*_f32, which costs more than its two scalar halves beside the other waves' MFMAs
+        // (MI355X_MICROARCH.md price list); its hazard recogniser does not see through inline asm, so every v_add_f32 trails
+        // the v_exp_f32 it consumes by four instructions (gfx940+ trans-use hazard needs one)
+        float psa = 0.f, psb = 0.f;
+        {
+            const float nm = -m_run;
+#define M4D_SM_A(SUB, R) do { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s[SUB][R]) : "v"(s[SUB][R]), "s"(p.sc), "v"(nm)); \
+                              asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s[SUB][(R) + 1]) : "v"(s[SUB][(R) + 1]), "s"(p.sc), "v"(nm)); } while (0)
+#define M4D_SM_B(SUB, R) do { asm volatile("v_exp_f32 %0, %1" : "=v"(s[SUB][R]) : "v"(s[SUB][R])); \
+                              asm volatile("v_exp_f32 %0, %1" : "=v"(s[SUB][(R) + 1]) : "v"(s[SUB][(R) + 1])); } while (0)
+#define M4D_SM_C(SUB, R) do { asm volatile("v_add_f32 %0, %1, %2" : "=v"(psa) : "v"(psa), "v"(s[SUB][R])); \
+                              asm volatile("v_add_f32 %0, %1, %2" : "=v"(psb) : "v"(psb), "v"(s[SUB][(R) + 1])); } while (0)
+            M4D_SM_A(0, 0); M4D_SM_B(0, 0);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][r], p.sc, -m_run));
-                s[sub][r] = pv;
-                psum += pv;
+            for (int i = 1; i < 16; ++i) {
+                M4D_SM_A(i >> 3, 2 * (i & 7));
+                M4D_SM_B(i >> 3, 2 * (i & 7));
+                M4D_SM_C((i - 1) >> 3, 2 * ((i - 1) & 7));
             }
-        l_run += psum;
+            asm volatile("s_nop 1");
+            M4D_SM_C(1, 14);
+#undef M4D_SM_A
+#undef M4D_SM_B
+#undef M4D_SM_C
+        }
+        l_run += psa + psb;
         // ---- O^T += V^T P^T ----  16 (c, d) steps, V^T fragments 4 steps ahead
         bf16x8 pf[4];
 #pragma unroll
@@ -531,11 +548,16 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
             static bool configured = false;
             if (!configured) {
-                if (hipFuncSetAttribute((const void*)attn128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
+                if (hipFuncSetAttribute((const void*)attn128p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
+                hipFuncSetAttribute((const void*)attn128p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
                 configured = true;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
-            hipLaunchKernelGGL(attn128p_kernel, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(512), 4 * 32768, st, q);
+            static int smx = -1;
+            if (smx < 0) { const char* v = getenv("M4D_ATTN_SMX"); smx = v ? atoi(v) : 1; }   // 1 = scalar softmax arithmetic (default: +9 % sustained over the packed form), 0 = packed
+            const dim3 gp((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
+            if (smx == 1) hipLaunchKernelGGL(attn128p_kernel<1>, gp, dim3(512), 4 * 32768, st, q);
+            else hipLaunchKernelGGL(attn128p_kernel<0>, gp, dim3(512), 4 * 32768, st, q);
         } else if (w8) {
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             hipLaunchKernelGGL(attn128_kernel<8>, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(512), 0, st, q);

@@ -15,7 +15,7 @@
 
 enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };
 
-template <int MODE>
+template <int MODE, int SMX>   // SMX: 1 = single-issue fp32 VALU forms in the elementwise step (default), 0 = packed v_pk_*_f32 (A/B)
 __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
     typedef bf16_t T;
     constexpr int D = 128, YB = 64, XB = 256;
@@ -190,9 +190,51 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
                     for (int j = 0; j < 4; ++j) { dv[j] = d0[j]; dv[4 + j] = d1[j]; }
                 }
             }
+            bf16x8 out;
+            if constexpr (SMX == 1) {
+                // single-issue v_fma_f32 / v_exp_f32 / v_mul_f32 as one volatile asm stream in a fixed order: beside the partner
+                // wave's MFMAs a packed fp32 VALU costs more than its two scalar halves (MI355X_MICROARCH.md price list) and hipcc
+                // SLP-packs plain C; its hazard recogniser does not see through inline asm, so no VALU consumes a v_exp_f32 result
+                // closer than eight instructions behind it (gfx940+ trans-use hazard needs one)
+                float x[8];
+                // ... nor through the MFMA -> VALU read-after-write hazard: the S / G accumulators were written by MFMAs that
+                // may have issued a few cycles ago, and a 16-pass MFMA result needs 18 wait states before a VALU may read it
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 15\n\ts_nop 3");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (STAT_Y) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(x[j]) : "v"(sv[rb + j]), "s"(p.sc), "v"(lv[j]));
+                    else asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(x[j]) : "v"(sv[rb + j]), "s"(p.sc), "v"(lse_x));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("v_exp_f32 %0, %1" : "=v"(x[j]) : "v"(x[j]));
+                if constexpr (HAS_G) {
+                    float tt[8], nd = 0.f;
+                    if constexpr (!STAT_Y) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(nd) : "s"(p.scale), "v"(delta_x));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if constexpr (STAT_Y) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(nd) : "s"(p.scale), "v"(dv[j]));
+                        asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(tt[j]) : "v"(gv[rb + j]), "s"(p.scale), "v"(nd));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x[j]) : "v"(x[j]), "v"(tt[j]));
+                } else {
+                    asm volatile("s_nop 1");
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float pv = x[j];
+                    if constexpr (STAT_Y) {
+                        if (!xvalid) pv = 0.f;
+                    } else {
+                        if (y0 + yb + j >= p.LY) pv = 0.f;
+                    }
+                    out[j] = (T)pv;
+                }
+                return out;
+            }
             // two elements per instruction wherever the ISA has a packed fp32 form (v_pk_fma_f32 / v_pk_mul_f32); only
             // the exp2 is scalar.  dS = P * (G * scale - delta * scale)
-            bf16x8 out;
             const f32x2 sc2 = {p.sc, p.sc}, scale2 = {p.scale, p.scale};
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
@@ -322,14 +364,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
 
 template <int MODE>
 int launch_bwd128(const BwdArgs& p, hipStream_t st, int nsplit) {
+    static int smx = -1;
+    if (smx < 0) { const char* v = getenv("M4D_ATTN_BWD_SMX"); smx = v ? atoi(v) : 1; }
     constexpr int STAGE = (MODE == BWD_DV ? 32768 : 49152) + (MODE == BWD_DQ ? 0 : 512);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess)
             return -3;
+        hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
         configured = true;
     }
     dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B), (unsigned)nsplit), block(512);
-    hipLaunchKernelGGL((attn_bwd128_kernel<MODE>), grid, block, 2 * STAGE, st, p);
+    if (smx == 1) hipLaunchKernelGGL((attn_bwd128_kernel<MODE, 1>), grid, block, 2 * STAGE, st, p);
+    else hipLaunchKernelGGL((attn_bwd128_kernel<MODE, 0>), grid, block, 2 * STAGE, st, p);
     return 0;
 }

@@ -50,6 +50,7 @@ template <int J, int END> M4D_DEV void m_prefetch(bf16x8 (&ring)[8], const unsig
     if constexpr (J < END) { m_read<J>(ring, va, ka); m_prefetch<J + 1, END>(ring, va, ka); }
 }
 
+template <int SMX>   // softmax arithmetic: 0 = packed fp32 (v_pk_fma_f32 / v_pk_add_f32), 1 = scalar v_fma_f32 / v_add_f32 (A/B)
 __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
     typedef bf16_t T;
     constexpr int D = 128, KVB = 64, STAGE = 32768, VOFF = 16384, QB = 256, NST = 4;
@@ -219,21 +220,49 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         }
         // p = exp2(s * sc - m): the multiply-subtract and the row sum run two elements per instruction (v_pk_fma_f32 /
         // v_pk_add_f32); only the 32 v_exp_f32 are scalar
-        const f32x2 sc2 = {p.sc, p.sc}, nm2 = {-m_run, -m_run};
-        f32x2 ps2 = {0.f, 0.f};
+        if constexpr (SMX == 0) {
+            const f32x2 sc2 = {p.sc, p.sc}, nm2 = {-m_run, -m_run};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 x = {s[sub][r], s[sub][r + 1]};
-                x = __builtin_elementwise_fma(x, sc2, nm2);
-                x[0] = __builtin_amdgcn_exp2f(x[0]);
-                x[1] = __builtin_amdgcn_exp2f(x[1]);
-                s[sub][r] = x[0];
-                s[sub][r + 1] = x[1];
-                ps2 += x;
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 x = {s[sub][r], s[sub][r + 1]};
+                    x = __builtin_elementwise_fma(x, sc2, nm2);
+                    x[0] = __builtin_amdgcn_exp2f(x[0]);
+                    x[1] = __builtin_amdgcn_exp2f(x[1]);
+                    s[sub][r] = x[0];
+                    s[sub][r + 1] = x[1];
+                    ps2 += x;
+                }
+            l_run += ps2[0] + ps2[1];
+        } else {
+            // single-issue forms pinned by inline asm (hipcc SLP-packs adjacent scalar f32 ops into v_pk_* otherwise).  The
+            // whole stream is volatile asm in a fixed order: hipcc's hazard recogniser does not see through inline asm, and
+            // a VALU that consumes a transcendental's result needs one other instruction in between (gfx940+ trans-use
+            // hazard) — here every v_add_f32 trails its v_exp_f32 by four instructions.
+            const float nm = -m_run;
+            float pa = 0.f, pb = 0.f;
+#define M4D_SM_A(SUB, R) do { asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s[SUB][R]) : "v"(s[SUB][R]), "s"(p.sc), "v"(nm)); \
+                              asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(s[SUB][(R) + 1]) : "v"(s[SUB][(R) + 1]), "s"(p.sc), "v"(nm)); } while (0)
+#define M4D_SM_B(SUB, R) do { asm volatile("v_exp_f32 %0, %1" : "=v"(s[SUB][R]) : "v"(s[SUB][R])); \
+                              asm volatile("v_exp_f32 %0, %1" : "=v"(s[SUB][(R) + 1]) : "v"(s[SUB][(R) + 1])); } while (0)
+#define M4D_SM_C(SUB, R) do { asm volatile("v_add_f32 %0, %1, %2" : "=v"(pa) : "v"(pa), "v"(s[SUB][R])); \
+                              asm volatile("v_add_f32 %0, %1, %2" : "=v"(pb) : "v"(pb), "v"(s[SUB][(R) + 1])); } while (0)
+            M4D_SM_A(0, 0); M4D_SM_B(0, 0);
+#pragma unroll
+            for (int i = 1; i < 16; ++i) {          // pair i = (sub i >> 3, r = 2 * (i & 7))
+                M4D_SM_A(i >> 3, 2 * (i & 7));
+                M4D_SM_B(i >> 3, 2 * (i & 7));
+                M4D_SM_C((i - 1) >> 3, 2 * ((i - 1) & 7));
             }
-        l_run += ps2[0] + ps2[1];
+            asm volatile("s_nop 1");
+            M4D_SM_C(1, 14);
+#undef M4D_SM_A
+#undef M4D_SM_B
+#undef M4D_SM_C
+            l_run += pa + pb;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) pf[c] = pack8<T>(s[c >> 1], (c & 1) * 8);
     };
