@@ -548,16 +548,21 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
             static bool configured = false;
             if (!configured) {
-                if (hipFuncSetAttribute((const void*)attn128p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
-                hipFuncSetAttribute((const void*)attn128p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                if (hipFuncSetAttribute((const void*)attn128p_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
+                hipFuncSetAttribute((const void*)attn128p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                hipFuncSetAttribute((const void*)attn128p_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                hipFuncSetAttribute((const void*)attn128p_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
                 configured = true;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
-            static int smx = -1;
+            static int smx = -1, prio = -1;
             if (smx < 0) { const char* v = getenv("M4D_ATTN_SMX"); smx = v ? atoi(v) : 1; }   // 1 = scalar softmax arithmetic (default: +9 % sustained over the packed form), 0 = packed
+            if (prio < 0) { const char* v = getenv("M4D_ATTN_PRIO"); prio = v ? atoi(v) : 1; }
             const dim3 gp((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
-            if (smx == 1) hipLaunchKernelGGL(attn128p_kernel<1>, gp, dim3(512), 4 * 32768, st, q);
-            else hipLaunchKernelGGL(attn128p_kernel<0>, gp, dim3(512), 4 * 32768, st, q);
+            if (smx == 0) hipLaunchKernelGGL((attn128p_kernel<0, 1>), gp, dim3(512), 4 * 32768, st, q);
+            else if (prio == 0) hipLaunchKernelGGL((attn128p_kernel<1, 0>), gp, dim3(512), 4 * 32768, st, q);
+            else if (prio == 2) hipLaunchKernelGGL((attn128p_kernel<1, 2>), gp, dim3(512), 4 * 32768, st, q);
+            else hipLaunchKernelGGL((attn128p_kernel<1, 1>), gp, dim3(512), 4 * 32768, st, q);
         } else if (w8) {
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             hipLaunchKernelGGL(attn128_kernel<8>, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(512), 0, st, q);

@@ -50,7 +50,9 @@ template <int J, int END> M4D_DEV void m_prefetch(bf16x8 (&ring)[8], const unsig
     if constexpr (J < END) { m_read<J>(ring, va, ka); m_prefetch<J + 1, END>(ring, va, ka); }
 }
 
-template <int SMX>   // softmax arithmetic: 0 = packed fp32 (v_pk_fma_f32 / v_pk_add_f32), 1 = scalar v_fma_f32 / v_add_f32 (A/B)
+// SMX: softmax arithmetic, 0 = packed fp32 (v_pk_fma_f32 / v_pk_add_f32), 1 = scalar v_fma_f32 / v_add_f32 (default)
+// PRIO: 0 = no s_setprio, 1 = raised priority around every MFMA phase (default), 2 = static: the younger wave group at priority 1
+template <int SMX, int PRIO>
 __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
     typedef bf16_t T;
     constexpr int D = 128, KVB = 64, STAGE = 32768, VOFF = 16384, QB = 256, NST = 4;
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         M4D_QK_TILE(0);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ka[kk] += STAGE;                    // K side now points at tile 1 (stage 1)
+        if constexpr (PRIO == 2) { if (grp == 1) __builtin_amdgcn_s_setprio(1); }
         if (grp == 1) __builtin_amdgcn_s_barrier();                        // group 1 runs one barrier behind group 0
 #define M4D_V_PHASE()                                                                                                 \
     do {                                                                                                             \
@@ -340,10 +343,10 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
             if (i + 3 < NT) dma_tile((i + 3) & 3, (int64_t)(i + 3) * KVB);
             __builtin_amdgcn_sched_barrier(0);
             m_prefetch<4, 8>(ring, va, ka);
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
             if (!(p.abl & 2)) m_steps<0, 32>(ring, va, ka, pf, qf, o, s);
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
             {   // advance the fragment addresses one stage (mod 4): va -> tile i+1, ka -> tile i+2
                 const unsigned dv = ((i + 1) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);
                 const unsigned dk = ((i + 2) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);
@@ -361,13 +364,14 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         // ---- last tile: V(NT-1), then PV only ----
         M4D_V_PHASE();
         m_prefetch<4, 8>(ring, va, ka);
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
         m_steps<0, 16>(ring, va, ka, pf, qf, o, s);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
 #undef M4D_V_PHASE
         if (grp == 0) __builtin_amdgcn_s_barrier();                        // balance the barrier count
+        if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     }
 #undef M4D_PV_TILE
 #undef M4D_PV_PREFETCH
