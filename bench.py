@@ -290,7 +290,7 @@ def main():
                 "launches": gk.get("launches", 0), "avg_launch_ms": gk.get("ms", 0.0) / max(1, gk.get("launches", 1)),
                 "share_of_step_time": gk.get("ms", 0.0) / (dt * 1e3),
                 "traffic_note": "PMC passes are separate rocprofv3 runs (tools/prof.sh), not collected inside bench.py: "
-                                "profiles/r01j_pmc_summary.md — FETCH_SIZE 2.79 GiB (x2-corrected) + WRITE_SIZE 0.36 GiB per launch, "
+                                "profiles/r01k_pmc_summary.md — FETCH_SIZE 2.79 GiB (x2-corrected) + WRITE_SIZE 0.36 GiB per launch, "
                                 "MFMA pipe busy 58.7 % of SIMD cycles",
             }
             ak = ks.get("attention", {})
