@@ -197,7 +197,12 @@ def main():
     if world > 1:
         from more4d_amd.dist import get_cfg_parallel_rank, init_sequence_parallel
         cfgp = args.parallelism == "cfg-sp" or (args.parallelism == "auto" and world % 2 == 0)
-        init_sequence_parallel(cfg_parallel=cfgp)
+        try:
+            init_sequence_parallel(cfg_parallel=cfgp)
+        except Exception as ex:     # sub-group creation failed identically on every rank: plain T-sharding over WORLD
+            if rank == 0:
+                print(f"[bench] cfg-parallel groups unavailable ({ex!r}); falling back to sp{world}", file=sys.stderr)
+            init_sequence_parallel(cfg_parallel=False)
         model.enable_multi_gpus_inference()
         branch = get_cfg_parallel_rank()
 
