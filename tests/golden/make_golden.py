@@ -239,6 +239,20 @@ def make_omnimae(ref):
     npz_save("omnimae.npz", frame=frame, feats=feats, cls=cls, pos_head=pos[0, :4, :8], pos_tail=pos[0, 190:196, 760:])
 
 
+def make_teacache_coeffs(ref):
+    """get_teacache_coefficients of the reference (cache_utils.py:4-16) for the model names of the released checkpoints and a few
+    near misses: the product's table is pinned to it (tests/test_host_logic.py)."""
+    import json
+    cu = sys.modules["MoRe4D.models.cache_utils"]
+    names = ["Wan2.1-Fun-V1.1-14B-Control", "Wan2.1-Fun-14B-InP", "Wan2.1-T2V-1.3B", "Wan2.1-Fun-V1.1-1.3B-Control", "Wan2.1-T2V-14B",
+             "Wan2.1-I2V-14B-480P", "Wan2.1-I2V-14B-720P", "Wan2.2-Fun-A14B-Control", "Wan2.2-TI2V-5B", "models/Wan2.1-Fun-V1.1-14B-Control/",
+             "SomethingElse-7B"]
+    out = {n: cu.get_teacache_coefficients(n) for n in names}
+    with open(os.path.join(HERE, "teacache_coeffs.json"), "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print("wrote teacache_coeffs.json", {k: (v[0] if v else None) for k, v in out.items()})
+
+
 def make_dit_ops(ref):
     """Per-op vectors: sinusoid, rope (incl. padded tail), rmsnorm, LN-modulate, SDPA,
     self-attn, cross-attn, block (with and without spatial guidance), head."""
@@ -506,6 +520,8 @@ if __name__ == "__main__":
         make_dit_ops(ref)
     if what in ("grads", "all"):
         make_dit_grads(ref)
+    if what in ("teacache", "all"):
+        make_teacache_coeffs(ref)
     if what in ("omnimae", "all"):
         make_omnimae(ref)
     if what in ("guidgrads", "all"):

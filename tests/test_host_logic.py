@@ -4,6 +4,7 @@ by tests/cpu_ops.py (test-only stand-in; the product has no CPU path)."""
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -449,3 +450,22 @@ def test_bench_flop_accounting_matches_survey():
     g2, a2 = bench.flops_per_forward(bench.CFG_14B, 21840, 2)
     assert abs((g2 + a2) / 1e12 - 1853.4) < 1.0
     assert bench.MFMA_BF16_PEAK_TF == 2500.0
+
+
+def test_teacache_coefficients_match_reference():
+    """The TeaCache rescaling polynomial per model name == the reference's get_teacache_coefficients (fixture generated from it)."""
+    import json
+    from more4d_amd.models.cache_utils import TeaCache, get_teacache_coefficients
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teacache_coeffs.json")))
+    for name, coeff in ref.items():
+        assert get_teacache_coefficients(name) == coeff, name
+    assert ref["Wan2.1-Fun-V1.1-14B-Control"] is None      # the reference's table does not know its own released checkpoint name
+    tc = TeaCache(ref["Wan2.1-Fun-14B-InP"], num_steps=50, rel_l1_thresh=0.1, num_skip_start_steps=5)
+    assert tc.cnt == 0 and tc.should_calc and tc.previous_residual_cond is None and abs(float(tc.rescale_func(0.1)) - float(
+        np.polyval(ref["Wan2.1-Fun-14B-InP"], 0.1))) < 1e-12
+    tc.cnt = 7
+    tc.reset()
+    assert tc.cnt == 0
+    for bad in (dict(num_steps=0), dict(num_steps=5, rel_l1_thresh=-1.0), dict(num_steps=5, num_skip_start_steps=6)):
+        with pytest.raises(ValueError):
+            TeaCache([1.0, 0.0], **bad)
