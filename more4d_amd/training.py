@@ -41,9 +41,13 @@ def adaptive_max_grad_norm(total_norm, max_grad_norm, initial_grad_norm_ratio, a
 
 
 def train_step(model, optimizer, *, latents, noise, sigmas, timesteps, forward_kwargs, global_step=0, max_grad_norm=0.05,
-               initial_grad_norm_ratio=5.0, abnormal_norm_clip_start=1000, motion_sub_loss_ratio=None, params=None):
+               initial_grad_norm_ratio=5.0, abnormal_norm_clip_start=1000, motion_sub_loss_ratio=None, params=None,
+               abnormal_loss=0.25, abnormal_loss_start=50):
     """One optimisation step.  `model` may be the bare WanTransformer4DModel or its DDP wrapper; returns
-    (loss, total_grad_norm, actual_max_grad_norm).  The one host sync is the adaptive-clip decision (as in :1996)."""
+    (loss, total_grad_norm, actual_max_grad_norm).  Host syncs: the abnormal-loss check (:1977-1985: after step 50 an
+    update whose process-averaged loss exceeds 0.25 is skipped — returned norms are None) and the adaptive-clip decision
+    (:1996).  The loss weighting of :1964 is diffusers' compute_loss_weighting_for_sd3; the released recipe leaves it at
+    its default scheme ("none" = 1)."""
     params = list(params) if params is not None else [p for p in model.parameters() if p.requires_grad]
     noisy, target = add_noise(latents, noise, sigmas)
     pred = model(x=noisy.to(next(iter(params)).dtype), t=timesteps, **forward_kwargs)
@@ -52,6 +56,14 @@ def train_step(model, optimizer, *, latents, noise, sigmas, timesteps, forward_k
         sub = torch.nn.functional.mse_loss(pred[:, 1:].float() - pred[:, :-1].float(),
                                            target[:, 1:].float() - target[:, :-1].float())
         loss = loss * (1 - motion_sub_loss_ratio) + sub * motion_sub_loss_ratio
+    if abnormal_loss is not None and global_step > abnormal_loss_start:
+        avg = loss.detach().clone()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(avg)
+            avg /= torch.distributed.get_world_size()
+        if float(avg) > abnormal_loss:
+            optimizer.zero_grad(set_to_none=True)
+            return loss.detach(), None, None
     loss.backward()
     total = float(grad_norm(params))
     actual = adaptive_max_grad_norm(total, max_grad_norm, initial_grad_norm_ratio, abnormal_norm_clip_start, global_step)

@@ -149,6 +149,12 @@ def test_train_step_host_logic(monkeypatch):
     losses = [float(training.train_step(m, opt, latents=lat, noise=noise, sigmas=sig, timesteps=sig * 1000,
                                         forward_kwargs=kw, global_step=i)[0]) for i in range(3)]
     assert losses[2] < losses[0]
+    # abnormal-loss skip (train_wan.py:1977-1985): after step 50 a loss above 0.25 leaves the parameters untouched
+    before = [p_.detach().clone() for p_ in m.parameters()]
+    res = training.train_step(m, opt, latents=lat, noise=noise, sigmas=sig, timesteps=sig * 1000, forward_kwargs=kw,
+                              global_step=60)
+    assert float(res[0]) > 0.25 and res[1] is None and res[2] is None
+    assert all(torch.equal(a, b) for a, b in zip(before, m.parameters())) and all(p_.grad is None for p_ in m.parameters())
     noisy, target = training.add_noise(lat, noise, sig)
     assert torch.allclose(noisy[0], 0.3 * lat[0] + 0.7 * noise[0]) and torch.equal(target, noise - lat)
 
