@@ -239,6 +239,18 @@ def make_omnimae(ref):
     npz_save("omnimae.npz", frame=frame, feats=feats, cls=cls, pos_head=pos[0, :4, :8], pos_tail=pos[0, 190:196, 760:])
 
 
+def make_riflex(ref):
+    """RIFLEx temporal RoPE table (get_1d_rotary_pos_embed_riflex, wan_transformer4d.py:264-321; enable_riflex :1011-1025) for the
+    tiny config's head dim 32 and the 14B head dim 128: sampled rows of the complex table."""
+    out = {}
+    for d in (32, 128):
+        da = d - 4 * (d // 6)
+        f = ref.dit.get_1d_rotary_pos_embed_riflex(1024, da, use_real=False, k=6 if d == 128 else 2, L_test=66, L_test_scale=4.886)
+        rows = torch.tensor([0, 1, 65, 66, 1023])
+        out[f"re{d}"], out[f"im{d}"] = f[rows].real, f[rows].imag
+    npz_save("riflex.npz", **out)
+
+
 def make_teacache_coeffs(ref):
     """get_teacache_coefficients of the reference (cache_utils.py:4-16) for the model names of the released checkpoints and a few
     near misses: the product's table is pinned to it (tests/test_host_logic.py)."""
@@ -520,6 +532,8 @@ if __name__ == "__main__":
         make_dit_ops(ref)
     if what in ("grads", "all"):
         make_dit_grads(ref)
+    if what in ("riflex", "all"):
+        make_riflex(ref)
     if what in ("teacache", "all"):
         make_teacache_coeffs(ref)
     if what in ("omnimae", "all"):

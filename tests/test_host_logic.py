@@ -469,3 +469,20 @@ def test_teacache_coefficients_match_reference():
     for bad in (dict(num_steps=0), dict(num_steps=5, rel_l1_thresh=-1.0), dict(num_steps=5, num_skip_start_steps=6)):
         with pytest.raises(ValueError):
             TeaCache([1.0, 0.0], **bad)
+
+
+def test_riflex_table_matches_reference():
+    """enable_riflex (reference :1011-1025 / :264-321): the edited temporal frequency table, sampled rows (tests/golden/riflex.npz)."""
+    from more4d_amd.models import WanTransformer4DModel
+    z = load_npz("riflex.npz")
+    rows = torch.tensor([0, 1, 65, 66, 1023])
+    for d, heads, k in ((32, 4, 2), (128, 1, 6)):
+        m = WanTransformer4DModel(**dict(TINY, dim=d * heads, num_heads=heads, ffn_dim=64, num_layers=1))
+        base = m.freqs.clone()
+        m.enable_riflex(k=k, L_test=66, L_test_scale=4.886)
+        da = d - 4 * (d // 6)
+        got = m.freqs[rows, :da // 2]
+        assert rel_err(got.real, z[f"re{d}"]) < 1e-12 and rel_err(got.imag, z[f"im{d}"]) < 1e-12
+        assert torch.equal(m.freqs[:, da // 2:], base[:, da // 2:])          # spatial axes untouched
+        m.disable_riflex()
+        assert torch.equal(m.freqs, base)
