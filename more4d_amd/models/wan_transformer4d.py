@@ -943,11 +943,9 @@ class WanTransformer4DModel(nn.Module):
             if isinstance(m, nn.Linear):
                 nn.init.normal_(m.weight, std=.02)
         nn.init.zeros_(self.head.head.weight)
-        for b in self.blocks:
-            for g in (b.spatial_guidance_self, b.spatial_guidance_ffn):
-                if g is not None:
-                    nn.init.zeros_(g.spatial_guide[-1].weight)
-                    nn.init.zeros_(g.spatial_guide[-1].bias)
+        # NB: like in the reference, this pass also re-initialises the Linear of every SpatialGuidanceModule that its own
+        # constructor had zeroed (:750-751): a fresh model starts with Xavier scale/shift projections behind zero gates —
+        # with both at zero neither would ever receive a gradient.
 
     @classmethod
     def from_pretrained(cls, pretrained_model_path, subfolder=None, transformer_additional_kwargs={},
