@@ -368,6 +368,15 @@ class DiagonalGaussianDistribution:
         self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
         self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
         self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def kl(self, other=None):
+        """KL to the standard normal (or to `other`), summed over dims [1, 2, 3] exactly like the published class does —
+        for the 5-D video latents this leaves the last axis, which train_vae.py:183 then sums itself."""
+        if other is None:
+            return 0.5 * torch.sum(self.mean.float().pow(2) + self.var.float() - 1.0 - self.logvar.float(), dim=[1, 2, 3])
+        return 0.5 * torch.sum((self.mean.float() - other.mean.float()).pow(2) / other.var.float() + self.var.float() / other.var.float()
+                               - 1.0 - self.logvar.float() + other.logvar.float(), dim=[1, 2, 3])
 
     def sample(self, generator=None):
         eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device if generator is None or
