@@ -315,3 +315,42 @@ def test_token_sharded_local_first_schedule_single_gpu():
                 c = _Ctx(B, L, Ls, grid, cos, sin, max(0, min(Ls, L - r * Ls)), {}, L, sp, r * Ls)
                 sa.run(xn[:, r * Ls:(r + 1) * Ls].contiguous(), out, gate, C, c)
                 assert rel_err(out.cpu(), full[:, r * Ls:(r + 1) * Ls].cpu()) < 1e-5, (local_first, r)
+
+
+def test_pipeline_call_end_to_end():
+    """WanFunControlPipeline.__call__ (reference :477-858) with the tiny DiT and the full-size VAE network on small frames:
+    control / depth / reference-image VAE encodes -> 48-channel control input -> CFG denoise loop -> decode.  The result must
+    equal the same stages composed by hand (conditioning order [control | start-image zeros | depth], :762-777; ref latent =
+    frame 0, :722), and the decoded video stays in [-1, 1]."""
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    from more4d_amd.pipeline import WanFunControlPipeline, denoise_latents
+    from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+    m = tiny_model()
+    vae = AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(load_keys("vae_keys.json"), 2024))
+    vae = vae.to(DEV, torch.float32)
+    g = torch.Generator().manual_seed(5)
+    F_, H_, W_ = 5, 32, 32
+    control = torch.rand(1, 3, F_, H_, W_, generator=g) * 2 - 1
+    depth = torch.rand(1, 3, 1, H_, W_, generator=g) * 2 - 1
+    ref = torch.rand(1, 3, 1, H_, W_, generator=g) * 2 - 1
+    lat0 = torch.randn(1, 16, 2, 4, 4, generator=g)
+    pe, ne = [torch.randn(9, 64, generator=g)], [torch.randn(3, 64, generator=g)]
+    clip = torch.randn(1, 257, 1280, generator=g)
+    pipe = WanFunControlPipeline(vae=vae, transformer=m, scheduler=FlowDPMSolverMultistepScheduler(solver_order=1, shift=1.0))
+    kw = dict(height=H_, width=W_, control_video=control, ref_image=ref, depth_image=depth, num_frames=F_, num_inference_steps=3,
+              guidance_scale=6.0, latents=lat0, prompt_embeds=[p.to(DEV) for p in pe], negative_prompt_embeds=[p.to(DEV) for p in ne],
+              clip_context=clip.to(DEV), shift=5)
+    out = pipe(output_type="latent", **kw).videos
+    with torch.no_grad():
+        enc = lambda v: vae.encode(v.to(DEV))[0].mode()
+        ctrl, dl, rl = enc(control), enc(depth.repeat(1, 1, F_, 1, 1)), enc(ref)[:, :, 0]
+        y = torch.cat([ctrl, torch.zeros_like(ctrl), dl], dim=1)
+        sch = FlowDPMSolverMultistepScheduler(solver_order=1, shift=1.0)
+        ts, _ = retrieve_timesteps(sch, device=DEV, sigmas=get_sampling_sigmas(3, 5))
+        want = denoise_latents(m, sch, lat0, ts, 6.0, [ne[0].to(DEV), pe[0].to(DEV)], clip_fea=clip.to(DEV), y=y, full_ref=rl)
+    assert out.shape == (1, 16, 2, 4, 4) and rel_err(out.cpu(), want.cpu()) < 1e-6
+    vid = pipe(output_type="no_normalize", **kw).videos
+    assert vid.shape == (1, 3, F_, H_, W_) and bool(torch.isfinite(vid).all()) and float(vid.abs().max()) <= 1.0
+    vid01 = pipe(output_type="numpy", **kw).videos
+    assert rel_err(vid01, (vid / 2 + 0.5).clamp(0, 1)) < 1e-6
