@@ -45,3 +45,20 @@ def test_adaptors_host_logic(monkeypatch):
         with torch.no_grad():
             out = m(z["x"])
         assert rel_err(out, z["out"]) < 2e-5, name
+
+
+def test_vae_from_pretrained_checkpoint_formats(tmp_path):
+    """AutoencoderKLWan.from_pretrained (reference wan_vae.py:849-871): the Wan2.1_VAE.pth layout (keys WITHOUT the `model.`
+    prefix the wrapper adds, :864-868), as .pth and as .safetensors."""
+    from safetensors.torch import save_file
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    sd = fill(load_keys("vae_keys.json"), 2024)
+    raw = {k[len("model."):]: v for k, v in sd.items()}
+    assert len(raw) == len(sd) == 194
+    torch.save(raw, tmp_path / "Wan2.1_VAE.pth")
+    save_file({k: v.contiguous() for k, v in raw.items()}, str(tmp_path / "vae.safetensors"))
+    for name in ("Wan2.1_VAE.pth", "vae.safetensors"):
+        vae = AutoencoderKLWan.from_pretrained(str(tmp_path / name), additional_kwargs={"latent_channels": 16})
+        got = vae.state_dict()
+        assert all(torch.equal(got[k], v) for k, v in sd.items())
+        assert vae.latent_channels == 16 and vae.config.temporal_compression_ratio == 4 and vae.spatial_compression_ratio == 8
