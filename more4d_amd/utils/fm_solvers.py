@@ -70,10 +70,51 @@ class FlowDPMSolverMultistepScheduler:
         self.timesteps = None
         self.sigmas = None
         self._step_index = None
+        self._begin_index = None
+        self.order = 1                  # the pipeline's warm-up arithmetic reads scheduler.order (:742)
+        self.init_noise_sigma = 1.0
+        # diffusers' ConfigMixin surface the callers touch (`scheduler.config.num_train_timesteps`, `.shift`)
+        self.config = type("Config", (dict,), {"__getattr__": dict.__getitem__})(
+            num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type, shift=shift,
+            use_dynamic_shifting=use_dynamic_shifting, final_sigmas_type=final_sigmas_type, algorithm_type=algorithm_type,
+            solver_type=solver_type, lower_order_final=lower_order_final, euler_at_final=euler_at_final, thresholding=thresholding)
+
+    def __len__(self):
+        return self.num_train_timesteps
 
     @property
     def step_index(self):
         return self._step_index
+
+    @property
+    def begin_index(self):
+        return self._begin_index
+
+    def set_begin_index(self, begin_index: int = 0):
+        """Start the step counter at `begin_index` instead of looking the first timestep up (reference :216-224)."""
+        self._begin_index = begin_index
+
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        """Index of `timestep` in the schedule; with duplicates the SECOND match, so that a loop entering mid-schedule does not
+        skip a sigma (reference :679-691)."""
+        sched = self.timesteps if schedule_timesteps is None else schedule_timesteps
+        idx = (sched.cpu() == int(timestep)).nonzero()
+        return int(idx[1 if len(idx) > 1 else 0])
+
+    def add_noise(self, original_samples, noise, timesteps):
+        """alpha_t x + sigma_t noise with (alpha, sigma) = (1 - s, s) of the schedule entry of each timestep (reference :815-854,
+        _sigma_to_alpha_sigma_t :333-335): img2img / in-painting entry points."""
+        sig = self.sigmas.to(device=original_samples.device, dtype=original_samples.dtype)
+        if self._begin_index is None:
+            steps = [self.index_for_timestep(t) for t in timesteps]
+        elif self._step_index is not None:
+            steps = [self._step_index] * timesteps.shape[0]
+        else:
+            steps = [self._begin_index] * timesteps.shape[0]
+        s_ = sig[steps].flatten()
+        while s_.dim() < original_samples.dim():
+            s_ = s_.unsqueeze(-1)
+        return (1 - s_) * original_samples + s_ * noise
 
     def set_timesteps(self, num_inference_steps: Union[int, None] = None, device=None,
                       sigmas: Optional[List[float]] = None, mu=None, shift: Optional[float] = None):
@@ -88,11 +129,15 @@ class FlowDPMSolverMultistepScheduler:
         self.timesteps = torch.from_numpy(timesteps).to(device=device, dtype=torch.int64)  # truncation, :276-277
         self.num_inference_steps = len(timesteps)
         self._step_index = None
+        self._begin_index = None
         self._sig64 = np.concatenate([sigmas, [0.0]]).astype(np.float32).astype(np.float64)   # the float32 table, in float64
         self.model_outputs = []          # data predictions x0 = x - sigma v of the last <= solver_order steps (float32)
         self.lower_order_nums = 0
 
     def _init_step_index(self, timestep):
+        if self._begin_index is not None:
+            self._step_index = self._begin_index
+            return
         t = int(timestep)
         idx = (self.timesteps.cpu() == t).nonzero()
         self._step_index = int(idx[1 if len(idx) > 1 else 0]) if len(idx) else len(self.timesteps) - 1

@@ -467,6 +467,27 @@ def make_sched(ref):
              sampling_sigmas=sig)
 
 
+def make_sched_api(ref):
+    """The scheduler's img2img / mid-schedule entry points (fm_solvers.py:216-224 set_begin_index, :679-704 index_for_timestep /
+    _init_step_index, :815-854 add_noise, :856 __len__) on the 50-step shift-5 schedule."""
+    sch = ref.fm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+    sch.set_timesteps(sigmas=ref.fm.get_sampling_sigmas(50, 5.0))
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 16, 2, 4, 4, generator=g)
+    n = torch.randn(2, 16, 2, 4, 4, generator=g)
+    ts = sch.timesteps[[3, 17]]
+    out = dict(x=x, n=n, ts=ts, noisy_lookup=sch.add_noise(x, n, ts), length=np.int64(len(sch)),
+               idx=np.array([sch.index_for_timestep(t) for t in ts]))
+    sch.set_begin_index(10)
+    out["noisy_begin"] = sch.add_noise(x, n, ts)                       # before the first step: sigma of begin_index for every sample
+    v = torch.randn(2, 16, 2, 4, 4, generator=g)
+    out["v"] = v
+    out["x_step"] = sch.step(v, sch.timesteps[10], x, return_dict=False)[0]   # step counter starts at begin_index
+    out["step_index_after"] = np.int64(sch.step_index)
+    out["noisy_mid"] = sch.add_noise(x, n, ts)                         # after a step: sigma of the current step index
+    npz_save("sched_api.npz", **out)
+
+
 def toy_velocity(x, t):
     """Deterministic stand-in for the DiT inside solver fixtures (smooth in x and t)."""
     return 0.3 * x + 0.1 * torch.sin(3.0 * x) + (float(t) / 1000.0 - 0.5)
@@ -548,5 +569,6 @@ if __name__ == "__main__":
         make_vae(ref)
     if what in ("sched", "all"):
         make_sched(ref)
+        make_sched_api(ref)
         make_sched_multistep(ref)
         make_sched_unipc(ref)

@@ -486,3 +486,21 @@ def test_riflex_table_matches_reference():
         assert torch.equal(m.freqs[:, da // 2:], base[:, da // 2:])          # spatial axes untouched
         m.disable_riflex()
         assert torch.equal(m.freqs, base)
+
+
+def test_scheduler_entry_points_match_reference(monkeypatch):
+    """set_begin_index / index_for_timestep / add_noise / __len__ / config of FlowDPMSolverMultistepScheduler against the
+    reference scheduler (tests/golden/sched_api.npz)."""
+    from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas
+    cpu_ops.install(monkeypatch)
+    z = load_npz("sched_api.npz")
+    sch = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+    sch.set_timesteps(sigmas=get_sampling_sigmas(50, 5.0))
+    assert len(sch) == int(z["length"]) and sch.config.num_train_timesteps == 1000 and sch.order == 1 and sch.begin_index is None
+    assert [sch.index_for_timestep(t) for t in z["ts"]] == z["idx"].tolist()
+    assert rel_err(sch.add_noise(z["x"], z["n"], z["ts"]), z["noisy_lookup"]) < 1e-6
+    sch.set_begin_index(10)
+    assert rel_err(sch.add_noise(z["x"], z["n"], z["ts"]), z["noisy_begin"]) < 1e-6
+    out = sch.step(z["v"], sch.timesteps[10], z["x"], return_dict=False)[0]
+    assert rel_err(out, z["x_step"]) < 1e-6 and sch.step_index == int(z["step_index_after"])
+    assert rel_err(sch.add_noise(z["x"], z["n"], z["ts"]), z["noisy_mid"]) < 1e-6
