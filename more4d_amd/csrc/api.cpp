@@ -6,7 +6,7 @@
 
 static thread_local char g_err[512] = "";
 
-extern "C" void m4d_set_error(const char* fmt, ...) {
+extern "C" __attribute__((visibility("hidden"))) void m4d_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);

@@ -74,7 +74,7 @@ M4D_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067
 M4D_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // ---- host-side error plumbing (api.cpp owns the storage) ----
-extern "C" void m4d_set_error(const char* fmt, ...);
+extern "C" __attribute__((visibility("hidden"))) void m4d_set_error(const char* fmt, ...);   // library-internal: not part of the ABI
 #define M4D_CHECK_ARG(cond, ...)                   \
     do {                                           \
         if (!(cond)) {                             \

@@ -31,6 +31,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} not exported"
     lib.m4d_version.restype = ctypes.c_int
     assert lib.m4d_version() >= 100
+    # ... and nothing else: the m4d_* dynamic symbols are exactly the header's entry points
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (m4d_[a-z0-9_]+)", nm))
+    assert exported == declared, exported ^ declared
     # every binding has exactly as many argtypes as the header declares parameters
     flat = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     for name, params in re.findall(r"\b(m4d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", flat):
