@@ -45,6 +45,9 @@ class AdamW(torch.optim.Optimizer):
                 lr = group["lr"]
                 ops.adamw_(p.data, g, st["exp_avg"], st["exp_avg_sq"], lr=float(lr), beta1=b1, beta2=b2, eps=group["eps"],
                            weight_decay=group["weight_decay"], step=st["step"], grad_scale=self._grad_scale)
+                # the kernel wrote through the raw pointer: tell torch, so that every (data_ptr, _version)-keyed cache of
+                # this parameter (fp32 copies, packed conv weights) is rebuilt and autograd sees the in-place update
+                torch.autograd.graph.increment_version(p)
         self._grad_scale = None
         return loss
 
@@ -63,11 +66,13 @@ def grad_norm(parameters):
     return acc.sqrt()
 
 
-def clip_grad_norm_(parameters, max_norm, optimizer=None):
+def clip_grad_norm_(parameters, max_norm, optimizer=None, total_norm=None):
     """accelerator.clip_grad_norm_ (:2009).  With a more4d_amd AdamW the coefficient is fused into the next step()
-    (no extra pass over 33 GB of gradients); otherwise the gradients are scaled in place.  Returns the total norm."""
+    (no extra pass over 33 GB of gradients); otherwise the gradients are scaled in place.  `total_norm`: the global norm
+    if the caller already has it (0-d device tensor from grad_norm) — the sum-of-squares pass is not repeated.
+    Returns the total norm."""
     parameters = [p for p in parameters if p.grad is not None]
-    total = grad_norm(parameters)
+    total = grad_norm(parameters) if total_norm is None else total_norm
     coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
     if isinstance(optimizer, AdamW):
         optimizer.set_grad_scale(coef.to(torch.float32).contiguous())

@@ -23,6 +23,7 @@ class WanPipelineOutput:
     videos: torch.Tensor
 
 
+@torch.no_grad()
 def denoise_latents(transformer, scheduler, latents, timesteps, guidance_scale, context, clip_fea=None, y=None,
                     full_ref=None, seq_len=None, first_frame_features=None, callback=None):
     """The 4D-STraG denoise loop on device.
@@ -133,6 +134,24 @@ class WanFunControlPipeline:
         return torch.randn(shape, generator=generator, dtype=torch.float32,
                            device=generator.device if generator is not None else "cpu").to(device)
 
+    def _prepare_timesteps(self, num_inference_steps, device, timesteps=None, shift=5):
+        """The reference's per-scheduler-type dispatch (:576-590): the diffusers-style Euler object shifts by its own
+        config.shift (`mu=1` only matters with dynamic shifting), UniPC takes (n, shift), the in-tree DPM-Solver takes the
+        pre-shifted `get_sampling_sigmas` table (its own shift stays 1)."""
+        from ..utils.flow_match_euler import FlowMatchEulerDiscreteScheduler
+        from ..utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+        sch = self.scheduler
+        if isinstance(sch, FlowMatchEulerDiscreteScheduler):
+            ts, _ = retrieve_timesteps(sch, num_inference_steps, device, timesteps, mu=1)
+        elif isinstance(sch, FlowUniPCMultistepScheduler):         # (a subclass of the DPM solver here: test it first)
+            sch.set_timesteps(num_inference_steps, device=device, shift=shift)
+            ts = sch.timesteps
+        elif isinstance(sch, FlowDPMSolverMultistepScheduler):
+            ts, _ = retrieve_timesteps(sch, device=device, sigmas=get_sampling_sigmas(num_inference_steps, shift))
+        else:
+            ts, _ = retrieve_timesteps(sch, num_inference_steps, device, timesteps)
+        return ts
+
     def _encode_control(self, video, device):
         """vae.encode(x)[0].mode() (reference prepare_control_latents :343-374)."""
         return self.vae.encode(video.to(device))[0].mode()
@@ -157,8 +176,7 @@ class WanFunControlPipeline:
                                     max_sequence_length, device)
         in_prompt_embeds = (ne + pe) if do_cfg else pe      # uncond first (:571)
         B = len(pe)
-        sig = get_sampling_sigmas(num_inference_steps, shift)
-        ts, _ = retrieve_timesteps(self.scheduler, device=device, sigmas=sig)
+        ts = self._prepare_timesteps(num_inference_steps, device, timesteps, shift)
         lat = self.prepare_latents(B, self.vae.config.latent_channels, num_frames, height, width, T, device,
                                    generator, latents)
         # control latents: [control video | start image (zeros) | depth] = 48 channels (:762-777)

@@ -65,9 +65,10 @@ def train_step(model, optimizer, *, latents, noise, sigmas, timesteps, forward_k
             optimizer.zero_grad(set_to_none=True)
             return loss.detach(), None, None
     loss.backward()
-    total = float(grad_norm(params))
+    total_dev = grad_norm(params)          # ONE sum-of-squares pass over the gradients; reused by the clip below
+    total = float(total_dev)
     actual = adaptive_max_grad_norm(total, max_grad_norm, initial_grad_norm_ratio, abnormal_norm_clip_start, global_step)
-    clip_grad_norm_(params, actual, optimizer=optimizer if isinstance(optimizer, AdamW) else None)
+    clip_grad_norm_(params, actual, optimizer=optimizer if isinstance(optimizer, AdamW) else None, total_norm=total_dev)
     optimizer.step()
     optimizer.zero_grad()
     return loss.detach(), total, actual

@@ -4,7 +4,11 @@ import numpy as np
 import torch
 
 
-def _second_half(v, half):
+def _second_half(v, half, members=False):
+    if members and isinstance(v, (list, tuple)):
+        # a tuple of batched tensors (first_frame_features = (patch [2B,..], cls [2B,..])): slice every member's batch axis;
+        # the reference passes one batched tensor `first_frame` here, which slices the same way (:25-30)
+        return type(v)(u[half:] for u in v)
     if hasattr(v, "slice_batch"):          # ContextCache
         return v.slice_batch(half)
     if isinstance(v, (torch.Tensor, list, tuple, np.ndarray)):
@@ -22,7 +26,7 @@ def cfg_skip():
                 half = int(bs // 2)
                 x = x[half:]
                 args = [_second_half(a, half) for a in args]
-                kwargs = {k: _second_half(v, half) for k, v in kwargs.items()}
+                kwargs = {k: _second_half(v, half, members=(k == "first_frame_features")) for k, v in kwargs.items()}
             result = func(self, x, *args, **kwargs)
             if skip:
                 result = torch.cat([result, result], dim=0)

@@ -215,7 +215,7 @@ class FlowDPMSolverMultistepScheduler:
         """CFG + solver step on the fp32 latent state, in place (pipeline :820-825).  Order 1: one fused kernel."""
         if self.solver_order == 1:
             return ops.cfg_euler_(latents_f32, v_pair, guidance_scale, self.dsigma(i), round_dtype)
-        vu, vc = v_pair[0].float().contiguous(), v_pair[1].float().contiguous()
+        vu, vc = (h.float().contiguous() for h in v_pair.chunk(2))      # [2B,...]: unconditional half, conditional half
         v = ops.lincomb([(1.0 - guidance_scale, vu), (guidance_scale, vc)])      # v_u + g (v_c - v_u)
         if round_dtype != torch.float32:
             v = v.to(round_dtype).float()

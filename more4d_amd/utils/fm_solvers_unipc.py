@@ -125,7 +125,7 @@ class FlowUniPCMultistepScheduler(FlowDPMSolverMultistepScheduler):
         return _SchedulerOutput(prev) if return_dict else (prev,)
 
     def step_cfg_(self, latents_f32, v_pair, guidance_scale, i, round_dtype=torch.float32):
-        vu, vc = v_pair[0].float().contiguous(), v_pair[1].float().contiguous()
+        vu, vc = (h.float().contiguous() for h in v_pair.chunk(2))      # [2B,...]: unconditional half, conditional half
         v = ops.lincomb([(1.0 - guidance_scale, vu), (guidance_scale, vc)])
         if round_dtype != torch.float32:
             v = v.to(round_dtype).float()
