@@ -151,6 +151,106 @@ def secondary_figures(model, cfg, dev):
     return out
 
 
+def standin_group(spw):
+    """A sequence-parallel group whose all-gather replicates the local shard: same shapes and kernels per rank, no xGMI traffic.
+    step time with the real group minus step time with this one = the exposed (un-hidden) part of the collectives."""
+    from more4d_amd.dist import SequenceParallelGroup
+
+    class _StandIn(SequenceParallelGroup):
+        def __init__(self):
+            self.group, self.world_size, self.rank = None, spw, 0
+
+        def all_gather(self, x, dim=1):
+            return torch.cat([x] * self.world_size, dim=dim)
+
+        def gather_start(self, x):
+            x = x.contiguous()
+            buf = torch.empty((self.world_size,) + tuple(x.shape), device=x.device, dtype=x.dtype)
+            buf.copy_(x.unsqueeze(0).expand_as(buf))     # every peer slot = a copy of the local shard (real values: power)
+            return buf, None, x
+    return _StandIn()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run, one rank per GPU
+    (the reference's multi-GPU entry is `accelerate launch`, train_wan.sh:9; inference wan_transformer4d.py:1187-1198)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(world, rank, local_rank):
+    """Bring the ranks up exactly as a measurement would (RCCL when GPUs are present, gloo otherwise), count them with an
+    all-reduce and print one JSON line on rank 0.  Runs in the GPU-less CPU suite at world 2."""
+    import torch.distributed as dist
+    gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    if world > 1:
+        if gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+        ones = torch.ones(1, device=torch.device("cuda", local_rank) if gpu else "cpu")
+        dist.all_reduce(ones)
+        n = int(ones.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        n = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": n, "backend": "nccl(RCCL)" if gpu else "gloo"}))
+    return 0
+
+
+def train_mode(args, world, rank, local_rank, dev, rccl_ranks, overrides):
+    """BASELINE configs[4]: one 14B DiT train step (fwd + recompute + bwd + clip + AdamW) per GPU at batch 1, data parallel over
+    the N ranks (weak scaling): value = samples/s of the whole job."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_train
+    cfg = dict(CFG_14B)
+    cfg["num_layers"] = args.layers
+    if args.guidance:
+        cfg["use_omnimae_guidance"] = True
+    model = build_model(cfg, dev, torch.bfloat16)
+    r = bench_train.run_train(model, cfg, dev, steps=args.steps, warmup=args.warmup, world=world, rank=rank, local_rank=local_rank,
+                              guidance=args.guidance)
+    dt = torch.tensor([r["value"]], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "4D-STraG train-step samples/sec (DiT fwd+bwd+AdamW), 49x480x832 bf16", "value": world / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[4]: Wan2.1-14B-shaped DiT train step, batch 1 per GPU, latent 1x16x13x60x104, L=21840 tokens "
+                                   "incl. the ref row, per-block recompute where activations are not stored, clip + AdamW (bf16 params "
+                                   "and state); random-init weights", "layers": args.layers, "parallelism": r["data_parallel"],
+                       "spatial_guidance": bool(args.guidance)},
+            "valid": args.layers == 40 and not overrides and math.isfinite(r["loss"]), "env_overrides": overrides,
+            "rccl_ranks": rccl_ranks, "collectives": exposed, "model_tflop_per_sample": r["model_tflop"], "mfma_frac_whole_step": r["mfma_frac"],
+            "max_mem_gb": r["max_mem_gb"], "stored_blocks": r["stored_blocks"], "loss": r["loss"],
+            "optimizer_state_gb_per_rank": r.get("optimizer_state_gb_per_rank")}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
+
+
+def m4d_overrides():
+    """A/B switches present in the environment: a run with any of them is not the shipping configuration."""
+    return sorted(k for k in os.environ if k.startswith("M4D_"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,28 +260,48 @@ def main():
     ap.add_argument("--no-ref", action="store_true", help="drop the reference-image row (L=20280)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-standin", action="store_true", help="N>1: skip the communication-free re-run that measures the exposed collectives")
     ap.add_argument("--guidance", action="store_true",
                     help="spatial guidance on (use_omnimae_guidance=True, synthetic OmniMAE patch features): the released 4D-STraG "
                          "checkpoint's configuration; the headline number is quoted without it (SURVEY 8d config 2)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary BASELINE.json figures (VAE round trip, train step) measured after the timed region")
+    ap.add_argument("--mode", choices=["denoise", "train"], default="denoise",
+                    help="denoise (default, BASELINE metric): the 4D-STraG denoise step, N>1 = T-sharded strong scaling; "
+                         "train: BASELINE configs[4], one DiT train step per GPU, N>1 = data parallel with bucketed gradient "
+                         "reduce-scatter + parameter all-gather over RCCL (weak scaling; value = samples/s)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring up the N ranks (RCCL on GPUs, gloo without), all-reduce a one per rank, print the count")
     ap.add_argument("--parallelism", choices=["auto", "sp", "cfg-sp"], default="auto",
                     help="N>1: 'sp' = all ranks shard the tokens of the CFG pair; 'cfg-sp' = the two CFG branches on the two "
                          "halves of the world, tokens sharded inside each half (auto: cfg-sp when N is even)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))       # plain `python bench.py --gpus N`: become the launcher of N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if args.launch_check:
+        return launch_check(world, rank, local_rank)
+    overrides = m4d_overrides()
+    from more4d_amd import _lib
+    if _lib.ABLATION_BUILD:
+        raise SystemExit("bench.py refuses the ablation build of the library (M4D_LIB=abl: kernels that skip work)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                           # proves every rank is on the RCCL communicator
+        rccl_ranks = int(ones.item())
+    if args.mode == "train":
+        return train_mode(args, world, rank, local_rank, dev, rccl_ranks, overrides)
 
     from more4d_amd import ops
     from more4d_amd.pipeline import denoise_latents
@@ -263,6 +383,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     ok = bool(torch.isfinite(x).all())
+    exposed = None
+    if world > 1 and not args.no_standin:
+        # the same steps once more with the collectives replaced by local copies (per-rank compute only)
+        import more4d_amd.dist as mdist
+        real_sp, real_rank, real_exchange = model._sp, model.sp_world_rank, mdist.cfg_exchange
+        if model.sp_world_size > 1:
+            model._sp, model.sp_world_rank = standin_group(model.sp_world_size), 0
+        mdist.cfg_exchange = lambda v: torch.cat([v, v])
+        try:
+            with torch.no_grad():
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run(args.warmup, args.steps, x)
+                torch.cuda.synchronize()
+                dts = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+            exposed = {"standin_ms_per_step": float(dts) / args.steps * 1e3,
+                       "exposed_collective_ms_per_step": (dt - float(dts)) / args.steps * 1e3,
+                       "note": "same ranks and shapes with every all-gather replaced by a local copy; max over ranks"}
+        except Exception as ex:
+            exposed = {"error": repr(ex)}
+        finally:
+            model._sp, model.sp_world_rank, mdist.cfg_exchange = real_sp, real_rank, real_exchange
 
     if rank == 0:
         gemm_fl, attn_fl = flops_per_forward(cfg, L, 2)
@@ -281,7 +425,8 @@ def main():
                            f"sp{world} (token/T-sharded, RCCL all-gather K,V^T)" if branch is None else
                            f"cfg2 x sp{world // 2} (CFG branches on the two halves; tokens T-sharded inside a half, RCCL "
                            "all-gather K,V^T; one velocity exchange per step)")},
-            "finite": ok, "valid": args.layers == 40 and ok,
+            "finite": ok, "valid": args.layers == 40 and ok and not overrides, "env_overrides": overrides,
+            "rccl_ranks": rccl_ranks, "collectives": exposed,
             "step_tflop": step_flops / 1e12,
             "mfma_frac_whole_step": step_flops / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TF * world),
         }

@@ -513,38 +513,46 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
 template <typename T>
 int launch(const AttnArgs& p, int D, hipStream_t st) {
     dim3 grid((unsigned)((int64_t)p.nq_tiles * p.heads * p.B)), block(256);
-    if (sizeof(T) == 2 && D == 128 && !getenv("M4D_ATTN_GENERIC")) {
+    M4D_ENV_ONCE(force_generic, "M4D_ATTN_GENERIC", 0);
+    M4D_ENV_ONCE(force_w4, "M4D_ATTN_W4", 0);
+    M4D_ENV_ONCE(force_lockstep, "M4D_ATTN_LOCKSTEP", 0);
+    if (sizeof(T) == 2 && D == 128 && !force_generic) {
         int64_t keys = 0;
         for (int i = 0; i < p.kv.nseg; ++i) keys += p.kv.len[i] > 0 ? p.kv.len[i] : 0;
         // 256-query workgroups (8 waves share each K/V tile) for long self-attention; short key loops (cross-attention)
         // keep the 4-wave workgroups (measured: 1000 vs 924 TF at Lk = 21840, 657 vs 678 TF at Lk = 512)
-        const bool w8 = p.Lq > 1024 && keys >= 2048 && !getenv("M4D_ATTN_W4");
+        const bool w8 = p.Lq > 1024 && keys >= 2048 && !force_w4;
         AttnArgs q = p;
         bool same_strides = true;     // the phased kernel shares one per-lane DMA offset across segments
         for (int i = 1; i < p.kv.nseg; ++i)
             if (p.kv.len[i] > 0 && (p.kv.k_ls[i] != p.kv.k_ls[0] || p.kv.vt_ls[i] != p.kv.vt_ls[0])) same_strides = false;
         if (p.kv.len[0] <= 0) same_strides = p.kv.nseg == 1;
-        static int wide_mode = -1;
-        if (wide_mode < 0) { const char* v = getenv("M4D_ATTN_WIDE"); wide_mode = v ? atoi(v) : 0; }   // 1: 64-queries-per-wave kernel (attention_wide.h); same-box A/B: phased 1048 vs wide 1020 TF sustained
+        M4D_ENV_ONCE(wide_mode, "M4D_ATTN_WIDE", 0);   // 1: 64-queries-per-wave kernel (attention_wide.h); same-box A/B: phased 1048 vs wide 1020 TF sustained
         if (w8 && same_strides && keys >= 4 * 64 + 64 * p.kv.nseg && wide_mode) {
             // 64 queries per wave: half the LDS traffic per MFMA, softmax interleaved into the MFMA stream (attention_wide.h)
             static bool configured_w = false;
             if (!configured_w) {
                 if (hipFuncSetAttribute((const void*)attn128w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
+#ifdef M4D_ABLATIONS
                 hipFuncSetAttribute((const void*)attn128w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
                 hipFuncSetAttribute((const void*)attn128w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
                 hipFuncSetAttribute((const void*)attn128w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+#endif
                 configured_w = true;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             const dim3 gw((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
-            switch (p.abl & 3) {   // timing ablations (tools only): 1 no softmax, 2 no MFMAs in the main loop
+#ifdef M4D_ABLATIONS
+            switch (p.abl & 3) {   // timing ablations (tool builds only): 1 no softmax, 2 no MFMAs in the main loop
                 case 1: hipLaunchKernelGGL(attn128w_kernel<1>, gw, dim3(256), 4 * 32768, st, q); break;
                 case 2: hipLaunchKernelGGL(attn128w_kernel<2>, gw, dim3(256), 4 * 32768, st, q); break;
                 case 3: hipLaunchKernelGGL(attn128w_kernel<3>, gw, dim3(256), 4 * 32768, st, q); break;
                 default: hipLaunchKernelGGL(attn128w_kernel<0>, gw, dim3(256), 4 * 32768, st, q);
             }
-        } else if (w8 && same_strides && !getenv("M4D_ATTN_LOCKSTEP")) {
+#else
+            hipLaunchKernelGGL(attn128w_kernel<0>, gw, dim3(256), 4 * 32768, st, q);
+#endif
+        } else if (w8 && same_strides && !force_lockstep) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
             static bool configured = false;
             if (!configured) {
@@ -555,9 +563,8 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
                 configured = true;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
-            static int smx = -1, prio = -1;
-            if (smx < 0) { const char* v = getenv("M4D_ATTN_SMX"); smx = v ? atoi(v) : 1; }   // 1 = scalar softmax arithmetic (default: +9 % sustained over the packed form), 0 = packed
-            if (prio < 0) { const char* v = getenv("M4D_ATTN_PRIO"); prio = v ? atoi(v) : 1; }
+            M4D_ENV_ONCE(smx, "M4D_ATTN_SMX", 1);   // 1 = scalar softmax arithmetic (default: +9 % sustained over the packed form), 0 = packed
+            M4D_ENV_ONCE(prio, "M4D_ATTN_PRIO", 1);
             const dim3 gp((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
             if (smx == 0) hipLaunchKernelGGL((attn128p_kernel<0, 1>), gp, dim3(512), 4 * 32768, st, q);
             else if (prio == 0) hipLaunchKernelGGL((attn128p_kernel<1, 0>), gp, dim3(512), 4 * 32768, st, q);
@@ -612,7 +619,10 @@ static int attention_impl(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_l
     p.B = B; p.heads = heads; p.nq_tiles = (int)((Lq + 127) / 128); p.accumulate = accumulate;
     p.sc = scale * 1.4426950408889634f;
     p.lse = lse;
-    { static int abl = -1; if (abl < 0) { const char* v = getenv("M4D_ATTN_ABL"); abl = v ? atoi(v) : 0; } p.abl = abl; }
+    p.abl = 0;
+#ifdef M4D_ABLATIONS
+    { M4D_ENV_ONCE(abl, "M4D_ATTN_ABL", 0); p.abl = abl; }
+#endif
     int rc = dt == M4D_BF16 ? launch<bf16_t>(p, head_dim, (hipStream_t)stream) : launch<float>(p, head_dim, (hipStream_t)stream);
     if (rc) { m4d_set_error("attention: unsupported configuration"); return rc; }
     M4D_CHECK_LAUNCH("attention");

@@ -346,7 +346,8 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
     p.ws = nullptr; p.y_chunk = 0;
     p.lse = a->lse; p.delta = a->delta; p.Lq = a->Lq;
     p.B = a->B; p.heads = a->heads; p.scale = a->scale; p.sc = a->scale * 1.4426950408889634f;
-    if (bf && a->head_dim == 128 && !getenv("M4D_ATTN_BWD_GENERIC")) {
+    M4D_ENV_ONCE(bwd_generic, "M4D_ATTN_BWD_GENERIC", 0);
+    if (bf && a->head_dim == 128 && !bwd_generic) {
         // production path: three forward-shaped passes (attention_bwd128.h)
         p.ybt = nullptr; p.ybt_bs = p.ybt_ls = 0; p.out_b = nullptr; p.ob_bs = p.ob_ls = 0;
         // dQ: X = (Q, dO), Y = (K, V, K^T)

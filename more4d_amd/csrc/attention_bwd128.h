@@ -364,8 +364,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
 
 template <int MODE>
 int launch_bwd128(const BwdArgs& p, hipStream_t st, int nsplit) {
-    static int smx = -1;
-    if (smx < 0) { const char* v = getenv("M4D_ATTN_BWD_SMX"); smx = v ? atoi(v) : 1; }
+    M4D_ENV_ONCE(smx, "M4D_ATTN_BWD_SMX", 1);
     constexpr int STAGE = (MODE == BWD_DV ? 32768 : 49152) + (MODE == BWD_DQ ? 0 : 512);
     static bool configured = false;
     if (!configured) {

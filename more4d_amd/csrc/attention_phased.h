@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
 #define M4D_V_PHASE()                                                                                                 \
     do {                                                                                                             \
         m_prefetch<0, 4>(ring, va, ka);      /* V^T(i) landed long ago; (only four: the softmax needs the registers) */ \
-        if (!(p.abl & 1)) softmax(KVB);                                                                              \
+        if (!(M4D_ABL(p) & 1)) softmax(KVB);                                                                              \
         /* pin the whole softmax (exp2, row sums, bf16 packing) in front of the barrier: without these uses the      \
            compiler sinks the 32 v_exp_f32 behind it, i.e. into the MFMA phase this schedule exists to keep clean */  \
         asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));                                          \
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             m_prefetch<4, 8>(ring, va, ka);
             if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-            if (!(p.abl & 2)) m_steps<0, 32>(ring, va, ka, pf, qf, o, s);
+            if (!(M4D_ABL(p) & 2)) m_steps<0, 32>(ring, va, ka, pf, qf, o, s);
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
             {   // advance the fragment addresses one stage (mod 4): va -> tile i+1, ka -> tile i+2

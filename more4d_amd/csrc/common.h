@@ -73,6 +73,24 @@ M4D_DEV float gelu_tanh_f(float x) {
 M4D_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 M4D_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// ---- A/B switches and timing ablations ----
+// Environment switches are read ONCE per process (M4D_ENV_ONCE).  Timing ablations (M4D_*_ABL: kernels that skip work,
+// run faster and return WRONG results) exist only in tool builds: `python -m more4d_amd.build --ablations` compiles with
+// -DM4D_ABLATIONS into lib/libmore4d_hip_abl.so; in the shipping library M4D_ABL() is the constant 0, the branches fold
+// away and the environment variables are never read.
+#include <stdlib.h>
+#define M4D_ENV_ONCE(var, name, dflt)                      \
+    static int var = -0x7fffffff;                          \
+    if (var == -0x7fffffff) {                              \
+        const char* v__ = getenv(name);                    \
+        var = v__ ? atoi(v__) : (dflt);                    \
+    }
+#ifdef M4D_ABLATIONS
+#define M4D_ABL(p) ((p).abl)
+#else
+#define M4D_ABL(p) 0
+#endif
+
 // ---- host-side error plumbing (api.cpp owns the storage) ----
 extern "C" __attribute__((visibility("hidden"))) void m4d_set_error(const char* fmt, ...);   // library-internal: not part of the ABI
 #define M4D_CHECK_ARG(cond, ...)                   \

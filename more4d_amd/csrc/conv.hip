@@ -399,8 +399,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.K = (int64_t)kt * kh * kw * Cin;
     // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
     const int64_t xbytes = (int64_t)Tin * Hin * Win * x_pixel_stride * 2;
-    static int conv_variant = -1;
-    if (conv_variant < 0) { const char* v = getenv("M4D_CONV_VARIANT"); conv_variant = v ? atoi(v) : 2; }
+    M4D_ENV_ONCE(conv_variant, "M4D_CONV_VARIANT", 2);
     const bool v2_shape = conv_variant == 2 && dt == M4D_BF16 && st == 1 && sh == 1 && sw == 1 && !ups && !tsplit && kt <= 8 &&
                           kh <= 8 && kw <= 8 && p.M >= 1024;
     if (v2_shape && xbytes >= (1ll << 30) && kt == 1 && pad_t == 0 && To == Tin) {

@@ -198,16 +198,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
         // my DMA for tile kt has landed; after the barrier everyone's has, and everyone is done reading stage^1
-        if (p.abl & 64) {   // ablation: DMA stream with two batches in flight, no consumer
+        if (M4D_ABL(p) & 64) {   // ablation: DMA stream with two batches in flight, no consumer
             if (kt + 1 < nk) issue(stage ^ 1, kt + 1);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            if (!(p.abl & 4)) __builtin_amdgcn_s_barrier();
+            if (!(M4D_ABL(p) & 4)) __builtin_amdgcn_s_barrier();
             continue;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk && !(p.abl & 1)) issue(stage ^ 1, kt + 1);
-        if (p.abl & 8) continue;
+        if (kt + 1 < nk && !(M4D_ABL(p) & 1)) issue(stage ^ 1, kt + 1);
+        if (M4D_ABL(p) & 8) continue;
         // Fragment double buffer.  hipcc's waitcnt pass drains lgkmcnt to 0 in front of every MFMA group here, so the
         // reads are issued from inline asm (invisible to that pass) and waited for with COUNTED lgkmcnt: the 6 reads
         // of step kk+1 are in flight while the 8 MFMAs of step kk run (cdna guide §5.7: own your waits).
@@ -360,7 +360,7 @@ constexpr int SLOT_BYTES = 512 * 64;   // (256 A rows + 256 W rows) x 64 B
 M4D_DEV int lds_off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 __global__ __launch_bounds__(512, 2) void gemm_bt256pp_kernel(GemmArgs p) {
-    const int ABL = p.abl;   // timing ablations (tools/abl.sh): results are wrong when != 0
+    const int ABL = M4D_ABL(p);   // timing ablations (tools/abl.sh): results are wrong when != 0
     typedef bf16_t T;
     int tm, tn;
     tile_coords(p, tm, tn);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256pp_kernel(GemmArgs p) {
         if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         // ---- compute phase
         __builtin_amdgcn_s_setprio(1);
-        if (!(p.abl & 8))
+        if (!(M4D_ABL(p) & 8))
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -470,9 +470,10 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.gate_stride = gate_stride; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : M;
     p.epilogue = epilogue; p.bias_on_m = bias_on_m;
-    static int abl_env = -1;
-    if (abl_env < 0) { const char* v = getenv("M4D_GEMM_ABL"); abl_env = v ? atoi(v) : 0; }
-    p.abl = abl_env;
+    p.abl = 0;
+#ifdef M4D_ABLATIONS
+    { M4D_ENV_ONCE(abl_env, "M4D_GEMM_ABL", 0); p.abl = abl_env; }
+#endif
     hipStream_t st = (hipStream_t)stream;
     // production kernel: big bf16 problems with K a multiple of the 64-wide K-tile
     const bool big = dt == M4D_BF16 && K % 64 == 0 && M >= 512 && N >= 512;

@@ -33,8 +33,8 @@ M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn, int bid) {
     const int in_band = bid - band * GM * p.tiles_n;
     tm = band * GM + in_band % band_rows;
     tn = in_band / band_rows;
-    if (p.abl & 16) { tm = 0; tn = 0; }          // ablation: every workgroup reads the same panels (all L2 hits)
-    if (p.abl & 32) { tm = blockIdx.x % p.tiles_m; tn = blockIdx.x / p.tiles_m; }   // ablation: naive order
+    if (M4D_ABL(p) & 16) { tm = 0; tn = 0; }          // ablation: every workgroup reads the same panels (all L2 hits)
+    if (M4D_ABL(p) & 32) { tm = blockIdx.x % p.tiles_m; tn = blockIdx.x / p.tiles_m; }   // ablation: naive order
 }
 M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn) { tile_coords(p, tm, tn, (int)blockIdx.x); }
 

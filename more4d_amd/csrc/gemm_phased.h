@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
     }
     const char* baseA = uniform_ptr((const char*)p.A + m0 * p.lda * 2);
     const char* baseW = uniform_ptr((const char*)p.W + n0 * p.ldw * 2);
-    const int nk = (p.abl & 128) ? 2 : (int)(p.K / 64);   // ablation 128: two K-tiles only (per-tile fixed cost)
+    const int nk = (M4D_ABL(p) & 128) ? 2 : (int)(p.K / 64);   // ablation 128: two K-tiles only (per-tile fixed cost)
     // one unit = two DMA instructions per lane: rows r0 + (lane's row) and r1 + (lane's row) of the operand tile
     auto stage = [&](const char* base, int64_t ld, unsigned voff, int r0, int r1, int slot_off, int kt) {
         const int kc = kt < nk ? kt : nk - 1;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
     } while (0)
 #define P_STORE_TILE(TM0, TN0, MLO, NLO)                                                                   \
     do {                                                                                                   \
-        if (p.abl & 256) break;       /* ablation 256: no epilogue */                                        \
+        if (M4D_ABL(p) & 256) break;       /* ablation 256: no epilogue */                                        \
         char* wl = dyn_smem + wave * 16384;                                                                \
         if ((p.ldc & 7) == 0 || p.epilogue == M4D_EPI_RESID_GATE || p.epilogue == M4D_EPI_STORE_F32) {     \
             epilogue_half_lds<T>(p, wl, acc[0][0], acc[0][1], acc[1][0], acc[1][1], (TM0) + wm * 128, (TN0) + wn * 64, (MLO), (NLO), lane); \

@@ -209,3 +209,86 @@ def test_product_guided_backward_host_logic(monkeypatch):
     m.activation_budget_gb = 1e6
     custom_mse_loss(m(**kw), zg["target"]).backward()
     same_grads({n: p.grad for n, p in m.named_parameters() if p.grad is not None}, ref_grads)
+
+
+def _sharded_dp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import more4d_amd.ops as real
+        for n in cpu_ops.NAMES + ["adamw_", "sumsq"]:
+            setattr(real, n, getattr(cpu_ops, n))
+        from more4d_amd.dist.data_parallel import ShardedDataParallel
+        from more4d_amd.models import WanTransformer4DModel
+        from more4d_amd.optim import AdamW, clip_grad_norm_
+        z, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_grads.npz")
+        sd0 = fill(load_keys("dit_tiny_keys.json"), 1234)
+        hp = dict(lr=1e-3, weight_decay=3e-2, eps=1e-10)
+        m = WanTransformer4DModel(**TINY)
+        m.load_state_dict(sd0)
+        m.train()
+        names = [n for n, _ in m.named_parameters()]
+        dp = ShardedDataParallel(m, bucket_bytes=300_000, **hp)          # several buckets, ragged last one
+        assert len(dp.buckets) > 3
+        assert all(torch.equal(p.detach(), sd0[n]) for n, p in m.named_parameters()), "flattening must not change values"
+        r = slice(rank, rank + 1)
+        kw = dict(seq_len=int(z["seq_len_pad"]))
+        totals = []
+        for it in range(2):                                              # second step: re-armed buckets, zeroed gradients
+            pred = m(x=z["x"][r], t=z["t"][r], context=[[z["ctx0"], z["ctx1"]][rank]], clip_fea=z["clip"][r], y=z["y"][r],
+                     full_ref=z["full_ref"][r], **kw)
+            custom_mse_loss(pred, zg["target"][r]).backward()
+            total = dp.reduce_gradients()
+            totals.append(float(total))
+            dp.step(max_norm=0.05, total_norm=total)
+            dp.zero_grad()
+        mine = {n: p.detach().clone() for n, p in m.named_parameters()}
+        # single-process reference: the same two steps on the global batch with the plain optimizer
+        ref = WanTransformer4DModel(**TINY)
+        ref.load_state_dict(sd0)
+        ref.train()
+        opt = AdamW(ref.parameters(), **hp)
+        ref_totals = []
+        for it in range(2):
+            pred = ref(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], clip_fea=z["clip"], y=z["y"], full_ref=z["full_ref"], **kw)
+            custom_mse_loss(pred, zg["target"]).backward()
+            if it == 0:
+                check_grads({n: p.grad for n, p in ref.named_parameters()}, zg, 1e-3)
+            ref_totals.append(float(clip_grad_norm_(ref.parameters(), 0.05, optimizer=opt)))
+            opt.step()
+            opt.zero_grad()
+        err = max(float((mine[n] - p.detach()).abs().max() / p.detach().abs().max().clamp_min(1e-6)) for n, p in ref.named_parameters())
+        moved = sum(float((mine[n] - sd0[n]).abs().sum()) for n in names)
+        state = dp.state_bytes()
+        full = sum(p.numel() for p in m.parameters()) * 4 * 2
+        digest = torch.stack([v.double().sum() for v in mine.values()]).sum().reshape(1)
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        if rank == 0:
+            q.put((err, totals, ref_totals, moved, state / full, float((gathered[0] - gathered[1]).abs())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_data_parallel_equals_single_process_gloo():
+    """more4d_amd.dist.data_parallel: bucketed reduce-scatter of the gradients, AdamW on each rank's slice, all-gather of the
+    parameters — two steps at world 2 equal two single-process steps on the global batch (same norms, same parameters on both
+    ranks), with half the optimizer state per rank."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_sharded_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, totals, ref_totals, moved, state_frac, diverge = q.get(timeout=600)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert err < 2e-4, err
+    assert all(abs(a - b) < 1e-4 * b for a, b in zip(totals, ref_totals)), (totals, ref_totals)
+    assert moved > 0 and diverge == 0.0 and 0.45 < state_frac < 0.6

@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import CFG_14B, build_model  # noqa: E402
+from bench import CFG_14B, build_model, standin_group  # noqa: E402
 
 
 def main():
@@ -25,30 +25,15 @@ def main():
     ap.add_argument("--layers", type=int, default=40)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    from more4d_amd.dist import SequenceParallelGroup
-    from more4d_amd.ops import KV
 
     spw = args.world // 2 if args.mode == "cfg-sp" else args.world
     B = 1 if args.mode == "cfg-sp" else 2
-
-    class FakeSP(SequenceParallelGroup):
-        def __init__(self):
-            self.group, self.world_size, self.rank = None, spw, 0
-
-        def all_gather(self, x, dim=1):
-            return torch.cat([x] * self.world_size, dim=dim)
-
-        def gather_start(self, x):
-            x = x.contiguous()
-            buf = torch.empty((self.world_size,) + tuple(x.shape), device=x.device, dtype=x.dtype)
-            buf.copy_(x.unsqueeze(0).expand_as(buf))     # every peer slot = a copy of the local shard (real values: power)
-            return buf, None, x
 
     cfg = dict(CFG_14B)
     cfg["num_layers"] = args.layers
     model = build_model(cfg, dev, torch.bfloat16)
     if spw > 1:
-        model.sp_world_size, model.sp_world_rank, model._sp = spw, 0, FakeSP()
+        model.sp_world_size, model.sp_world_rank, model._sp = spw, 0, standin_group(spw)
     g = torch.Generator(device=dev).manual_seed(1234)
     F_, H_, W_ = 13, 60, 104
     x = torch.randn(B, 16, F_, H_, W_, generator=g, device=dev).bfloat16()

@@ -18,8 +18,10 @@ from bench import CFG_14B, MFMA_BF16_PEAK_TF, build_model, flops_per_forward  # 
 
 
 def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=None, profile_ops=False, world=1, rank=0,
-              local_rank=0, guidance=False):
-    """Time `steps` training steps of `model` (already on `dev`, bf16): fwd + (recompute) + bwd + clip + AdamW."""
+              local_rank=0, guidance=False, dp="sharded"):
+    """Time `steps` training steps of `model` (already on `dev`, bf16): fwd + (recompute) + bwd + clip + AdamW.
+    world > 1: data parallel, one sample per rank — dp="sharded" = more4d_amd.dist.data_parallel (bucketed reduce-scatter,
+    sharded AdamW, parameter all-gather), dp="ddp" = torch DDP's bucketed all-reduce + the replicated optimizer (A/B)."""
     from more4d_amd import ops
     from more4d_amd.optim import AdamW, clip_grad_norm_
     model = model.train()
@@ -27,12 +29,17 @@ def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=N
         p_.requires_grad_(True)
     model.activation_budget_gb = act_budget
     net = model
-    if world > 1:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True,
-                  bucket_cap_mb=512)
-    opt = AdamW(model.parameters(), lr=2e-5, weight_decay=3e-2, eps=1e-10,
-                state_dtype=torch.float32 if fp32_state else None)
+    hp = dict(lr=2e-5, weight_decay=3e-2, eps=1e-10, state_dtype=torch.float32 if fp32_state else None)
+    sdp = opt = None
+    if world > 1 and dp == "sharded":
+        from more4d_amd.dist.data_parallel import ShardedDataParallel
+        sdp = ShardedDataParallel(model, **hp)
+    else:
+        if world > 1:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True,
+                      bucket_cap_mb=512)
+        opt = AdamW(model.parameters(), **hp)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     F_, H_, W_ = 13, 60, 104
@@ -77,9 +84,13 @@ def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=N
         diff = pred.float() - target
         loss = (diff * diff * (diff.abs() <= 50).float()).mean()            # custom_mse_loss :1953-1963
         loss.backward()
-        clip_grad_norm_(model.parameters(), 0.05, optimizer=opt)
-        opt.step()
-        opt.zero_grad(set_to_none=False)
+        if sdp is not None:
+            sdp.step(max_norm=0.05, total_norm=sdp.reduce_gradients())
+            sdp.zero_grad()
+        else:
+            clip_grad_norm_(model.parameters(), 0.05, optimizer=opt)
+            opt.step()
+            opt.zero_grad(set_to_none=False)
         return loss
 
     for _ in range(warmup):
@@ -102,7 +113,12 @@ def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=N
            "value": dt, "unit": "s/step", "n_gpus": world, "layers": cfg["num_layers"], "loss": float(loss.detach()),
            "model_tflop": model_flops / 1e12, "mfma_frac": model_flops / dt / 1e12 / MFMA_BF16_PEAK_TF,
            "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "stored_blocks": [model.last_stored_blocks, model.last_full_blocks],
-           "state_dtype": "float32" if fp32_state else "bfloat16"}
+           "state_dtype": "float32" if fp32_state else "bfloat16",
+           "data_parallel": "single GPU" if world == 1 else (
+               "bucketed reduce-scatter + sharded AdamW + parameter all-gather (RCCL)" if sdp is not None else "torch DDP all-reduce")}
+    if sdp is not None:
+        out["optimizer_state_gb_per_rank"] = sdp.state_bytes() / 2 ** 30
+        sdp.close()
     if timers:
         torch.cuda.synchronize()
         out["ops_ms_per_step"] = {k: round(sum(s.elapsed_time(e) for s, e in v) / steps, 2) for k, v in
@@ -119,6 +135,7 @@ def main():
     ap.add_argument("--act-budget", type=float, default=None, help="GB of stored activations (default: automatic; 0 = recompute)")
     ap.add_argument("--profile-ops", action="store_true", help="HIP-event time per ops.* entry point (adds syncs)")
     ap.add_argument("--guidance", action="store_true", help="train with spatial guidance on (use_omnimae_guidance, random-init gates)")
+    ap.add_argument("--dp", choices=["sharded", "ddp"], default="sharded")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +154,7 @@ def main():
     model = build_model(cfg, dev, torch.bfloat16)
     out = run_train(model, cfg, dev, steps=args.steps, warmup=args.warmup, fp32_state=args.fp32_state,
                     act_budget=args.act_budget, profile_ops=args.profile_ops, world=world, rank=rank, local_rank=local_rank,
-                    guidance=args.guidance)
+                    guidance=args.guidance, dp=args.dp)
     out["guidance"] = args.guidance
     if rank == 0:
         print(json.dumps(out))
