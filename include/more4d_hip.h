@@ -211,6 +211,24 @@ int m4d_rel_l1(const float* prev, const float* cur, float* out2, int64_t n, m4d_
  * of the Motion Perception Module resized to the latent token grid (wan_transformer4d.py:1152). */
 int m4d_bilinear_cl(m4d_dtype dt, const void* x, void* out, int B, int Hi, int Wi, int Ho, int Wo, int C, m4d_stream stream);
 
+/* ------------------------------------------------------------------ stage-1 geometry (scripts/inference/infer.py)
+ * The prologue / epilogue either side of the sampler, all float32 unless a dtype is given.
+ * minmax: out[g] = {min, max} of each of n_groups contiguous groups of group_len floats (the depth range of :826 and the
+ *   per-axis extent of the first frame's point cloud, :209-212).
+ * backproject (:179-195 after the bilinear resize, which is m4d_bilinear_cl with C = 1): coords [3,H,W] = K^-1 (u, v, 1) * depth
+ *   on the linspace(0,1) pixel grid, K = [[fx,0,.5],[0,fy,.5],[0,0,1]] (pass 1/fx, 1/fy); zclean [H,W] = z clamped to [0, 1e4]
+ *   with nan / < 1e-5 replaced by 1 (:823-825).
+ * depth_control (:826-828): out [3, hw] (dtype out_dt) = 2 (zclean - min) / (max - min + 1e-8) - 1, three identical channels.
+ * flow_recover: rel [B,3,F,hw] (dtype in_dt) = decoded displacements, frame0 float [B,3,hw] = first-frame coordinates;
+ *   out float [B,3,F,hw]: frame 0 = frame0 (:870), frames f > 0 = (rel + frame0/diff) * diff with diff = max over the three
+ *   axes of (max - min) of frame0 (0 -> 1), minmax float [B*3, 2] from m4d_minmax (mode 0, inverse_flow_norm_transform_no_diff
+ *   :198-219), or rel + frame0 (mode 1, --normalize_track_z :857-861; minmax may be NULL). */
+int m4d_minmax(const float* x, int64_t n_groups, int64_t group_len, float* out, m4d_stream stream);
+int m4d_backproject(const float* depth, int H, int W, float inv_fx, float inv_fy, float* coords, float* zclean, m4d_stream stream);
+int m4d_depth_control(m4d_dtype out_dt, const float* zclean, const float* minmax, void* out, int64_t hw, m4d_stream stream);
+int m4d_flow_recover(m4d_dtype in_dt, const void* rel, const float* frame0, const float* minmax, float* out, int B, int F,
+                     int64_t hw, int mode, m4d_stream stream);
+
 /* ------------------------------------------------------------------ training step (train_wan.py:1891-2015)
  * Backward halves of the DiT kernels above and the fused optimizer update.  The reference gets these from torch
  * autograd (accelerator.backward, :1988) and torch.optim.AdamW (:1136-1142, :2014); GEMM-shaped gradients

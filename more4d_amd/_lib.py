@@ -81,6 +81,10 @@ SIGNATURES = {
     "m4d_lincomb": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_int64,
                             c_void_p]),
     "m4d_rel_l1": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m4d_minmax": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "m4d_backproject": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "m4d_depth_control": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m4d_flow_recover": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "m4d_bilinear_cl": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "m4d_conv_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
                     [c_int] * 19 + [c_void_p]),

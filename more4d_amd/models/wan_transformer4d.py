@@ -719,6 +719,7 @@ class WanTransformer4DModel(nn.Module):
             prev = tc.previous_residual_cond if cond_flag else tc.previous_residual_uncond
             if prev is None:
                 should_calc = True
+            self.should_calc = should_calc       # the reference keeps the step's decision on the model too (:1206-1220)
         if should_calc:
             ori = xres.clone() if tc is not None else None
             for i, block in enumerate(self.blocks):

@@ -473,6 +473,51 @@ def rel_l1(prev, cur):
     return d / p_
 
 
+def minmax(x, n_groups):
+    """x float32, contiguous, viewed as [n_groups, -1] -> float32 [n_groups, 2] = (min, max) of every group."""
+    _dev(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() % n_groups:
+        raise TypeError("minmax: contiguous float32 input divisible into the groups")
+    out = torch.empty((n_groups, 2), device=x.device, dtype=torch.float32)
+    check(_lib.load().m4d_minmax(_ptr(x), n_groups, x.numel() // n_groups, _ptr(out), _stream()), "m4d_minmax")
+    return out
+
+
+def backproject(depth, inv_fx, inv_fy):
+    """depth float32 [H, W] -> (coords float32 [3, H, W], zclean float32 [H, W]) (infer.py:179-195, :823-825)."""
+    _dev(depth)
+    if depth.dtype != torch.float32 or depth.dim() != 2 or not depth.is_contiguous():
+        raise TypeError("backproject: contiguous float32 [H, W] depth")
+    H, W = depth.shape
+    coords = torch.empty((3, H, W), device=depth.device, dtype=torch.float32)
+    zc = torch.empty((H, W), device=depth.device, dtype=torch.float32)
+    check(_lib.load().m4d_backproject(_ptr(depth), H, W, float(inv_fx), float(inv_fy), _ptr(coords), _ptr(zc), _stream()),
+          "m4d_backproject")
+    return coords, zc
+
+
+def depth_control(zclean, mm, out_dtype):
+    """zclean float32 [H, W], mm float32 [1, 2] -> out_dtype [3, H, W] in [-1, 1] (infer.py:826-828)."""
+    _dev(zclean, mm)
+    H, W = zclean.shape
+    out = torch.empty((3, H, W), device=zclean.device, dtype=out_dtype)
+    check(_lib.load().m4d_depth_control(dt_code(out_dtype), _ptr(zclean), _ptr(mm), _ptr(out), H * W, _stream()), "m4d_depth_control")
+    return out
+
+
+def flow_recover(rel, frame0, mm=None, track_z=False):
+    """rel [B,3,F,H,W] (T), frame0 float32 [B,3,H,W], mm float32 [B*3,2] -> float32 [B,3,F,H,W] point trajectories."""
+    _dev(rel, frame0, mm)
+    rel = rel.contiguous()
+    B, C, F, H, W = rel.shape
+    if C != 3 or tuple(frame0.shape) != (B, 3, H, W) or frame0.dtype != torch.float32 or not frame0.is_contiguous():
+        raise ValueError("flow_recover: rel [B,3,F,H,W], frame0 float32 contiguous [B,3,H,W]")
+    out = torch.empty((B, 3, F, H, W), device=rel.device, dtype=torch.float32)
+    check(_lib.load().m4d_flow_recover(dt_code(rel.dtype), _ptr(rel), _ptr(frame0), _ptr(mm), _ptr(out), B, F, H * W,
+                                       1 if track_z else 0, _stream()), "m4d_flow_recover")
+    return out
+
+
 def bilinear_cl(x, out_hw):
     """x [B, Hi, Wi, C] channels-last -> [B, Ho, Wo, C] (bilinear, align_corners=False)."""
     _dev(x)

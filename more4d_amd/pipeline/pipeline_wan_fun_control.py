@@ -152,6 +152,16 @@ class WanFunControlPipeline:
             ts, _ = retrieve_timesteps(sch, num_inference_steps, device, timesteps)
         return ts
 
+    @staticmethod
+    def _preprocess(video, height, width):
+        """`self.image_processor.preprocess(...)` of the reference (:637-639, :681-683, :704-706) for float tensors: diffusers'
+        VaeImageProcessor (third-party, restated — parity unpinned) resizes to (height, width) and maps [0, 1] -> [-1, 1]; a
+        tensor that already holds negative values is taken to be normalised and passed through."""
+        if tuple(video.shape[-2:]) != (height, width):
+            raise NotImplementedError(f"control / reference frames must already be {height}x{width} (got {tuple(video.shape[-2:])})")
+        video = video.float()
+        return video if float(video.min()) < 0 else video * 2.0 - 1.0
+
     def _encode_control(self, video, device):
         """vae.encode(x)[0].mode() (reference prepare_control_latents :343-374)."""
         return self.vae.encode(video.to(device))[0].mode()
@@ -181,7 +191,7 @@ class WanFunControlPipeline:
                                    generator, latents)
         # control latents: [control video | start image (zeros) | depth] = 48 channels (:762-777)
         if control_video is not None:
-            ctrl = self._encode_control(control_video.float(), device)
+            ctrl = self._encode_control(self._preprocess(control_video, height, width), device)
         else:
             ctrl = torch.zeros_like(lat)
         parts = [ctrl, torch.zeros_like(lat)]
@@ -190,7 +200,7 @@ class WanFunControlPipeline:
         y = torch.cat([p.to(device=device, dtype=torch.float32) for p in parts], dim=1)
         full_ref = None
         if self.transformer.config.get("add_ref_conv", False):
-            full_ref = self._encode_control(ref_image.float(), device)[:, :, 0] if ref_image is not None \
+            full_ref = self._encode_control(self._preprocess(ref_image, height, width), device)[:, :, 0] if ref_image is not None \
                 else torch.zeros_like(lat)[:, :, 0]
         elif ref_image is not None:
             raise ValueError("The add_ref_conv is False, but ref_image is not None")

@@ -130,6 +130,9 @@ def _install_third_party_names():
         def __init__(self, latent_dist):
             self.latent_dist = latent_dist
 
+        def __getitem__(self, i):        # published BaseOutput behaviour: out[0] is the first field
+            return (self.latent_dist,)[i]
+
     mo.AutoencoderKLOutput = AutoencoderKLOutput
 
     _mod("diffusers.schedulers")

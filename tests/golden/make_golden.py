@@ -453,6 +453,172 @@ def make_vae(ref):
     npz_save("adaptor_dec.npz", x=xt, out=da(xt), **sd_arrays("sd.", da))
 
 
+def make_block_14b_long(ref):
+    """One 14B-width block at L = 2080 (grid (4, 20, 26)): long enough that the PRODUCTION bf16 kernels are on the path
+    (gemm_bt256p_kernel needs M, N >= 512; attn128p_kernel needs Lq > 1024 and >= 2048 keys).  Weights and inputs are
+    regenerated from the seeded recipe; stored: 65 sampled output rows and every row's L2 norm (the full output is 42 MB)."""
+    from weights import block_weights_14b, randn_named
+    d = ref.dit
+    blk = d.WanAttentionBlock("i2v_cross_attn", 5120, 13824, 40, (-1, -1), True, True, 1e-6,
+                              use_spatial_guidance=False).eval()
+    sd = block_weights_14b(seed=0)
+    blk.load_state_dict({k[len("blocks.0."):]: v for k, v in sd.items()})
+    grid = (4, 20, 26)
+    L = 2080
+    x = randn_named("in.x", (1, L, 5120), 6)
+    e0 = randn_named("in.e0", (1, 6, 5120), 6, 0.2)
+    ctx = randn_named("in.ctx", (1, 257 + 512, 5120), 6)
+    freqs = torch.cat([d.rope_params(1024, 128 - 4 * (128 // 6)), d.rope_params(1024, 2 * (128 // 6)),
+                       d.rope_params(1024, 2 * (128 // 6))], dim=1)
+    y = blk(x, e0, torch.tensor([L]), torch.tensor([list(grid)]), freqs, ctx, None,
+            dtype=torch.float32, t=0, dino_features=None)
+    rows = torch.arange(0, L, 32)
+    rows = torch.cat([rows, torch.tensor([L - 1])])
+    npz_save("dit_block_14b_long.npz", grid=np.array(grid), rows=rows, out_rows=y[0, rows], row_norm=y[0].norm(dim=-1),
+             delta_rows=(y - x)[0, rows], delta_norm=(y - x)[0].norm(dim=-1))
+
+
+def make_teacache_loop(ref):
+    """TeaCache pinned to the reference (cache_utils.py:19-74, hooks wan_transformer4d.py:1201-1270, 1336-1339): the tiny DiT
+    in a 10-step CFG Euler loop with enable_teacache(coefficients("Wan2.1-Fun-14B-Control"), 10, thresh, num_skip_start_steps=1,
+    offload=False): per-step compute/skip decisions, the accumulated distance, every step's latent and the final latent."""
+    from MoRe4D.models.cache_utils import get_teacache_coefficients
+    m = ref.dit.WanTransformer4DModel(**TINY_DIT).eval()
+    load_recipe(m, None, seed=1234)
+    g = torch.Generator().manual_seed(17)
+    lat = torch.randn(1, 16, 1, 32, 32, generator=g)
+    y = torch.randn(1, 48, 1, 32, 32, generator=g)
+    full_ref = torch.randn(1, 16, 32, 32, generator=g)
+    ctx_c = torch.randn(9, 64, generator=g)
+    ctx_u = torch.randn(1, 64, generator=g)
+    clip = torch.randn(1, 257, 1280, generator=g)
+    steps, shift, gs = 10, 5.0, 6.0
+    coeff = get_teacache_coefficients("Wan2.1-Fun-14B-Control")
+    out = {}
+    for tag, thresh in (("a", 15000.0), ("b", 30000.0)):      # the tiny random model moves e0 by ~100 % per step: rescaled distances are 5e3-2e4
+        m.enable_teacache(coeff, steps, thresh, num_skip_start_steps=1, offload=False)
+        sch = ref.fm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+        sch.set_timesteps(sigmas=ref.fm.get_sampling_sigmas(steps, shift))
+        x = lat.clone()
+        calc, acc, traj = [], [], []
+        for i, t in enumerate(sch.timesteps):
+            v = m(x=torch.cat([x, x]), t=t.expand(2), context=[ctx_u, ctx_c], seq_len=256, clip_fea=torch.cat([clip, clip]),
+                  y=torch.cat([y, y]), full_ref=torch.cat([full_ref, full_ref]))
+            calc.append(bool(m.should_calc))
+            acc.append(float(m.teacache.accumulated_rel_l1_distance) if m.teacache.cnt != 0 else 0.0)
+            vu, vc = v.chunk(2)
+            x = sch.step(vu + gs * (vc - vu), t, x, return_dict=False)[0]
+            traj.append(x.clone())
+        print("teacache", tag, thresh, "calc:", calc)
+        out.update({f"{tag}_thresh": np.float64(thresh), f"{tag}_calc": np.array(calc), f"{tag}_acc": np.array(acc),
+                    f"{tag}_traj": torch.stack(traj), f"{tag}_final": x})
+        m.disable_teacache()
+    npz_save("teacache_loop.npz", lat=lat, y=y, full_ref=full_ref, ctx_c=ctx_c, ctx_u=ctx_u, clip=clip, steps=np.int64(steps),
+             shift=np.float64(shift), guidance=np.float64(gs), coeff=np.array(coeff), **out)
+
+
+def _reference_functions(path, names, extra=None):
+    """Execute only the named top-level functions of a reference script that cannot be imported as a whole (scripts/inference/
+    infer.py pulls in UniDepth, gsplat, decord ...): the function definitions are compiled FROM THE REFERENCE FILE at fixture
+    generation time — nothing is copied into this repository."""
+    import ast
+    import typing
+    import torch.nn.functional as F_
+    src = open(path).read()
+    tree = ast.parse(src)
+    def wanted(n):
+        if isinstance(n, ast.FunctionDef):
+            return n.name in names
+        if isinstance(n, ast.Assign):      # module-level constants the functions read (e.g. DEFAULT_H_ORI, DEFAULT_W_ORI = 540, 960)
+            return any(isinstance(t, ast.Name) and t.id in names for tg in n.targets for t in ast.walk(tg))
+        return False
+    keep = [n for n in tree.body if wanted(n)]
+    assert len(keep) == len(names) - sum(1 for x in names if x.isupper()) + 1 or len(keep) >= 1, [getattr(n, "name", "assign") for n in keep]
+    ns = {"torch": torch, "F": F_, "np": np, "Tuple": typing.Tuple, "List": typing.List, "Dict": typing.Dict,
+          "Optional": typing.Optional}
+    ns.update(extra or {})
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def make_pipeline_chain(ref):
+    """The whole stage-1 chain around the denoise loop, hand-restated from pipeline_wan_fun_control.py:626-723 (conditioning),
+    :741-840 (loop), :382-386 (decode_latents_no_normalize) and scripts/inference/infer.py:820-871 (depth prologue, decoder
+    prompt, coordinate recovery) — every ARITHMETIC step calls the imported reference: AutoencoderKLWan, WanTransformer4DModel,
+    VAEDecoderadaptor, FlowDPMSolverMultistepScheduler and infer.py's back_project_coords / inverse_flow_norm_transform_no_diff.
+    (diffusers' VaeImageProcessor.preprocess is absent: its published behaviour for same-size tensors in [0, 1] is x*2-1.)"""
+    from weights import fill
+    inf = _reference_functions(os.path.join(_ref_import.REF_ROOT, "scripts/inference/infer.py"),
+                               ["DEFAULT_H_ORI", "get_intrinsic_matrix", "back_project_coords", "inverse_flow_norm_transform_no_diff"])
+    H = W = 32
+    NF = 5
+    vae = ref.vae.AutoencoderKLWan().eval()
+    shapes = {k: list(t.shape) for k, t in vae.state_dict().items()}
+    vae.load_state_dict(fill(shapes, seed=2024))
+    dec_prompt = ref.traj.VAEDecoderadaptor().eval()
+    dp_shapes = {k: list(t.shape) for k, t in dec_prompt.state_dict().items()}
+    dec_prompt.load_state_dict(fill(dp_shapes, seed=77))
+    m = ref.dit.WanTransformer4DModel(**TINY_DIT).eval()
+    load_recipe(m, None, seed=1234)
+    g = torch.Generator().manual_seed(23)
+    image01 = torch.rand(1, 3, 1, H, W, generator=g)                      # get_image_latent: [1,3,1,H,W] in [0,1]
+    control_video = image01.repeat(1, 1, NF, 1, 1)                        # create_control_video_from_image(...).repeat (:816-817)
+    ref_image = image01.clone()
+    depth_pred = torch.rand(24, 24, generator=g) * 3 + 0.5                # depth model output at its own resolution
+    depth_pred[5, 6] = 0.0                                                # hits the "< 1e-5 -> 1" branch of the depth prologue
+    depth_bad = depth_pred.clone()                                        # NaN / inf depth: pins the prologue's clean-up only (the
+    depth_bad[3, 4] = float("nan")                                        # coordinate recovery of the reference turns all-NaN on it)
+    depth_bad[7, 9] = float("inf")
+    ctx_c = torch.randn(9, 64, generator=g)
+    ctx_u = torch.randn(1, 64, generator=g)
+    clip = torch.randn(1, 257, 1280, generator=g)
+    lat0 = torch.randn(1, 16, 2, H // 8, W // 8, generator=g)
+    steps, shift, gs = 4, 3.0, 6.0
+    # ---- depth prologue (infer.py:820-828)
+    def depth_prologue(dp):
+        ffc = inf["back_project_coords"](dp, H, W, torch.device("cpu"))
+        ffc = ffc.permute(2, 0, 1).unsqueeze(0).unsqueeze(2)
+        dpv = ffc[:, 2, :, :].unsqueeze(1).repeat(1, 3, 1, 1, 1)
+        dpv = torch.clamp(dpv, min=0.0, max=10000.0)
+        dpv[torch.isinf(dpv) | torch.isnan(dpv) | (dpv < 1e-5)] = 1
+        dmin, dmax = dpv.min(), dpv.max()
+        return ffc, 2 * (dpv - dmin) / (dmax - dmin + 1e-8) - 1
+    first_frame_coords, dpv = depth_prologue(depth_pred)
+    _, dpv_bad = depth_prologue(depth_bad)
+    # ---- conditioning (pipeline :626-723): preprocess = x*2-1 for [0,1] tensors, encode(...).mode()
+    enc = lambda v: vae.encode(v.float())[0].mode()
+    control_latents = enc(control_video * 2 - 1)
+    depth_latents = enc(dpv.repeat(1, 1, NF, 1, 1).float())
+    ref_latents = enc(ref_image * 2 - 1)[:, :, 0]
+    start = torch.zeros_like(lat0)
+    yv = torch.cat([control_latents, start, depth_latents], dim=1)
+    # ---- loop (:741-840)
+    sch = ref.fm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+    sch.set_timesteps(sigmas=ref.fm.get_sampling_sigmas(steps, shift))
+    x = lat0.clone()
+    seq_len = (H // 16) * (W // 16) * lat0.shape[2]
+    for t in sch.timesteps:
+        v = m(x=torch.cat([x, x]), t=t.expand(2), context=[ctx_u, ctx_c], seq_len=seq_len, clip_fea=torch.cat([clip, clip]),
+              y=torch.cat([yv, yv]), full_ref=torch.cat([ref_latents, ref_latents]))
+        vu, vc = v.chunk(2)
+        x = sch.step(vu + gs * (vc - vu), t, x, return_dict=False)[0]
+    video = vae.decode(x).sample                                          # decode_latents_no_normalize (clamped to [-1,1], :825-832)
+    recon = dec_prompt(video).float()                                     # infer.py:848-849
+    flow_rel, diff = inf["inverse_flow_norm_transform_no_diff"](recon, first_frame_coords)          # :862
+    # (the --normalize_track_z branch :857-860 adds a [1,3,H,W] tensor to [1,3,F,H,W]: it raises for F != 3 in the reference
+    #  itself, so there is nothing to pin; more4d_amd.utils.io.recover_coords implements the evident intent, unpinned)
+    coords_rel = torch.cat([first_frame_coords, flow_rel[:, :, 1:]], dim=2)                          # :870
+    import json
+    with open(os.path.join(HERE, "adaptor_dec_keys.json"), "w") as fh:
+        json.dump(dp_shapes, fh, indent=0, sort_keys=True)
+    npz_save("pipeline_chain.npz", image01=image01, depth_pred=depth_pred, ctx_c=ctx_c, ctx_u=ctx_u, clip=clip, lat0=lat0,
+             steps=np.int64(steps), shift=np.float64(shift), guidance=np.float64(gs), num_frames=np.int64(NF),
+             first_frame_coords=first_frame_coords, depth_pixel_values=dpv, depth_bad=depth_bad,
+             depth_pixel_values_bad=dpv_bad, control_latents=control_latents,
+             depth_latents=depth_latents, ref_latents=ref_latents, y=yv, final_latents=x, video=video, recon=recon,
+             flow_rel=flow_rel, diff=diff, coords_rel=coords_rel)
+
+
 def make_sched(ref):
     """sigma/timestep tables of the in-tree order-1 solver and one step, 50 steps shift 5."""
     sig = ref.fm.get_sampling_sigmas(50, 5.0)
@@ -563,6 +729,12 @@ if __name__ == "__main__":
         make_dit_guid_grads(ref)
     if what in ("dit14b", "all"):
         make_block_14b_width(ref)
+    if what in ("dit14blong", "all"):
+        make_block_14b_long(ref)
+    if what in ("teacache_loop", "all"):
+        make_teacache_loop(ref)
+    if what in ("chain", "all"):
+        make_pipeline_chain(ref)
     if what in ("loop", "all"):
         make_loop(ref)
     if what in ("vae", "all"):

@@ -103,3 +103,51 @@ def test_omnimae_vit_patch_features():
     assert rel_err(sd["trunk.pos_embed"][0, 190:196, 760:], z["pos_tail"]) < 1e-6
     feats, cls = oom.forward_patch_features(sd, oom.normalize(z["frame"]))
     assert rel_err(feats, z["feats"]) < 2e-5 and rel_err(cls, z["cls"]) < 2e-5
+
+
+def test_geometry_oracle_matches_reference_chain():
+    """oracle/geometry.py against the reference's own back_project_coords / depth prologue / inverse_flow_norm_transform_no_diff
+    (tests/golden/pipeline_chain.npz, made by make_golden.py:make_pipeline_chain)."""
+    from oracle import geometry as og
+    z = load_npz("pipeline_chain.npz")
+    H = W = 32
+    ffc = og.back_project_coords(z["depth_pred"], H, W).permute(2, 0, 1)[None, :, None]
+    assert rel_err(ffc, z["first_frame_coords"]) < 1e-6
+    assert rel_err(og.depth_control_image(ffc), z["depth_pixel_values"]) < 1e-6
+    bad = og.back_project_coords(z["depth_bad"], H, W).permute(2, 0, 1)[None, :, None]
+    assert rel_err(og.depth_control_image(bad), z["depth_pixel_values_bad"]) < 1e-6
+    flow, diff = og.recover_flow(z["recon"], z["first_frame_coords"])
+    assert rel_err(flow, z["flow_rel"]) < 1e-6 and rel_err(diff, z["diff"]) < 1e-7
+    assert rel_err(og.stage1_coords(z["recon"], z["first_frame_coords"]), z["coords_rel"]) < 1e-6
+
+
+def test_chain_oracle_matches_reference():
+    """The whole stage-1 chain (conditioning encodes -> CFG loop -> decode -> decoder prompt -> coordinates) composed from the
+    oracle pieces equals the chain composed from the reference's modules."""
+    from oracle import dit as odit, geometry as og, sched as osched, vae as ovae
+    from weights import fill
+    from util import load_keys
+    z = load_npz("pipeline_chain.npz")
+    NF = int(z["num_frames"])
+    vsd = fill(load_keys("vae_keys.json"), 2024)
+    enc = lambda v: ovae.vae_encode(vsd, v.float())[:, :16]
+    ctrl = enc(og.preprocess_image(z["image01"].repeat(1, 1, NF, 1, 1)))
+    assert rel_err(ctrl, z["control_latents"]) < 2e-5
+    depth = enc(z["depth_pixel_values"].repeat(1, 1, NF, 1, 1))
+    assert rel_err(depth, z["depth_latents"]) < 2e-5
+    refl = enc(og.preprocess_image(z["image01"]))[:, :, 0]
+    assert rel_err(refl, z["ref_latents"]) < 2e-5
+    y = torch.cat([ctrl, torch.zeros_like(ctrl), depth], dim=1)
+    sd = fill(load_keys("dit_tiny_keys.json"), 1234)
+    cfg = TINY
+    ts, sig = osched.set_timesteps(osched.sampling_sigmas(int(z["steps"]), float(z["shift"])))
+
+    def fn(x2, t2):
+        return odit.dit_forward(sd, cfg, x2, t2, [z["ctx_u"], z["ctx_c"]], 2 * 2 * 2, torch.cat([z["clip"]] * 2), torch.cat([y] * 2),
+                                torch.cat([refl] * 2))
+    final = osched.denoise_loop(fn, z["lat0"], ts, sig, float(z["guidance"]))
+    assert rel_err(final, z["final_latents"]) < 1e-4
+    video = ovae.vae_decode(vsd, final).clamp(-1, 1)
+    assert rel_err(video, z["video"]) < 1e-4
+    recon = ovae.decoder_adaptor(fill(load_keys("adaptor_dec_keys.json"), 77), video)
+    assert rel_err(recon, z["recon"]) < 1e-4

@@ -234,3 +234,49 @@ def test_shipping_library_has_no_ablation_switches():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"M4D_GEMM_ABL" not in blob and b"M4D_ATTN_ABL" not in blob
     assert b"M4D_GEMM_VARIANT" in blob          # (the A/B switches between correct kernels are still there)
+
+
+def _teacache_loop(m, z, tag, dev="cpu", dtype=torch.float32):
+    """The loop of make_golden.py:make_teacache_loop on the product model; returns (decisions, trajectory)."""
+    from more4d_amd.models.cache_utils import get_teacache_coefficients
+    from more4d_amd.utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas
+    steps = int(z["steps"])
+    coeff = get_teacache_coefficients("Wan2.1-Fun-14B-Control")
+    assert np.allclose(coeff, z["coeff"].numpy())
+    m.enable_teacache(coeff, steps, float(z[f"{tag}_thresh"]), num_skip_start_steps=1, offload=False)
+    sch = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
+    sch.set_timesteps(sigmas=get_sampling_sigmas(steps, float(z["shift"])), device=dev)
+    x = z["lat"].to(dev).float().clone()
+    y2 = torch.cat([z["y"]] * 2).to(dev, dtype)
+    ref2 = torch.cat([z["full_ref"]] * 2).to(dev, dtype)
+    clip2 = torch.cat([z["clip"]] * 2).to(dev)
+    ctx = [z["ctx_u"].to(dev), z["ctx_c"].to(dev)]
+    calc, traj = [], []
+    with torch.no_grad():
+        for i, t in enumerate(sch.timesteps):
+            v = m(x=torch.cat([x, x]).to(dtype), t=t.to(dev).expand(2), context=ctx, seq_len=256, clip_fea=clip2, y=y2, full_ref=ref2)
+            calc.append(bool(m.should_calc))
+            sch.step_cfg_(x, v.contiguous(), float(z["guidance"]), i, round_dtype=dtype)
+            traj.append(x.clone())
+    m.disable_teacache()
+    return calc, torch.stack(traj)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_teacache_matches_reference_run(monkeypatch, tag):
+    """TeaCache (cache_utils.py:19-74 + the hooks wan_transformer4d.py:1201-1270, 1336-1339) pinned to a reference run: the
+    same compute / skip decision at every step and the same latent trajectory (host logic over the torch stand-ins)."""
+    from more4d_amd.models import WanTransformer4DModel
+    cpu_ops.install(monkeypatch)
+    import more4d_amd.ops as real
+    for n in ("rel_l1", "axpby"):
+        monkeypatch.setattr(real, n, getattr(cpu_ops, n))
+    z = load_npz("teacache_loop.npz")
+    m = WanTransformer4DModel(**TINY)
+    m.load_state_dict(fill(load_keys("dit_tiny_keys.json"), 1234))
+    m.eval()
+    calc, traj = _teacache_loop(m, z, tag)
+    assert calc == [bool(c) for c in z[f"{tag}_calc"]], (calc, z[f"{tag}_calc"])
+    assert not all(calc) and any(calc[1:])
+    assert rel_err(traj, z[f"{tag}_traj"]) < 2e-4
+    assert rel_err(traj[-1], z[f"{tag}_final"]) < 2e-4
