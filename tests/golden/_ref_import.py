@@ -113,6 +113,10 @@ def _install_third_party_names():
             self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
             self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
             self.std = torch.exp(0.5 * self.logvar)
+            self.var = torch.exp(self.logvar)
+
+        def kl(self, other=None):        # published: summed over dims [1, 2, 3] (the 5-D video latent keeps its last axis)
+            return 0.5 * torch.sum(torch.pow(self.mean, 2) + self.var - 1.0 - self.logvar, dim=[1, 2, 3])
 
         def sample(self, generator=None):
             eps = torch.randn(self.mean.shape, generator=generator, dtype=self.mean.dtype)

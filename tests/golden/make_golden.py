@@ -619,6 +619,83 @@ def make_pipeline_chain(ref):
              flow_rel=flow_rel, diff=diff, coords_rel=coords_rel)
 
 
+def make_vae_train(ref):
+    """One train_vae.py step (scripts/4D_STraG_training/train_vae.py:434-495, loss :173-187: L1 summed over the sample + 1e-6 KL)
+    on [1,3,5,32,32] targets with the reference's modules, `--finetune_vae_decoder`:
+      A ("as written"): the encode runs under torch.no_grad() (:444-448), so only decoder_prompt and vae.model.decoder (+ conv2)
+        receive gradients — through decode_memory_saver = decode_full (wan_vae.py:633-676: per-latent-frame checkpoint, the
+        streaming cache DETACHED between slices, then clamp_(-1, 1));
+      B ("gradient through the frozen encoder"): the same step with the no_grad removed — what encode_memory_saver = encode_full
+        (wan_vae.py:549-613) exists for: gradients reach encoder_prompt through the frozen encoder, and the KL term has a
+        gradient path.
+    Stored: inputs, eps of posterior.sample(), forward values, loss terms, and for every parameter with a gradient its norm and a
+    4096-value subsample (weights come from the seeded recipe)."""
+    import json
+    from weights import fill
+    tv = _reference_functions(os.path.join(_ref_import.REF_ROOT, "scripts/4D_STraG_training/train_vae.py"), ["compute_loss"])
+    import types
+    args = types.SimpleNamespace(rec_loss="l1", kl_scale=1e-6)
+    torch.set_grad_enabled(True)
+    try:
+        vae = ref.vae.AutoencoderKLWan()
+        shapes = {k: list(t.shape) for k, t in vae.state_dict().items()}
+        vae.load_state_dict(fill(shapes, seed=2024))
+        ea, da = ref.traj.VAEEncoderadaptor(), ref.traj.VAEDecoderadaptor()
+        ea_shapes = {k: list(t.shape) for k, t in ea.state_dict().items()}
+        da_shapes = {k: list(t.shape) for k, t in da.state_dict().items()}
+        with open(os.path.join(HERE, "adaptor_enc_keys.json"), "w") as fh:
+            json.dump(ea_shapes, fh, indent=0, sort_keys=True)
+        ea.load_state_dict(fill(ea_shapes, seed=78))
+        da.load_state_dict(fill(da_shapes, seed=77))
+        ea.requires_grad_(True).train()
+        da.requires_grad_(True).train()
+        vae.model.encoder.requires_grad_(False).eval()          # train_vae.py:355
+        vae.model.decoder.requires_grad_(True).train()          # :357-358
+        g = torch.Generator().manual_seed(31)
+        coords = torch.randn(1, 3, 5, 32, 32, generator=g) * 0.3
+        targets = coords - coords[:, :, 0:1]                    # normalize_coordinates default branch (:168-170)
+        out = {"targets": targets}
+
+        def named(prefix, mod):
+            return {prefix + n: p for n, p in mod.named_parameters()}
+        allp = {**named("encoder_prompt.", ea), **named("decoder_prompt.", da), **named("vae.", vae)}
+
+        def record(tag):
+            n = 0
+            for name, p in allp.items():
+                if p.grad is not None:
+                    out[f"{tag}/grad/{name}"] = grad_sample(p.grad)
+                    out[f"{tag}/norm/{name}"] = p.grad.norm()
+                    n += 1
+                    p.grad = None
+            print(tag, "parameters with gradients:", n)
+
+        for tag in ("A", "B"):
+            pseudo = ea(targets) * 2 - 1
+            eg = torch.Generator().manual_seed(5)
+            if tag == "A":
+                with torch.no_grad():
+                    posterior = vae.encode_memory_saver(pseudo).latent_dist
+                    latents = posterior.sample(generator=eg)
+            else:
+                posterior = vae.encode_memory_saver(pseudo).latent_dist
+                latents = posterior.sample(generator=eg)
+            recon = vae.decode_memory_saver(latents).sample
+            rec2 = da(recon)
+            loss, nll, kl = tv["compute_loss"](rec2, targets, posterior, args)
+            loss.backward()
+            eps = torch.randn(posterior.mean.shape, generator=torch.Generator().manual_seed(5))
+            assert torch.allclose(latents.detach(), posterior.mean.detach() + posterior.std.detach() * eps)
+            out.update({f"{tag}/pseudo": pseudo.detach(), f"{tag}/params": posterior.parameters.detach(), f"{tag}/eps": eps,
+                        f"{tag}/latents": latents.detach(), f"{tag}/recon": recon.detach(), f"{tag}/reconstructions": rec2.detach(),
+                        f"{tag}/loss": loss.detach(), f"{tag}/nll": nll.detach(), f"{tag}/kl": kl.detach()})
+            print(tag, "loss", float(loss), "nll", float(nll), "kl", float(kl), "clamped", float((recon.abs() >= 1).float().mean()))
+            record(tag)
+        npz_save("vae_train.npz", **out)
+    finally:
+        torch.set_grad_enabled(False)
+
+
 def make_sched(ref):
     """sigma/timestep tables of the in-tree order-1 solver and one step, 50 steps shift 5."""
     sig = ref.fm.get_sampling_sigmas(50, 5.0)
@@ -735,6 +812,8 @@ if __name__ == "__main__":
         make_teacache_loop(ref)
     if what in ("chain", "all"):
         make_pipeline_chain(ref)
+    if what in ("vaetrain", "all"):
+        make_vae_train(ref)
     if what in ("loop", "all"):
         make_loop(ref)
     if what in ("vae", "all"):
