@@ -89,6 +89,14 @@ class _AdaptorBase(nn.Module):
         return ops.groupnorm_cl(x.view(F, HW, -1), self._f32(norm.weight), self._f32(norm.bias), F=F, HW=HW,
                                 groups=norm.num_groups, eps=norm.eps, silu=True).view(F * HW, -1)
 
+    def _run(self, x):
+        """Per-sample forward; under autograd (trainable adaptor or an input that needs its gradient, train_vae.py:438-455) every
+        sample is one `vae_autograd.AdaptorFn` node whose backward recomputes groups of frames with the HIP kernels."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ..vae_autograd import adaptor_train
+            return adaptor_train(self, x)
+        return torch.stack([self._forward_one(u) for u in x])
+
     def _resnet(self, h, blk, F, H, W):
         c = blk.in_channels
         y, _ = self._conv(self._gn_swish(h, blk.norm1, F, H * W), blk.conv1, F, H, W, c)
@@ -127,20 +135,21 @@ class VAEEncoderadaptor(_AdaptorBase):
         self.conv_out = zero_module(torch.nn.Conv2d(block_out, in_channels, kernel_size=3, stride=1, padding=1))
         self._setup()
 
+    def _forward_one(self, x):
+        """x [3, F, H, W] -> sigmoid(net(x) + x)."""
+        C, F, H, W = x.shape
+        T, dev = self.dtype, self.device
+        xb = x.to(device=dev, dtype=T).contiguous()
+        h = ops.ncthw_to_cl(xb, T, Cp=8).view(F * H * W, 8)
+        h, _ = self._conv(h, self.conv_in, F, H, W, 8)
+        for blk in self.down[0].block:
+            h = self._resnet(h, blk, F, H, W)
+        h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
+        return ops.cl_to_ncthw(h, T, C=C, T=F, H=H, W=W, pixel_stride=cop, act=2, aux=xb)
+
     def forward(self, x):
         """x [B, 3, F, H, W] -> sigmoid(net(x) + x), same shape (reference :177-196)."""
-        B, C, F, H, W = x.shape
-        T, dev = self.dtype, self.device
-        outs = []
-        for b in range(B):
-            xb = x[b].to(device=dev, dtype=T).contiguous()
-            h = ops.ncthw_to_cl(xb, T, Cp=8).view(F * H * W, 8)
-            h, _ = self._conv(h, self.conv_in, F, H, W, 8)
-            for blk in self.down[0].block:
-                h = self._resnet(h, blk, F, H, W)
-            h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
-            outs.append(ops.cl_to_ncthw(h, T, C=C, T=F, H=H, W=W, pixel_stride=cop, act=2, aux=xb))
-        return torch.stack(outs)
+        return self._run(x)
 
 
 class VAEDecoderadaptor(_AdaptorBase):
@@ -175,17 +184,17 @@ class VAEDecoderadaptor(_AdaptorBase):
         self.conv_out = torch.nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
         self._setup()
 
+    def _forward_one(self, z):
+        C, F, H, W = z.shape
+        T, dev = self.dtype, self.device
+        zb = z.to(device=dev, dtype=T).contiguous()
+        h = ops.ncthw_to_cl(zb, T, Cp=8).view(F * H * W, 8)
+        h, _ = self._conv(h, self.conv_in, F, H, W, 8)
+        for blk in self.up[0].block:
+            h = self._resnet(h, blk, F, H, W)
+        h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
+        return ops.cl_to_ncthw(h, T, C=self.out_ch, T=F, H=H, W=W, pixel_stride=cop)
+
     def forward(self, z):
         """z [B, 3, F, H, W] -> [B, out_ch, F, H, W] (reference :260-279)."""
-        B, C, F, H, W = z.shape
-        T, dev = self.dtype, self.device
-        outs = []
-        for b in range(B):
-            zb = z[b].to(device=dev, dtype=T).contiguous()
-            h = ops.ncthw_to_cl(zb, T, Cp=8).view(F * H * W, 8)
-            h, _ = self._conv(h, self.conv_in, F, H, W, 8)
-            for blk in self.up[0].block:
-                h = self._resnet(h, blk, F, H, W)
-            h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
-            outs.append(ops.cl_to_ncthw(h, T, C=self.out_ch, T=F, H=H, W=W, pixel_stride=cop))
-        return torch.stack(outs)
+        return self._run(z)

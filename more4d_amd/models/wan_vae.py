@@ -157,11 +157,16 @@ def _round(n, m):
 
 
 class _Act:
-    """A channels-last activation: `data` is a [t*h*w, C] row-strided 2-D view."""
-    __slots__ = ("data", "t", "h", "w", "c")
+    """A channels-last activation: `data` is a [t*h*w, C] row-strided 2-D view (`g`: its gradient in the training runner)."""
+    __slots__ = ("data", "t", "h", "w", "c", "g")
 
     def __init__(self, data, t, h, w, c):
         self.data, self.t, self.h, self.w, self.c = data, t, h, w, c
+        self.g = None
+
+
+def _data(a):
+    return a.data if isinstance(a, _Act) else a
 
 
 class _Stage:
@@ -244,7 +249,7 @@ class _Runner:
         else:
             ho, wo, pad = hl, wl, kh // 2
         y = ops.conv_cl(x.data, w, b, Tin=x.t, Hin=x.h, Win=x.w, Cin=x.c, k=(1, kh, kw), stride=(1, stride_hw, stride_hw),
-                        pad=(0, pad, pad), out_thw=(t, ho, wo), resid=resid, out=out, ups=ups, tsplit=tsplit,
+                        pad=(0, pad, pad), out_thw=(t, ho, wo), resid=_data(resid), out=out, ups=ups, tsplit=tsplit,
                         x_pixel_stride=x_pixel_stride)
         return _Act(y, t, ho, wo, cop)
 
@@ -254,22 +259,46 @@ class _Runner:
         st = self.stage(key, kt - 1, t, h, w, cip)
         fill(st.chunk(t))
         y = ops.conv_cl(st.buf, wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=(kt, kh, kw), pad=(0, kh // 2, kw // 2),
-                        out_thw=(t, h, w), resid=resid, out=out)
+                        out_thw=(t, h, w), resid=_data(resid), out=out)
         st.roll(t)
         return _Act(y, t, h, w, cop)
 
+    # fill callbacks: write a chunk into a conv's staging buffer (the training runner returns objects that also know
+    # how to take the gradient of that chunk back to where it came from)
     def norm_into(self, x: _Act, norm, silu=True):
         g = self.gamma(norm)
         return lambda dst: ops.rmsnorm_silu_cl(x.data, g, silu=silu, out=dst)
+
+    def copy_into(self, x: _Act):
+        return lambda dst: dst.copy_(x.data)
+
+    def tsplit_view(self, y: _Act, c):
+        """[t, h, w, 2c] read as 2t frames of c channels (even frame = first half, odd frame = second half, :138-141)."""
+        return _Act(y.data, y.t, y.h, y.w, c)
+
+    def video_into(self, x_ncthw):
+        _, t, H, W = x_ncthw.shape
+        return lambda dst: ops.ncthw_to_cl(x_ncthw, self.T, Cp=self.cin_pad, out=dst.view(t, H, W, -1))
+
+    def snapshot(self):
+        """The streaming state in front of the next chunk: every conv's tail frames and the first-chunk flags (what the
+        reference's `_clone_cache`, wan_vae.py:604-613, captures for the checkpointed twins)."""
+        return ({k: (st.n_tail, st.h, st.w, st.c, st.buf[:st.n_tail].clone()) for k, st in self.stages.items()}, dict(self.flags))
+
+    def restore(self, snap):
+        tails, flags = snap
+        self.stages = {}
+        for k, (n_tail, h, w, c, tail) in tails.items():
+            st = _Stage(n_tail, 1, h, w, c, self.T, self.dev)
+            st.buf[:n_tail].copy_(tail)
+            self.stages[k] = st
+        self.flags = dict(flags)
 
     # ---- blocks
     def residual_block(self, x: _Act, blk, key, out=None):
         r = blk.residual
         y1 = self.conv_causal(key + ".residual.2", r[2], x.t, x.h, x.w, self.norm_into(x, r[0]))
-        if isinstance(blk.shortcut, nn.Identity):
-            h = x.data
-        else:
-            h = self.conv_plain(x, blk.shortcut).data
+        h = x if isinstance(blk.shortcut, nn.Identity) else self.conv_plain(x, blk.shortcut)
         return self.conv_causal(key + ".residual.6", r[6], x.t, x.h, x.w, self.norm_into(y1, r[3]), resid=h, out=out)
 
     def attention_block(self, x: _Act, blk):
@@ -304,10 +333,9 @@ class _Runner:
                     self.flags[key] = True
                 else:
                     # time_conv over [tail, x]; its tail starts at zero and never sees chunk 0 (:124-132)
-                    y = self.conv_causal(key + ".time_conv", rs.time_conv, x.t, x.h, x.w, lambda dst: dst.copy_(x.data))
+                    y = self.conv_causal(key + ".time_conv", rs.time_conv, x.t, x.h, x.w, self.copy_into(x))
                     # channels [0,C) -> even frames, [C,2C) -> odd frames (:138-141): read through the tsplit view
-                    return self.conv_plain(_Act(y.data, x.t, x.h, x.w, x.c), conv, ups=True, tsplit=True,
-                                           x_pixel_stride=2 * x.c)
+                    return self.conv_plain(self.tsplit_view(y, x.c), conv, ups=True, tsplit=True, x_pixel_stride=2 * x.c)
             return self.conv_plain(x, conv, ups=True)
         if mode in ("downsample2d", "downsample3d"):
             conv = rs.resample[1]
@@ -334,8 +362,7 @@ class _Runner:
         """x_ncthw [3, t, H, W] (one chunk) -> writes [t', h, w, 2z] into out_view."""
         enc = self.vae.model.encoder
         _, t, H, W = x_ncthw.shape
-        a = self.conv_causal("enc.conv1", enc.conv1, t, H, W,
-                             lambda dst: ops.ncthw_to_cl(x_ncthw, self.T, Cp=self.cin_pad, out=dst.view(t, H, W, -1)))
+        a = self.conv_causal("enc.conv1", enc.conv1, t, H, W, self.video_into(x_ncthw))
         for i, layer in enumerate(enc.downsamples):
             key = f"enc.down.{i}"
             a = self.residual_block(a, layer, key) if isinstance(layer, ResidualBlock) else self.resample(a, layer, key)
@@ -348,7 +375,7 @@ class _Runner:
     def decoder(self, z_act: _Act):
         """z_act: one latent frame [1*h*w, z] -> _Act [t_out*H*W, 4] (3 channels + pad)."""
         dec = self.vae.model.decoder
-        a = self.conv_causal("dec.conv1", dec.conv1, z_act.t, z_act.h, z_act.w, lambda dst: dst.copy_(z_act.data))
+        a = self.conv_causal("dec.conv1", dec.conv1, z_act.t, z_act.h, z_act.w, self.copy_into(z_act))
         a = self.residual_block(a, dec.middle[0], "dec.mid.0")
         a = self.attention_block(a, dec.middle[1])
         a = self.residual_block(a, dec.middle[2], "dec.mid.2")
@@ -460,21 +487,38 @@ class AutoencoderKLWan(nn.Module):
             pos += run.encoder(chunk, view)
         a = _Act(enc_out.view(lat_t * h * w, z2), lat_t, h, w, z2)
         y = run.conv_plain(a, self.model.conv1)
-        zc = self.latent_channels
-        inv = (1.0 / self.std).to(dev)
-        ch_scale = torch.cat([inv, torch.ones(zc, device=dev)])
-        ch_shift = torch.cat([-self.mean.to(dev) * inv, torch.zeros(zc, device=dev)])
+        ch_scale, ch_shift = self._latent_affine(dev)
         return ops.cl_to_ncthw(y.data, T, C=z2, T=lat_t, H=h, W=w, pixel_stride=y.data.stride(0), ch_scale=ch_scale,
                                ch_shift=ch_shift)
 
+    def _latent_affine(self, dev):
+        """Per-channel (scale, shift) of the encoder output [mu | logvar]: mu <- (mu - mean) / std, logvar untouched (:539-545)."""
+        zc = self.latent_channels
+        inv = (1.0 / self.std).to(dev)
+        return (torch.cat([inv, torch.ones(zc, device=dev)]),
+                torch.cat([-self.mean.to(dev) * inv, torch.zeros(zc, device=dev)]))
+
     def _encode(self, x):
         return torch.stack([self._encode_one(u) for u in x])
+
+    def _wants_grad(self, x, mods):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
 
     def encode(self, x, return_dict=True):
         dist = DiagonalGaussianDistribution(self._encode(x))
         return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
 
-    encode_memory_saver = encode   # training-time checkpointed twin (wan_vae.py:549-613): same forward values
+    def encode_memory_saver(self, x, return_dict=True):
+        """Training-time twin (reference `encode_full`, wan_vae.py:549-613, wrapper :783-812): same forward values; under
+        autograd the gradient is computed chunk by chunk with the streaming cache cut between chunks, like the reference's
+        per-chunk checkpoint + `_detach_cache`.  Without grad it IS `encode`."""
+        if self._wants_grad(x, [self.model.encoder, self.model.conv1]):
+            from ..vae_autograd import vae_encode_train
+            params = vae_encode_train(self, x)
+        else:
+            params = self._encode(x)
+        dist = DiagonalGaussianDistribution(params)
+        return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
 
     # ---- decode
     def _decode_one(self, z):
@@ -497,7 +541,14 @@ class AutoencoderKLWan(nn.Module):
         out = self._decode(z).sample
         return DecoderOutput(sample=out) if return_dict else (out,)
 
-    decode_memory_saver = decode
+    def decode_memory_saver(self, z, return_dict=True):
+        """Training-time twin (reference `decode_full`, wan_vae.py:633-676, wrapper :815-843)."""
+        if self._wants_grad(z, [self.model.decoder, self.model.conv2]):
+            from ..vae_autograd import vae_decode_train
+            out = vae_decode_train(self, z)
+        else:
+            out = self._decode(z).sample
+        return DecoderOutput(sample=out) if return_dict else (out,)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_path, additional_kwargs={}):

@@ -473,6 +473,107 @@ def rel_l1(prev, cur):
     return d / p_
 
 
+# ------------------------------------------------------------------ VAE / adaptor training (vae_autograd.py)
+def pad_transpose(src, pixel_stride, C, T, H, W, Hp, Wp, pad_top, pad_left, nshift, cols, rows=None):
+    """Channels-last frames src [T, H, W] x C (pixel stride `pixel_stride`) -> pixel-major panels [nshift*C (or rows), cols]:
+    out[s*C + c, q] = P[q + s][c] where P is the stack of frames zero-padded to [T, Hp, Wp] (image at (pad_top, pad_left)) and
+    flattened; columns beyond the last frame are zero.  The operand layout of the conv weight-gradient GEMMs."""
+    _dev(src)
+    rows = rows or nshift * C
+    out = torch.empty((rows, cols), device=src.device, dtype=src.dtype)
+    if rows > nshift * C:
+        out[nshift * C:].zero_()
+    check(_lib.load().m4d_pad_transpose(dt_code(src.dtype), _ptr(src), pixel_stride, C, T, H, W, Hp, Wp, pad_top, pad_left, nshift,
+                                        _ptr(out), cols, _stream()), "m4d_pad_transpose")
+    return out
+
+
+def gemm_bt_batched(a, w, *, M, N, K, nb1, a_bs1, w_bs1, nb2=1, a_bs2=0, w_bs2=0):
+    """float32 out[i2, i1] = A_(i1,i2) [M, K] . W_(i1,i2) [N, K]^T with A_(i1,i2) = a + i1*a_bs1 + i2*a_bs2 (elements; row stride
+    a.stride(0)), likewise W.  Split-K partial products of the conv weight gradient: K-slices as batch 1, taps as batch 2."""
+    _dev(a, w)
+    if a.dtype != w.dtype or a.stride(-1) != 1 or w.stride(-1) != 1:
+        raise TypeError("gemm_bt_batched: operands of one dtype with contiguous rows")
+    out = torch.empty((nb2, nb1, M, N), device=a.device, dtype=torch.float32)
+    check(_lib.load().m4d_gemm_bt_batched(dt_code(a.dtype), _ptr(a), a.stride(0), a_bs1, a_bs2, _ptr(w), w.stride(0), w_bs1, w_bs2,
+                                          _ptr(out), M, N, K, nb1, nb2, _stream()), "m4d_gemm_bt_batched")
+    return out
+
+
+def wgrad_reduce(part, dw, dt, M):
+    """dw[co, dt, dh, dw_, ci] += sum_s part[dh, s, co, dw_*cip + ci]  (part float32 [kh, S, M, kw*cip], dw float32
+    [cop, kt, kh, kw, cip])."""
+    _dev(part, dw)
+    kh, S, Mp, N = part.shape
+    cop, kt, kh2, kw, cip = dw.shape
+    if kh != kh2 or N != kw * cip or Mp < cop or part.dtype != torch.float32 or dw.dtype != torch.float32:
+        raise ValueError("wgrad_reduce: shape mismatch")
+    check(_lib.load().m4d_wgrad_reduce(_ptr(part), _ptr(dw), S, Mp, cop, kt, kh, kw, cip, dt, _stream()), "m4d_wgrad_reduce")
+    return dw
+
+
+def rmsnorm_silu_cl_bwd(x, gamma, dy, *, silu=True):
+    """Backward of rmsnorm_silu_cl: x, dy [P, C] (row-strided) -> (dx [P, C] in x.dtype, dgamma float32 [C])."""
+    _dev(x, gamma, dy)
+    P, ldx = _rows2d(x)
+    Pd, ldd = _rows2d(dy)
+    C = x.shape[-1]
+    if Pd != P or dy.shape[-1] != C or dy.dtype != x.dtype:
+        raise ValueError("rmsnorm_silu_cl_bwd: dy mismatch")
+    dx = torch.empty((P, C), device=x.device, dtype=x.dtype)
+    dg = torch.zeros(C, device=x.device, dtype=torch.float32)
+    check(_lib.load().m4d_rmsnorm_silu_cl_bwd(dt_code(x.dtype), _ptr(x), ldx, _ptr(gamma), _ptr(dy), ldd, _ptr(dx), C, _ptr(dg), P, C,
+                                              int(silu), _stream()), "m4d_rmsnorm_silu_cl_bwd")
+    return dx, dg
+
+
+def softmax_rows_bwd(p, dp, *, scale, C):
+    """p T [R, Cpad] (softmax rows, columns >= C zero), dp float32 [R, Cpad] -> dS T [R, Cpad] = scale * p * (dp - rowsum(p*dp))."""
+    _dev(p, dp)
+    R, Cpad = p.shape
+    if dp.shape != p.shape or dp.dtype != torch.float32 or not p.is_contiguous() or not dp.is_contiguous():
+        raise ValueError("softmax_rows_bwd: contiguous p (T) and dp (float32) of one shape")
+    out = torch.empty_like(p)
+    check(_lib.load().m4d_softmax_rows_bwd(dt_code(p.dtype), _ptr(p), _ptr(dp), _ptr(out), R, C, Cpad, float(scale), _stream()),
+          "m4d_softmax_rows_bwd")
+    return out
+
+
+def upsample2x_cl(x, t, h, w, c, *, tsplit=False):
+    """Nearest-exact 2x of channels-last frames [t, h, w, c] -> [t*2h*2w, c]; tsplit: the input holds 2c channels per pixel and
+    frame 2i / 2i+1 of the result comes from the first / second channel half (wan_vae.py:138-141)."""
+    _dev(x)
+    tt = t * (2 if tsplit else 1)
+    out = torch.empty((tt * 4 * h * w, c), device=x.device, dtype=x.dtype)
+    check(_lib.load().m4d_upsample2x_cl(dt_code(x.dtype), _ptr(x), _ptr(out), t, h, w, c, int(tsplit), 0, _stream()), "m4d_upsample2x_cl")
+    return out
+
+
+def upsample2x_cl_bwd(du, t, h, w, c, *, tsplit=False):
+    """Transpose of upsample2x_cl: du [t'*2h*2w, c] -> [t*h*w, c (2c with tsplit)] (sum over each 2x2 block)."""
+    _dev(du)
+    du = du.contiguous()
+    out = torch.empty((t * h * w, c * (2 if tsplit else 1)), device=du.device, dtype=du.dtype)
+    check(_lib.load().m4d_upsample2x_cl(dt_code(du.dtype), _ptr(du), _ptr(out), t, h, w, c, int(tsplit), 1, _stream()),
+          "m4d_upsample2x_cl(bwd)")
+    return out
+
+
+def groupnorm_cl_bwd(x, weight, bias, dy, *, F, HW, groups=32, eps=1e-6, silu=True):
+    """Backward of groupnorm_cl(+swish): x, dy [F, HW, C] -> (dx [F, HW, C], dweight float32 [C], dbias float32 [C])."""
+    _dev(x, weight, bias, dy)
+    C = x.shape[-1]
+    if not x.is_contiguous() or not dy.is_contiguous() or dy.dtype != x.dtype:
+        raise ValueError("groupnorm_cl_bwd: contiguous x, dy of one dtype")
+    dx = torch.empty_like(x)
+    dwt = torch.zeros(C, device=x.device, dtype=torch.float32)
+    dbs = torch.zeros(C, device=x.device, dtype=torch.float32)
+    ws = torch.zeros((F * groups * 4,), device=x.device, dtype=torch.float32)
+    check(_lib.load().m4d_groupnorm_cl_bwd(dt_code(x.dtype), _ptr(x), _ptr(weight), _ptr(bias), _ptr(dy), _ptr(dx), _ptr(dwt), _ptr(dbs),
+                                           _ptr(ws), F, HW, C, groups, float(eps), int(silu), _stream()), "m4d_groupnorm_cl_bwd")
+    return dx, dwt, dbs
+
+
 def minmax(x, n_groups):
     """x float32, contiguous, viewed as [n_groups, -1] -> float32 [n_groups, 2] = (min, max) of every group."""
     _dev(x)
@@ -592,6 +693,7 @@ def add(a, b, out=None):
 
 
 ACT_SILU, ACT_GELU_TANH, ACT_GELU_ERF = 1, 2, 3
+ACT_SIGMOID, ACT_SIGMOID_OUT, ACT_CLAMP1 = 4, 5, 6      # sigmoid(pre); sigmoid given its OUTPUT; clamp(pre, -1, 1)
 
 
 def act_bwd_(dy, pre, act):

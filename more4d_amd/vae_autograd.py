@@ -1,0 +1,584 @@
+"""Training path of the Motion-Sensitive VAE and its trajectory adaptors (`encode_full` / `decode_full`,
+wan_vae.py:549-676, `encode_memory_saver` / `decode_memory_saver` :783-843; scripts/4D_STraG_training/train_vae.py:434-495).
+
+torch.autograd is only the tape between the three big nodes (encoder adaptor -> VAE encode -> VAE decode -> decoder adaptor);
+inside a node every forward AND backward step is a HIP kernel (ops.*) on channels-last activations.  Like the reference's
+checkpointed twins, a node's forward keeps no activations: it records the streaming state in front of every chunk
+(`_Runner.snapshot`) and the backward recomputes one chunk at a time with a small tape (`_TrainRunner`), walks it in reverse
+and moves on.  The reference detaches the streaming cache between chunks (`_detach_cache`, :616-621), so a chunk's gradient
+reaches its own input frames and the parameters but never the frames of earlier chunks — restated here by simply not
+propagating into the tail frames of a conv's staging buffer.
+
+Gradients of a convolution (stride 1, causal in T, zero padding in H/W):
+  * data gradient  = the SAME implicit-GEMM conv kernel run over dy (followed by kt-1 zero frames) with the taps flipped and
+    the channel roles swapped;
+  * weight gradient = sum over pixels of dy[p, co] * x[p + tap, ci]: dy and x are transposed once into pixel-major panels in a
+    zero-padded frame geometry (`ops.pad_transpose`), in which every tap is a plain column offset, then one batched split-K GEMM
+    per temporal tap (`ops.gemm_bt_batched`) and a reduction of the partial sums (`ops.wgrad_reduce`).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops
+from .models.wan_vae import _Act, _Runner, _Stage, _round
+
+
+# ------------------------------------------------------------------------------------------------ conv gradients
+def _flipped(wp, cop, k, cip):
+    """packed forward weight [cop, (kt,kh,kw,cip)] -> data-gradient weight [cip, (kt,kh,kw flipped), cop8]."""
+    kt, kh, kw = k
+    w5 = wp.view(cop, kt, kh, kw, cip).flip(1, 2, 3).permute(4, 1, 2, 3, 0)      # [cip, kt, kh, kw, cop]
+    cop8 = _round(cop, 8)
+    out = torch.zeros((cip, kt, kh, kw, cop8), device=wp.device, dtype=wp.dtype)
+    out[..., :cop] = w5
+    return out.view(cip, -1), cop8
+
+
+def conv_dgrad(dy, wp, cop, cip, k, t, h, w, stride=(1, 1, 1)):
+    """dy [To*Ho*Wo, cop] (rows contiguous over pixels) -> gradient w.r.t. the t chunk frames of the conv input [t*h*w, cip].
+    stride (1,1,1): h, w are also the output extent; (1,2,2): Conv2d stride 2 behind ZeroPad2d(0,1,0,1) (:86-92);
+    (2,1,1): the temporal stride-2 conv of downsample3d over [1 tail frame + t chunk frames] (:160-161)."""
+    kt, kh, kw = k
+    wd, cop8 = _flipped(wp, cop, k, cip)
+    T, dev = dy.dtype, dy.device
+    if stride == (1, 1, 1):
+        buf = torch.zeros((t + kt - 1, h * w, cop8), device=dev, dtype=T)
+        buf[:t, :, :cop] = dy.view(t, h * w, cop)
+        return ops.conv_cl(buf, wd, None, Tin=t + kt - 1, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, kh // 2, kw // 2), out_thw=(t, h, w))
+    if stride == (1, 2, 2):
+        ho, wo = h // 2, w // 2
+        buf = torch.zeros((t, h, w, cop8), device=dev, dtype=T)
+        buf[:, 0:2 * ho:2, 0:2 * wo:2, :cop] = dy.view(t, ho, wo, cop)           # zero insertion: D[2i, 2j] = dy[i, j]
+        return ops.conv_cl(buf, wd, None, Tin=t, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, kh - 1, kw - 1), out_thw=(t, h, w))
+    if stride == (2, 1, 1):
+        to = dy.shape[0] // (h * w)
+        buf = torch.zeros((t + 2, h * w, cop8), device=dev, dtype=T)             # frame 0 = D[-1] = 0, frame 1 + 2j = dy[j]
+        buf[1:1 + 2 * to:2, :, :cop] = dy.view(to, h * w, cop)
+        return ops.conv_cl(buf, wd, None, Tin=t + 2, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, 0, 0), out_thw=(t, h, w))
+    raise NotImplementedError(stride)
+
+
+def conv_wgrad(x, xps, Tin, Hin, Win, cip, dy, cop, k, pad_hw):
+    """x: the conv's input buffer ([Tin, Hin, Win] pixels of cip channels, pixel stride xps), dy [To*Ho*Wo, cop] (stride-1 conv,
+    To = Tin - kt + 1, Ho = Hin, Wo = Win) -> float32 packed-layout weight gradient [cop, kt, kh, kw, cip]."""
+    kt, kh, kw = k
+    ph, pw = pad_hw
+    To = Tin - kt + 1
+    Hp, Wp = Hin + 2 * ph, _round(Win + 2 * pw, 8)
+    P = To * Hp * Wp
+    S = max(1, min(64, P // 4096))
+    Ks = _round(-(-P // S), 64)
+    S = -(-P // Ks)
+    Pa = S * Ks
+    Pb = Pa + (kt - 1) * Hp * Wp + (kh - 1) * Wp
+    M, N = _round(cop, 4), kw * cip
+    a = ops.pad_transpose(dy, cop, cop, To, Hin, Win, Hp, Wp, 0, 0, 1, Pa, rows=M)                # [M, Pa]
+    b = ops.pad_transpose(x, xps, cip, Tin, Hin, Win, Hp, Wp, ph, pw, kw, Pb)                     # [kw*cip, Pb]
+    dw = torch.zeros((cop, kt, kh, kw, cip), device=dy.device, dtype=torch.float32)
+    for dt in range(kt):
+        part = ops.gemm_bt_batched(a, b[:, dt * Hp * Wp:], M=M, N=N, K=Ks, nb1=S, a_bs1=Ks, w_bs1=Ks, nb2=kh, a_bs2=0, w_bs2=Wp)
+        ops.wgrad_reduce(part, dw, dt, M)                                                         # part [kh, S, M, N]
+    return dw
+
+
+def _unpack_wgrad(dw, conv):
+    """packed [cop, kt, kh, kw, cip] float32 -> the parameter's own layout / dtype."""
+    w = conv.weight
+    co, ci = w.shape[0], w.shape[1]
+    g = dw[:co, :, :, :, :ci].permute(0, 4, 1, 2, 3)
+    if w.dim() == 4:
+        g = g[:, :, 0]
+    return g.contiguous()
+
+
+class _Grads:
+    """float32 accumulators for parameter gradients, keyed by the parameter object."""
+
+    def __init__(self):
+        self.g = {}
+
+    def add(self, p, val):
+        if not p.requires_grad:
+            return
+        val = val.reshape(p.shape).float()
+        if id(p) in self.g:
+            self.g[id(p)][1].add_(val)
+        else:
+            self.g[id(p)] = (p, val.clone())
+
+    def get(self, p):
+        hit = self.g.get(id(p))
+        return None if hit is None else hit[1].to(p.dtype)
+
+
+def _acc(node, g):
+    """node.g += g (first contribution is kept by reference: callers hand over freshly allocated tensors)."""
+    if node is None:
+        return
+    if node.g is None:
+        node.g = g
+    else:
+        ops.add(node.g, g.contiguous(), out=node.g)
+
+
+class _Fill:
+    """A chunk written into a conv's staging buffer + the way its gradient flows back."""
+
+    def __init__(self, fwd, bwd):
+        self.fwd, self.bwd = fwd, bwd
+
+    def __call__(self, dst):
+        return self.fwd(dst)
+
+
+# ------------------------------------------------------------------------------------------------ training runner
+class _TrainRunner(_Runner):
+    """Recomputes ONE chunk of the encoder / decoder keeping what the backward needs, then `backward()` walks the tape."""
+
+    def __init__(self, vae, device, dtype, grads, snap=None):
+        super().__init__(vae, device, dtype)
+        self.tape = []
+        self.grads = grads
+        self.video_grad = None       # gradient of the encoder's input chunk (channels-last), set by video_into's backward
+        self.last_act = None         # the most recent conv output (the network head after encoder() / decoder())
+        if snap is not None:
+            self.restore(snap)
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+    # ---- fills
+    def norm_into(self, x, norm, silu=True):
+        g = self.gamma(norm)
+
+        def bwd(dchunk):
+            dx, dg = ops.rmsnorm_silu_cl_bwd(x.data, g, dchunk, silu=silu)
+            self.grads.add(norm.gamma, dg)
+            _acc(x, dx)
+        return _Fill(lambda dst: ops.rmsnorm_silu_cl(x.data, g, silu=silu, out=dst), bwd)
+
+    def copy_into(self, x):
+        return _Fill(lambda dst: dst.copy_(x.data), lambda dchunk: _acc(x, dchunk))
+
+    def video_into(self, x_ncthw):
+        base = super().video_into(x_ncthw)
+        self.video_grad = None
+
+        def bwd(dchunk):
+            self.video_grad = dchunk
+        return _Fill(base, bwd)
+
+    def tsplit_view(self, y, c):
+        v = _Act(y.data, y.t, y.h, y.w, c)
+        self.tape.append(lambda: _acc(y, v.g))            # v.g is produced in y's own [t*h*w, 2c] layout (upsample2x_bwd)
+        return v
+
+    # ---- convs
+    def _conv_grads(self, conv, xbuf, xps, Tin, Hin, Win, cip, dy, k, pad_hw, wp, cop):
+        if conv.weight.requires_grad:
+            dw = conv_wgrad(xbuf, xps, Tin, Hin, Win, cip, dy, cop, k, pad_hw)
+            self.grads.add(conv.weight, _unpack_wgrad(dw, conv))
+        if conv.bias is not None and conv.bias.requires_grad:
+            self.grads.add(conv.bias, ops.colsum(dy)[0][:conv.bias.numel()])
+
+    def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None):
+        wgt, b, k, cip, cop = self.packed(conv)
+        kt, kh, kw = k
+        st = self.stage(key, kt - 1, t, h, w, cip)
+        fill(st.chunk(t))
+        y = ops.conv_cl(st.buf, wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=k, pad=(0, kh // 2, kw // 2),
+                        out_thw=(t, h, w), resid=None if resid is None else resid.data, out=out)
+        ya = _Act(y, t, h, w, cop)                         # (no roll: the tails of the NEXT chunk come from its own snapshot)
+        self.last_act = ya
+
+        def bwd():
+            dy = ya.g
+            if dy is None:
+                return
+            dy = dy.contiguous()
+            if resid is not None:
+                _acc(resid, dy.clone())
+            self._conv_grads(conv, st.buf, cip, st.n_tail + t, h, w, cip, dy, k, (kh // 2, kw // 2), wgt, cop)
+            fill.bwd(conv_dgrad(dy, wgt, cop, cip, k, t, h, w))
+        self.tape.append(bwd)
+        return ya
+
+    def conv_plain(self, x, conv, resid=None, out=None, stride_hw=1, ups=False, tsplit=False, x_pixel_stride=None):
+        wgt, b, k, cip, cop = self.packed(conv)
+        kt, kh, kw = k
+        assert kt == 1 and cip == x.c
+        src = x
+        if ups:           # materialise the nearest-exact 2x (and the channel-half -> frame interleave) the inference kernel fuses
+            u = ops.upsample2x_cl(x.data, x.t, x.h, x.w, x.c, tsplit=tsplit)
+            src = _Act(u, x.t * (2 if tsplit else 1), 2 * x.h, 2 * x.w, x.c)
+        t, hl, wl = src.t, src.h, src.w
+        if stride_hw == 2:
+            ho, wo, pad = hl // 2, wl // 2, 0
+        else:
+            ho, wo, pad = hl, wl, kh // 2
+        xps = src.data.stride(0)
+        y = ops.conv_cl(src.data, wgt, b, Tin=t, Hin=hl, Win=wl, Cin=cip, k=k, stride=(1, stride_hw, stride_hw), pad=(0, pad, pad),
+                        out_thw=(t, ho, wo), resid=None if resid is None else resid.data, out=out, x_pixel_stride=xps)
+        ya = _Act(y, t, ho, wo, cop)
+        self.last_act = ya
+
+        def bwd():
+            dy = ya.g
+            if dy is None:
+                return
+            dy = dy.contiguous()
+            if resid is not None:
+                _acc(resid, dy.clone())
+            if stride_hw == 1:
+                self._conv_grads(conv, src.data, xps, t, hl, wl, cip, dy, k, (pad, pad), wgt, cop)
+                dsrc = conv_dgrad(dy, wgt, cop, cip, k, t, hl, wl)
+            else:
+                if conv.weight.requires_grad:
+                    raise NotImplementedError("weight gradient of the stride-2 encoder convs (the encoder is frozen in train_vae.py:355)")
+                dsrc = conv_dgrad(dy, wgt, cop, cip, k, t, hl, wl, stride=(1, 2, 2))
+            if ups:
+                _acc(x, ops.upsample2x_cl_bwd(dsrc, x.t, x.h, x.w, x.c, tsplit=tsplit))
+            else:
+                _acc(x, dsrc)
+        self.tape.append(bwd)
+        return ya
+
+    # ---- attention (single head over h*w tokens per frame, wan_vae.py:244-266)
+    def attention_block(self, x, blk):
+        from .autograd import linear_bwd, _tpad
+        C, hw = x.c, x.h * x.w
+        hwp = _round(hw, 8)
+        g = self.gamma(blk.norm)
+        wq, bq, _, _, _ = self.packed(blk.to_qkv)
+        wp, bp, _, _, _ = self.packed(blk.proj)
+        scale = 1.0 / math.sqrt(C)
+        outs = torch.empty((x.t * hw, C), device=self.dev, dtype=self.T)
+        saved = []
+        for f in range(x.t):
+            xf = x.data[f * hw:(f + 1) * hw]
+            xn = torch.zeros((hwp, C), device=self.dev, dtype=self.T)
+            ops.rmsnorm_silu_cl(xf, g, silu=False, out=xn[:hw])
+            qk = ops.gemm_bt(xn, wq[:2 * C], bq[:2 * C])
+            vt = ops.gemm_bt(wq[2 * C:], xn, bq[2 * C:], bias_on_m=True)
+            s = ops.gemm_bt(qk[:, :C], qk[:hw, C:], None, epilogue=ops.EPI_STORE_F32) if hw % 4 == 0 else \
+                ops.gemm_bt(qk[:, :C], qk[:, C:], None, epilogue=ops.EPI_STORE_F32)
+            p = ops.softmax_rows(s, self.T, C=hw, Cpad=hwp, scale=scale)
+            o = ops.gemm_bt(p, vt, None)
+            ops.conv_cl(o, wp, bp, Tin=1, Hin=1, Win=hw, Cin=C, k=(1, 1, 1), out_thw=(1, 1, hw), resid=xf,
+                        out=outs[f * hw:(f + 1) * hw])
+            saved.append((xn, qk, vt, p, o))
+        ya = _Act(outs, x.t, x.h, x.w, C)
+
+        def bwd():
+            if ya.g is None:
+                return
+            dx_all = torch.zeros((x.t * hw, C), device=self.dev, dtype=self.T)
+            for f in range(x.t):
+                xn, qk, vt, p, o = saved[f]
+                dout = torch.zeros((hwp, C), device=self.dev, dtype=self.T)
+                dout[:hw] = ya.g[f * hw:(f + 1) * hw]
+                do, dwp, dbp = linear_bwd(o, wp, dout)                                    # proj (1x1 conv)
+                self.grads.add(blk.proj.weight, dwp)
+                self.grads.add(blk.proj.bias, dbp)
+                pT, doT = ops.transpose(p), ops.transpose(do)
+                dvt = ops.gemm_bt(doT, pT)                                                 # [C, hwp]: dV^T = dO^T P
+                dp = ops.gemm_bt(do, ops.transpose(vt), None, epilogue=ops.EPI_STORE_F32)  # [hwp, hwp] = dO V^T
+                ds = ops.softmax_rows_bwd(p, dp, scale=scale, C=hw)                        # T [hwp, hwp]
+                q, kk = qk[:, :C].contiguous(), qk[:, C:].contiguous()
+                dq = ops.gemm_bt(ds, ops.transpose(kk))                                    # dS K
+                dk = ops.gemm_bt(ops.transpose(ds), ops.transpose(q))                      # dS^T Q
+                dqk = torch.cat([dq, dk], dim=1)
+                dqk[hw:].zero_()
+                dxn, dwqk, dbqk = linear_bwd(xn, wq[:2 * C], dqk)
+                dvtT = ops.transpose(dvt)                                                  # [hwp, C]
+                dvtT[hw:].zero_()
+                dxn2, dwv, dbv = linear_bwd(xn, wq[2 * C:], dvtT)
+                dxn = ops.add(dxn, dxn2)
+                self.grads.add(blk.to_qkv.weight, torch.cat([dwqk.float(), dwv.float()]))
+                self.grads.add(blk.to_qkv.bias, torch.cat([dbqk, dbv]))
+                xf = x.data[f * hw:(f + 1) * hw]
+                dxf, dg = ops.rmsnorm_silu_cl_bwd(xf, g, dxn[:hw], silu=False)
+                self.grads.add(blk.norm.gamma, dg)
+                dx_all[f * hw:(f + 1) * hw] = ops.add(dxf, ya.g[f * hw:(f + 1) * hw].contiguous())   # + the skip connection
+            _acc(x, dx_all)
+        self.tape.append(bwd)
+        return ya
+
+    def resample(self, x, rs, key):
+        if rs.mode == "downsample3d" and self.flags.get(key):
+            # later chunks: Conv2d stride 2 into the staging buffer [1 tail frame | t frames], then the (3,1,1)/(2,1,1) time conv
+            conv = rs.resample[1]
+            wgt, b, k, cip, cop = self.packed(rs.time_conv)
+            ho, wo = x.h // 2, x.w // 2
+            st = self.stage(key + ".time_conv", 1, x.t, ho, wo, cop)
+            mid = self.conv_plain(x, conv, stride_hw=2, out=st.chunk(x.t))
+            to = x.t // 2
+            y = ops.conv_cl(st.buf, wgt, b, Tin=1 + x.t, Hin=ho, Win=wo, Cin=cop, k=(3, 1, 1), stride=(2, 1, 1), out_thw=(to, ho, wo))
+            ya = _Act(y, to, ho, wo, cop)
+
+            def bwd():
+                if ya.g is None:
+                    return
+                if rs.time_conv.weight.requires_grad:
+                    raise NotImplementedError("weight gradient of the strided encoder time_conv (the encoder is frozen in train_vae.py:355)")
+                _acc(mid, conv_dgrad(ya.g.contiguous(), wgt, cop, cop, (3, 1, 1), x.t, ho, wo, stride=(2, 1, 1)))
+            # the tape runs in reverse: time-conv gradient first, then (already recorded) the stride-2 conv's
+            self.tape.append(bwd)
+            return ya
+        if rs.mode == "downsample3d":
+            self.flags[key] = True
+            return self.conv_plain(x, rs.resample[1], stride_hw=2)
+        return super().resample(x, rs, key)
+
+
+# ------------------------------------------------------------------------------------------------ autograd nodes
+def _trainable(mods):
+    return [p for m in mods for p in m.parameters() if p.requires_grad]
+
+
+class VaeDecodeFn(Function):
+    """decode_full (wan_vae.py:633-676) + clamp(-1, 1) (:815-818): z [16, T', h, w] -> video [3, T, 8h, 8w]."""
+
+    @staticmethod
+    def forward(ctx, z, vae, *params):
+        dev, T = vae.device, vae.dtype
+        zc, lt, h, w = z.shape
+        run = _Runner(vae, dev, T)
+        zin = ops.ncthw_to_cl(z.detach().to(dev), T, ch_scale=vae.std.to(dev), ch_shift=vae.mean.to(dev))
+        a = run.conv_plain(_Act(zin.view(lt * h * w, zc), lt, h, w, zc), vae.model.conv2)
+        snaps, frames = [], []
+        for i in range(lt):
+            snaps.append(run.snapshot())
+            o = run.decoder(_Act(a.data[i * h * w:(i + 1) * h * w], 1, h, w, zc))
+            frames.append(ops.cl_to_ncthw(o.data, T, C=3, T=o.t, H=o.h, W=o.w, pixel_stride=o.data.stride(0), act=1))
+        ctx.vae, ctx.snaps, ctx.params = vae, snaps, params
+        ctx.save_for_backward(z.detach())
+        ctx.zdtype = z.dtype
+        return torch.cat(frames, dim=1)
+
+    @staticmethod
+    def backward(ctx, dvideo):
+        vae, snaps, params = ctx.vae, ctx.snaps, ctx.params
+        (z,) = ctx.saved_tensors
+        dev, T = vae.device, vae.dtype
+        zc, lt, h, w = z.shape
+        grads = _Grads()
+        zin = ops.ncthw_to_cl(z.to(dev), T, ch_scale=vae.std.to(dev), ch_shift=vae.mean.to(dev))
+        tr0 = _TrainRunner(vae, dev, T, grads)
+        zin_act = _Act(zin.view(lt * h * w, zc), lt, h, w, zc)
+        a = tr0.conv_plain(zin_act, vae.model.conv2)
+        da = torch.zeros_like(a.data)
+        pos = 0
+        for i in range(lt):
+            tr = _TrainRunner(vae, dev, T, grads, snaps[i])
+            ai = _Act(a.data[i * h * w:(i + 1) * h * w], 1, h, w, zc)
+            o = tr.decoder(ai)
+            dv = dvideo[:, pos:pos + o.t].to(dev, T).contiguous()
+            pos += o.t
+            g = ops.ncthw_to_cl(dv, T, Cp=o.c).view(o.t * o.h * o.w, o.c)
+            ops.act_bwd_(g, o.data.contiguous(), ops.ACT_CLAMP1)        # clamp_(-1, 1): gradient only where the value passed through
+            o.g = g
+            tr.backward()
+            if ai.g is not None:
+                da[i * h * w:(i + 1) * h * w] = ai.g
+            del tr
+        a.g = da
+        tr0.backward()
+        dz = None
+        if ctx.needs_input_grad[0]:
+            dz = ops.cl_to_ncthw(zin_act.g, ctx.zdtype, C=zc, T=lt, H=h, W=w, pixel_stride=zin_act.g.stride(0),
+                                 ch_scale=vae.std.to(dev), ch_shift=torch.zeros(zc, device=dev)).to(ctx.zdtype)
+        return (dz, None) + tuple(grads.get(p) for p in params)
+
+
+class VaeEncodeFn(Function):
+    """encode_full (wan_vae.py:549-613): x [3, T, H, W] -> [2z, T', h, w] = (mu normalised | logvar)."""
+
+    @staticmethod
+    def forward(ctx, x, vae, *params):
+        dev, T = vae.device, vae.dtype
+        z2 = 2 * vae.latent_channels
+        xd = x.detach().to(dev)
+        t = xd.shape[1]
+        run = _Runner(vae, dev, T)
+        n_chunks = 1 + (t - 1) // 4
+        h, w = xd.shape[2] // 8, xd.shape[3] // 8
+        enc_out = torch.empty((n_chunks, h * w, z2), device=dev, dtype=T)
+        snaps = []
+        pos = 0
+        for i in range(n_chunks):
+            snaps.append(run.snapshot())
+            chunk = xd[:, :1] if i == 0 else xd[:, 1 + 4 * (i - 1):1 + 4 * i]
+            pos += run.encoder(chunk, lambda tt, pos=pos: enc_out[pos:pos + tt].view(tt * h * w, z2))
+        y = run.conv_plain(_Act(enc_out.view(n_chunks * h * w, z2), n_chunks, h, w, z2), vae.model.conv1)
+        ctx.vae, ctx.snaps, ctx.params = vae, snaps, params
+        ctx.save_for_backward(xd)
+        ctx.xdtype = x.dtype
+        ch_scale, ch_shift = vae._latent_affine(dev)
+        return ops.cl_to_ncthw(y.data, T, C=z2, T=n_chunks, H=h, W=w, pixel_stride=y.data.stride(0), ch_scale=ch_scale, ch_shift=ch_shift)
+
+    @staticmethod
+    def backward(ctx, dout):
+        vae, snaps, params = ctx.vae, ctx.snaps, ctx.params
+        (xd,) = ctx.saved_tensors
+        dev, T = vae.device, vae.dtype
+        z2 = 2 * vae.latent_channels
+        t = xd.shape[1]
+        n_chunks = 1 + (t - 1) // 4
+        H, W = xd.shape[2], xd.shape[3]
+        h, w = H // 8, W // 8
+        grads = _Grads()
+        ch_scale, _ = vae._latent_affine(dev)
+        dy = ops.ncthw_to_cl(dout.to(dev, T).contiguous(), T, ch_scale=ch_scale, ch_shift=torch.zeros(z2, device=dev)).view(n_chunks * h * w, z2)
+        # conv1 (1x1x1 over all latent frames): needs its input again -> recompute the chunks first, keeping only the encoder outputs
+        enc_out = torch.empty((n_chunks, h * w, z2), device=dev, dtype=T)
+        run = _Runner(vae, dev, T)
+        pos = 0
+        for i in range(n_chunks):
+            chunk = xd[:, :1] if i == 0 else xd[:, 1 + 4 * (i - 1):1 + 4 * i]
+            pos += run.encoder(chunk, lambda tt, pos=pos: enc_out[pos:pos + tt].view(tt * h * w, z2))
+        tr0 = _TrainRunner(vae, dev, T, grads)
+        eo = _Act(enc_out.view(n_chunks * h * w, z2), n_chunks, h, w, z2)
+        y = tr0.conv_plain(eo, vae.model.conv1)
+        y.g = dy
+        tr0.backward()
+        dx = torch.zeros(xd.shape, device=dev, dtype=T) if ctx.needs_input_grad[0] else None
+        pos = 0
+        for i in range(n_chunks):
+            chunk = xd[:, :1] if i == 0 else xd[:, 1 + 4 * (i - 1):1 + 4 * i]
+            tc = chunk.shape[1]
+            tr = _TrainRunner(vae, dev, T, grads, snaps[i])
+            holder = {}
+
+            def view(tt, holder=holder):
+                holder["buf"] = torch.empty((tt * h * w, z2), device=dev, dtype=T)
+                return holder["buf"]
+            lt = tr.encoder(chunk, view)
+            tr.last_act.g = eo.g[pos * h * w:(pos + lt) * h * w].contiguous()
+            pos += lt
+            tr.backward()
+            if dx is not None and tr.video_grad is not None:
+                lo = 0 if i == 0 else 1 + 4 * (i - 1)
+                dx[:, lo:lo + tc] = ops.cl_to_ncthw(tr.video_grad, T, C=3, T=tc, H=H, W=W, pixel_stride=tr.video_grad.stride(0))
+            del tr
+        return (None if dx is None else dx.to(ctx.xdtype), None) + tuple(grads.get(p) for p in params)
+
+
+def vae_decode_train(vae, z):
+    """decode_memory_saver under autograd: z [B,16,T',h,w] -> [B,3,T,H,W]."""
+    params = _trainable([vae.model.decoder, vae.model.conv2])
+    return torch.stack([VaeDecodeFn.apply(u, vae, *params) for u in z])
+
+
+def vae_encode_train(vae, x):
+    params = _trainable([vae.model.encoder, vae.model.conv1])
+    return torch.stack([VaeEncodeFn.apply(u, vae, *params) for u in x])
+
+
+# ------------------------------------------------------------------------------------------------ trajectory adaptors
+class _AdaptorTape:
+    """Forward of one frame group of an adaptor keeping the intermediates + its backward (trajectory_module.py:101-122,
+    :177-196, :260-279): conv_in, ResnetBlocks (GroupNorm-swish-conv x2 + skip), GroupNorm-swish, conv_out."""
+
+    def __init__(self, mod, grads, F, H, W):
+        self.m, self.grads, self.F, self.H, self.W = mod, grads, F, H, W
+        self.tape = []
+
+    def conv(self, x, conv, cin, resid=None):
+        m, F, H, W = self.m, self.F, self.H, self.W
+        w, b, cip, cop = m._packed(conv)
+        y = ops.conv_cl(x.data, w, b, Tin=F, Hin=H, Win=W, Cin=cin, k=(1, 3, 3), pad=(0, 1, 1), out_thw=(F, H, W),
+                        resid=None if resid is None else resid.data)
+        ya = _Act(y, F, H, W, cop)
+
+        def bwd():
+            dy = ya.g.contiguous()
+            if resid is not None:
+                _acc(resid, dy.clone())
+            if conv.weight.requires_grad:
+                dw = conv_wgrad(x.data, x.data.stride(0), F, H, W, cip, dy, cop, (1, 3, 3), (1, 1))
+                self.grads.add(conv.weight, _unpack_wgrad(dw, conv))
+                self.grads.add(conv.bias, ops.colsum(dy)[0][:conv.bias.numel()])
+            _acc(x, conv_dgrad(dy, w, cop, cip, (1, 3, 3), F, H, W))
+        self.tape.append(bwd)
+        return ya
+
+    def gn_swish(self, x, norm):
+        m, F, HW = self.m, self.F, self.H * self.W
+        wt, bs = m._f32(norm.weight), m._f32(norm.bias)
+        y = ops.groupnorm_cl(x.data.view(F, HW, -1), wt, bs, F=F, HW=HW, groups=norm.num_groups, eps=norm.eps, silu=True).view(F * HW, -1)
+        ya = _Act(y, F, self.H, self.W, x.c)
+
+        def bwd():
+            dx, dwt, dbs = ops.groupnorm_cl_bwd(x.data.view(F, HW, -1), wt, bs, ya.g.contiguous().view(F, HW, -1), F=F, HW=HW,
+                                                groups=norm.num_groups, eps=norm.eps, silu=True)
+            self.grads.add(norm.weight, dwt)
+            self.grads.add(norm.bias, dbs)
+            _acc(x, dx.view(F * HW, -1))
+        self.tape.append(bwd)
+        return ya
+
+    def resnet(self, h, blk):
+        y = self.conv(self.gn_swish(h, blk.norm1), blk.conv1, blk.in_channels)
+        return self.conv(self.gn_swish(y, blk.norm2), blk.conv2, blk.in_channels, resid=h)
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+
+class AdaptorFn(Function):
+    """One sample through VAEEncoderadaptor / VAEDecoderadaptor: x [3, F, H, W] -> [3, F, H, W].  The forward is the module's
+    own inference path; the backward recomputes groups of frames (the nets are per-frame 2-D) with a tape."""
+    FRAMES_PER_GROUP = 4
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        ctx.mod, ctx.params = mod, params
+        ctx.save_for_backward(x.detach())
+        ctx.xdtype = x.dtype
+        with torch.no_grad():
+            return mod._forward_one(x.detach())
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, params = ctx.mod, ctx.params
+        (x,) = ctx.saved_tensors
+        T, dev = mod.dtype, mod.device
+        C, F, H, W = x.shape
+        grads = _Grads()
+        enc = mod.final_activation is not None           # the encoder adaptor ends in sigmoid(h + x)
+        dx = torch.zeros((C, F, H, W), device=dev, dtype=T) if ctx.needs_input_grad[0] else None
+        blocks = mod.down[0].block if enc else mod.up[0].block
+        for f0 in range(0, F, AdaptorFn.FRAMES_PER_GROUP):
+            f1 = min(F, f0 + AdaptorFn.FRAMES_PER_GROUP)
+            n = f1 - f0
+            xb = x[:, f0:f1].to(dev, T).contiguous()
+            tp = _AdaptorTape(mod, grads, n, H, W)
+            x0 = _Act(ops.ncthw_to_cl(xb, T, Cp=8).view(n * H * W, 8), n, H, W, 8)
+            h = tp.conv(x0, mod.conv_in, 8)
+            for blk in blocks:
+                h = tp.resnet(h, blk)
+            h = tp.conv(tp.gn_swish(h, mod.norm_out), mod.conv_out, mod.ch)
+            g = dout[:, f0:f1].to(dev, T).contiguous()
+            if enc:       # y = sigmoid(h + x): dy * y (1 - y), the same for the net branch and the skip
+                y = ops.cl_to_ncthw(h.data, T, C=C, T=n, H=H, W=W, pixel_stride=h.c, act=2, aux=xb)
+                g = g.clone()
+                ops.act_bwd_(g, y.contiguous(), ops.ACT_SIGMOID_OUT)
+            h.g = ops.ncthw_to_cl(g, T, Cp=h.c).view(n * H * W, h.c)
+            tp.backward()
+            if dx is not None:
+                d0 = ops.cl_to_ncthw(x0.g, T, C=C, T=n, H=H, W=W, pixel_stride=x0.g.stride(0))
+                dx[:, f0:f1] = ops.add(d0, g) if enc else d0
+        return (None if dx is None else dx.to(ctx.xdtype), None) + tuple(grads.get(p) for p in params)
+
+
+def adaptor_train(mod, x):
+    params = [p for p in mod.parameters() if p.requires_grad]
+    return torch.stack([AdaptorFn.apply(u, mod, *params) for u in x])

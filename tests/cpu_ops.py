@@ -382,8 +382,15 @@ def add(a, b, out=None):
 
 @torch.enable_grad()
 def act_bwd_(dy, pre, act):
+    if act == 5:        # sigmoid, given its OUTPUT
+        s = pre.float()
+        dy.copy_((dy.float() * s * (1 - s)).to(dy.dtype))
+        return dy
+    if act == 6:        # clamp(-1, 1), given the un-clamped value
+        dy.copy_((dy.float() * ((pre.float() >= -1) & (pre.float() <= 1)).float()).to(dy.dtype))
+        return dy
     x = pre.float().detach().requires_grad_(True)
-    y = {1: F.silu, 2: lambda t: F.gelu(t, approximate="tanh"), 3: F.gelu}[act](x)
+    y = {1: F.silu, 2: lambda t: F.gelu(t, approximate="tanh"), 3: F.gelu, 4: torch.sigmoid}[act](x)
     (g,) = torch.autograd.grad(y, x, dy.float())
     dy.copy_(g.to(dy.dtype))
     return dy
@@ -499,3 +506,95 @@ def adamw_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
     p.copy_(pf.to(p.dtype))
     m.copy_(mf.to(m.dtype))
     v.copy_(vf.to(v.dtype))
+
+
+# ------------------------------------------------------------------ VAE training ops (vae_autograd.py)
+NAMES += ["pad_transpose", "gemm_bt_batched", "wgrad_reduce", "rmsnorm_silu_cl_bwd", "softmax_rows_bwd", "upsample2x_cl",
+          "upsample2x_cl_bwd", "groupnorm_cl_bwd"]
+
+
+def pad_transpose(src, pixel_stride, C, T, H, W, Hp, Wp, pad_top, pad_left, nshift, cols, rows=None):
+    flat = src.reshape(-1)
+    v = torch.as_strided(flat, (T, H, W, C), (H * W * pixel_stride, W * pixel_stride, pixel_stride, 1), flat.storage_offset())
+    padded = torch.zeros((T, Hp, Wp, C), dtype=src.dtype)
+    padded[:, pad_top:pad_top + H, pad_left:pad_left + W] = v
+    lin = torch.zeros((cols + nshift, C), dtype=src.dtype)
+    n = min(cols + nshift, T * Hp * Wp)
+    lin[:n] = padded.reshape(-1, C)[:n]
+    out = torch.zeros((rows or nshift * C, cols), dtype=src.dtype)
+    for s in range(nshift):
+        out[s * C:(s + 1) * C] = lin[s:s + cols].t()
+    return out
+
+
+def gemm_bt_batched(a, w, *, M, N, K, nb1, a_bs1, w_bs1, nb2=1, a_bs2=0, w_bs2=0):
+    out = torch.zeros((nb2, nb1, M, N), dtype=torch.float32)
+    lda, ldw = a.stride(0), w.stride(0)
+    af, wf = a.reshape(-1) if a.is_contiguous() else None, None
+    for i2 in range(nb2):
+        for i1 in range(nb1):
+            ao = i1 * a_bs1 + i2 * a_bs2
+            wo = i1 * w_bs1 + i2 * w_bs2
+            A = torch.as_strided(a, (M, K), (lda, 1), a.storage_offset() + ao).float()
+            Wm = torch.as_strided(w, (N, K), (ldw, 1), w.storage_offset() + wo).float()
+            out[i2, i1] = A @ Wm.t()
+    del af, wf
+    return out
+
+
+def wgrad_reduce(part, dw, dt, M):
+    kh, S, Mp, N = part.shape
+    cop, kt, kh2, kw, cip = dw.shape
+    assert kh == kh2 and N == kw * cip
+    dw[:, dt] += part.sum(dim=1)[:, :cop].view(kh, cop, kw, cip).permute(1, 0, 2, 3)
+    return dw
+
+
+@torch.enable_grad()
+def rmsnorm_silu_cl_bwd(x, gamma, dy, *, silu=True):
+    xf = x.float().detach().requires_grad_(True)
+    g = gamma.float().detach().requires_grad_(True)
+    C = x.shape[-1]
+    u = xf / xf.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(C) * g
+    y = F.silu(u) if silu else u
+    y.backward(dy.float().reshape(y.shape))
+    return xf.grad.to(x.dtype), g.grad
+
+
+def softmax_rows_bwd(p, dp, *, scale, C):
+    pf = p.float()
+    d = dp.float()
+    pf = pf.clone()
+    pf[:, C:] = 0
+    ds = scale * pf * (d - (pf * d).sum(dim=-1, keepdim=True))
+    return ds.to(p.dtype)
+
+
+def upsample2x_cl(x, t, h, w, c, *, tsplit=False):
+    cw = c * (2 if tsplit else 1)
+    v = x.reshape(t, h, w, cw)
+    if tsplit:
+        v = torch.stack([v[..., :c], v[..., c:]], dim=1).reshape(2 * t, h, w, c)
+    v = v.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    return v.reshape(-1, c).contiguous()
+
+
+def upsample2x_cl_bwd(du, t, h, w, c, *, tsplit=False):
+    tt = t * (2 if tsplit else 1)
+    v = du.float().reshape(tt, h, 2, w, 2, c).sum(dim=(2, 4))
+    if tsplit:
+        v = v.reshape(t, 2, h, w, c).permute(0, 2, 3, 1, 4).reshape(t, h, w, 2 * c)
+    return v.reshape(t * h * w, -1).to(du.dtype).contiguous()
+
+
+@torch.enable_grad()
+def groupnorm_cl_bwd(x, weight, bias, dy, *, F, HW, groups=32, eps=1e-6, silu=True):
+    C = x.shape[-1]
+    xf = x.float().detach().view(F, HW, C).permute(0, 2, 1).requires_grad_(True)
+    wt = weight.float().detach().requires_grad_(True)
+    bs = bias.float().detach().requires_grad_(True)
+    y = torch.nn.functional.group_norm(xf, groups, wt, bs, eps)
+    if silu:
+        y = y * torch.sigmoid(y)
+    y.backward(dy.float().view(F, HW, C).permute(0, 2, 1))
+    return xf.grad.permute(0, 2, 1).reshape(x.shape).to(x.dtype).contiguous(), wt.grad, bs.grad

@@ -63,3 +63,37 @@ def test_adaptors():
     assert rel_err(ov.encoder_adaptor(sd_of(z), z["x"]), z["out"]) < TOL
     z = load_npz("adaptor_dec.npz")
     assert rel_err(ov.decoder_adaptor(sd_of(z), z["x"]), z["out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_vae_train_step_oracle_matches_reference_gradients(tag):
+    """oracle/vae_train.py under torch autograd == the reference's train_vae.py step (tests/golden/vae_train.npz): loss terms,
+    forward values and EVERY parameter gradient the reference produced — A: step as written (encode under no_grad: decoder +
+    decoder prompt), B: gradient through the frozen encoder (encoder prompt + KL path as well)."""
+    from oracle import vae_train as ovt
+    from util import grad_sample
+    z = load_npz("vae_train.npz")
+    sdv = {k: v.clone().requires_grad_(True) for k, v in fill(load_keys("vae_keys.json"), 2024).items()}
+    sde = {k: v.clone().requires_grad_(True) for k, v in fill(load_keys("adaptor_enc_keys.json"), 78).items()}
+    sdd = {k: v.clone().requires_grad_(True) for k, v in fill(load_keys("adaptor_dec_keys.json"), 77).items()}
+    loss, nll, kl, fwd = ovt.train_step_loss(sdv, sde, sdd, z["targets"], z[f"{tag}/eps"], grad_through_encoder=(tag == "B"))
+    for k in ("pseudo", "params", "latents", "recon", "reconstructions"):
+        assert rel_err(fwd[k].detach(), z[f"{tag}/{k}"]) < 2e-5, k
+    assert abs(float(nll) - float(z[f"{tag}/nll"])) < 1e-5 * float(z[f"{tag}/nll"])
+    assert abs(float(kl) - float(z[f"{tag}/kl"])) < 1e-5 * float(z[f"{tag}/kl"])
+    loss.backward()
+    named = {**{"vae." + k: v for k, v in sdv.items()}, **{"encoder_prompt." + k: v for k, v in sde.items()},
+             **{"decoder_prompt." + k: v for k, v in sdd.items()}}
+    names = [k[len(tag) + 6:] for k in z if k.startswith(f"{tag}/grad/")]
+    assert len(names) > 100
+    gmax = max(float(z[f"{tag}/grad/{n}"].abs().max()) for n in names)
+    for n in names:
+        g = named[n].grad
+        assert g is not None, n
+        ref = z[f"{tag}/grad/{n}"]
+        e = float((grad_sample(g).double() - ref.double()).abs().max() / max(float(ref.abs().max()), 1e-3 * gmax))
+        assert e < 2e-4, (n, e)
+    # nothing else received a gradient (the frozen encoder, and in A the encoder prompt)
+    extra = [n for n, v in named.items() if v.grad is not None and n not in names and not n.startswith("vae.model.encoder")
+             and not n.startswith("vae.model.conv1")]
+    assert not extra, extra
