@@ -283,7 +283,8 @@ int m4d_resid_gate(const float* x, m4d_dtype y_dt, const void* y, const float* g
 /* out = a + b (T, n % 4 == 0): sums of gradient branches. */
 int m4d_add(m4d_dtype dt, const void* a, const void* b, void* out, int64_t n, m4d_stream stream);
 
-/* dy *= act'(pre) in place (act: 1 silu, 2 gelu_tanh, 3 gelu_erf; the m4d_unary / GEMM-epilogue activations). */
+/* dy *= act'(pre) in place (act: 1 silu, 2 gelu_tanh, 3 gelu_erf: the m4d_unary / GEMM-epilogue activations; 4 sigmoid, 5 sigmoid
+ * with `pre` = its OUTPUT (the encoder adaptor's sigmoid(h + x), trajectory_module.py:194), 6 clamp(pre, -1, 1) (wan_vae.py:817)). */
 int m4d_act_bwd(m4d_dtype dt, void* dy, const void* pre, int64_t n, int act, m4d_stream stream);
 
 /* Backward of m4d_ln_modulate without guidance: y = LN(x) * m + s with m = 1 + scale[sample] | ln_w | 1.
@@ -321,6 +322,41 @@ int m4d_sumsq(m4d_dtype dt, const void* x, int64_t n, float* out, m4d_stream str
 int m4d_adamw(m4d_dtype dt, void* param, const void* grad, m4d_dtype state_dt, void* exp_avg, void* exp_avg_sq, int64_t n,
               float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* grad_scale,
               m4d_stream stream);
+
+/* ------------------------------------------------------------------ VAE / adaptor training (train_vae.py:434-495)
+ * Backward halves of the Motion-Sensitive-VAE kernels: the reference gets them from torch autograd through `encode_full` /
+ * `decode_full` (wan_vae.py:549-676: per-chunk checkpoint, streaming cache detached between chunks) and the adaptors
+ * (trajectory_module.py:101-279).  Convolution DATA gradients reuse m4d_conv_cl with flipped taps; the WEIGHT gradient is
+ *   pad_transpose (dy and x -> pixel-major panels in a zero-padded frame geometry, every tap = a column offset)
+ *   -> gemm_bt_batched (split-K partial products, K-slices x taps as the batch) -> wgrad_reduce.
+ * pad_transpose: src = T frames of H x W pixels, C channels, pixel stride `pixel_stride`; out [nshift*C, cols] (row stride cols):
+ *   out[s*C + c][q] = P[q + s][c], P = the frames zero-padded to [T, Hp, Wp] with the image at (pad_top, pad_left), flattened;
+ *   zero beyond the last frame.
+ * gemm_bt_batched: float32 out[i2][i1] [M, N] = A_(i1,i2) [M,K] . W_(i1,i2) [N,K]^T (unrounded accumulators), A_(i1,i2) =
+ *   A + i1*a_bs1 + i2*a_bs2 elements with row stride lda, W likewise; i1 < nb1, i2 < nb2.
+ * wgrad_reduce: dw[co][dt][dh][dw][ci] += sum_s part[dh][s][co][dw*cip + ci]; part float32 [kh, S, Mp, kw*cip], dw float32
+ *   [cop, kt, kh, kw, cip] (the packed weight layout of m4d_conv_cl).
+ * rmsnorm_silu_cl_bwd: backward of m4d_rmsnorm_silu_cl (wan_vae.py:43-58 + SiLU): dx T [P, C], dgamma float32 [C] (+=).
+ * softmax_rows_bwd: dS = scale * P * (dP - rowsum(P dP)) on [rows, Cpad] (columns >= C written as 0): mid-block attention :244-266.
+ * upsample2x_cl: nearest-exact 2x of channels-last frames [t,h,w,c] -> [t',2h,2w,c] (tsplit: input pixels hold 2c channels and
+ *   frame 2i / 2i+1 of the result reads the first / second half, :138-141); backward != 0 runs the transpose (sum of each 2x2
+ *   block, frames back into channel halves).
+ * groupnorm_cl_bwd: backward of m4d_groupnorm_cl (GroupNorm(32, eps 1e-6) + swish, trajectory_module.py:32-60): dx T [F,HW,C],
+ *   dweight / dbias float32 [C] (+=); ws from m4d_groupnorm_cl_bwd_workspace floats. */
+int m4d_pad_transpose(m4d_dtype dt, const void* src, int64_t pixel_stride, int C, int T, int H, int W, int Hp, int Wp, int pad_top,
+                      int pad_left, int nshift, void* out, int64_t cols, m4d_stream stream);
+int m4d_gemm_bt_batched(m4d_dtype dt, const void* A, int64_t lda, int64_t a_bs1, int64_t a_bs2, const void* W, int64_t ldw,
+                        int64_t w_bs1, int64_t w_bs2, float* out, int64_t M, int64_t N, int64_t K, int nb1, int nb2, m4d_stream stream);
+int m4d_wgrad_reduce(const float* part, float* dw, int S, int Mp, int cop, int kt, int kh, int kw, int cip, int dt, m4d_stream stream);
+int m4d_rmsnorm_silu_cl_bwd(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, const void* dy, int64_t dy_ld, void* dx,
+                            int64_t dx_ld, float* dgamma, int64_t P, int C, int silu, m4d_stream stream);
+int m4d_softmax_rows_bwd(m4d_dtype dt, const void* p, const float* dp, void* out, int64_t rows, int C, int Cpad, float scale,
+                         m4d_stream stream);
+int m4d_upsample2x_cl(m4d_dtype dt, const void* in, void* out, int t, int h, int w, int c, int tsplit, int backward, m4d_stream stream);
+int64_t m4d_groupnorm_cl_bwd_workspace(int F, int64_t HW, int G);
+int m4d_groupnorm_cl_bwd(m4d_dtype dt, const void* x, const float* weight, const float* bias, const void* dy, void* dx, float* dweight,
+                         float* dbias, float* ws, int64_t ws_floats, int F, int64_t HW, int C, int G, float eps, int silu,
+                         m4d_stream stream);
 
 #ifdef __cplusplus
 }

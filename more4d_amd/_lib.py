@@ -81,6 +81,16 @@ SIGNATURES = {
     "m4d_lincomb": (c_int, [c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_int64,
                             c_void_p]),
     "m4d_rel_l1": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m4d_pad_transpose": (c_int, [c_int, c_void_p, c_int64] + [c_int] * 9 + [c_void_p, c_int64, c_void_p]),
+    "m4d_gemm_bt_batched": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                    c_int64, c_int64, c_int, c_int, c_void_p]),
+    "m4d_wgrad_reduce": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "m4d_rmsnorm_silu_cl_bwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                        c_int, c_void_p]),
+    "m4d_softmax_rows_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "m4d_upsample2x_cl": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "m4d_groupnorm_cl_bwd_workspace": (c_int64, [c_int, c_int64, c_int]),
+    "m4d_groupnorm_cl_bwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "m4d_minmax": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "m4d_backproject": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "m4d_depth_control": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

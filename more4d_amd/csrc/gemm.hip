@@ -33,6 +33,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(GemmArgs p) {
     constexpr int KSTEPS = KT / 16;      // MFMA K=16 steps per tile
     typedef typename Frag8<T>::type frag_t;
 
+    if (p.nb1 > 0) {   // batched: blockIdx.y = i2 * nb1 + i1 picks the operand panels and the output slab
+        const int b = blockIdx.y, i1 = b % p.nb1, i2 = b / p.nb1;
+        p.A = (const char*)p.A + (i1 * p.a_bs1 + i2 * p.a_bs2) * ES;
+        p.W = (const char*)p.W + (i1 * p.w_bs1 + i2 * p.w_bs2) * ES;
+        p.out = (float*)p.out + (int64_t)b * p.M * p.ldc;
+    }
     int tm, tn;
     tile_coords(p, tm, tn);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
@@ -470,6 +476,7 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.gate_stride = gate_stride; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : M;
     p.epilogue = epilogue; p.bias_on_m = bias_on_m;
+    p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0;
     p.abl = 0;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(abl_env, "M4D_GEMM_ABL", 0); p.abl = abl_env; }
@@ -507,5 +514,32 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
         else hipLaunchKernelGGL(gemm_bt_kernel<float>, grid, block, 0, st, p);
     }
     M4D_CHECK_LAUNCH("gemm_bt");
+    return 0;
+}
+
+
+// Batched A.W^T with float32 (unrounded) outputs: the split-K partial products of the VAE conv weight gradients
+// (more4d_amd/vae_autograd.py:conv_wgrad): batch (i1, i2) reads A + i1*a_bs1 + i2*a_bs2 and W + i1*w_bs1 + i2*w_bs2.
+extern "C" int m4d_gemm_bt_batched(m4d_dtype dt, const void* A, int64_t lda, int64_t a_bs1, int64_t a_bs2, const void* W, int64_t ldw,
+                                   int64_t w_bs1, int64_t w_bs2, float* out, int64_t M, int64_t N, int64_t K, int nb1, int nb2,
+                                   m4d_stream stream) {
+    const int es = dt == M4D_BF16 ? 2 : 4;
+    M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "gemm_bt_batched: bad dtype %d", (int)dt);
+    M4D_CHECK_ARG(A && W && out && M > 0 && N > 0 && K > 0 && nb1 > 0 && nb2 > 0, "gemm_bt_batched: null/empty");
+    M4D_CHECK_ARG((K * es) % 16 == 0 && N % 4 == 0, "gemm_bt_batched: K*sizeof(T) %% 16 and N %% 4 must be 0");
+    M4D_CHECK_ARG((lda * es) % 16 == 0 && (ldw * es) % 16 == 0 && (a_bs1 * es) % 16 == 0 && (a_bs2 * es) % 16 == 0 &&
+                  (w_bs1 * es) % 16 == 0 && (w_bs2 * es) % 16 == 0, "gemm_bt_batched: strides must keep rows 16-byte aligned");
+    M4D_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_bt_batched: pointers must be 16-byte aligned");
+    M4D_CHECK_ARG((int64_t)nb1 * nb2 <= 65535, "gemm_bt_batched: too many batches");
+    GemmArgs p;
+    p.A = A; p.W = W; p.bias = nullptr; p.out = out; p.gate = nullptr;
+    p.lda = lda; p.ldw = ldw; p.ldc = N; p.M = M; p.N = N; p.K = K;
+    p.gate_stride = 0; p.rows_per_sample = M; p.epilogue = M4D_EPI_STORE_F32; p.bias_on_m = 0;
+    p.nb1 = nb1; p.a_bs1 = a_bs1; p.a_bs2 = a_bs2; p.w_bs1 = w_bs1; p.w_bs2 = w_bs2; p.abl = 0;
+    p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(nb1 * nb2)), block(256);
+    if (dt == M4D_BF16) hipLaunchKernelGGL(gemm_bt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_bt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+    M4D_CHECK_LAUNCH("gemm_bt_batched");
     return 0;
 }

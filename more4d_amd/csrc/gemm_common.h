@@ -15,6 +15,8 @@ struct GemmArgs {
     int64_t lda, ldw, ldc, M, N, K, gate_stride, rows_per_sample;
     int epilogue, bias_on_m;
     int tiles_m, tiles_n;
+    int64_t a_bs1, a_bs2, w_bs1, w_bs2;   // batched launches (gridDim.y = nb1 * nb2): element offsets of batch (i1, i2); out += batch * M * ldc
+    int nb1;                               // 0 = not batched
     int abl;   // timing ablations (tools only; results wrong when != 0): 1 no DMA, 2 frags once, 4 no barriers, 8 no MFMA
 };
 
@@ -90,8 +92,10 @@ M4D_DEV void epilogue_tile(const GemmArgs& p, const f32x16& acc, int64_t m, int6
         for (int rq = 0; rq < 4; ++rq) {
             const int64_t nb = nb0 + rq * 8 + hi * 4;
             if (nb >= p.N) continue;
+            if (!p.nb1) {      // (batched split-K partial sums keep their float32 accumulators)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[rq][e] = round_through<T>(v[rq][e]);
+                for (int e = 0; e < 4; ++e) v[rq][e] = round_through<T>(v[rq][e]);
+            }
             store4((float*)p.out + m * p.ldc + nb, v[rq]);
         }
     } else {

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out
         store4(out + i, load4(a + i) + load4(b + i));
 }
 
-// ------------------------------------------------------------------ dy *= act'(pre)   (act: 1 silu, 2 gelu_tanh, 3 gelu_erf)
+// ------------------------------------------------------------------ dy *= act'(pre)   (act: 1 silu, 2 gelu_tanh, 3 gelu_erf, 4 sigmoid,
+// 5 sigmoid given its output, 6 clamp(-1,1))
 M4D_DEV float dact(float x, int act) {
     if (act == 1) { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
     if (act == 2) {
@@ -134,6 +135,9 @@ M4D_DEV float dact(float x, int act) {
         return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x * x);
     }
     if (act == 3) return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    if (act == 4) { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }     // sigmoid
+    if (act == 5) return x * (1.f - x);                                                    // sigmoid, x = its OUTPUT
+    if (act == 6) return (x >= -1.f && x <= 1.f) ? 1.f : 0.f;                              // clamp(-1, 1)
     return 1.f;
 }
 template <typename T>
@@ -541,7 +545,7 @@ extern "C" int m4d_add(m4d_dtype dt, const void* a, const void* b, void* out, in
 
 extern "C" int m4d_act_bwd(m4d_dtype dt, void* dy, const void* pre, int64_t n, int act, m4d_stream stream) {
     M4D_CHECK_ARG(DT_OK(dt), "act_bwd: bad dtype");
-    M4D_CHECK_ARG(dy && pre && n > 0 && n % 4 == 0 && act >= 1 && act <= 3, "act_bwd: bad arguments");
+    M4D_CHECK_ARG(dy && pre && n > 0 && n % 4 == 0 && act >= 1 && act <= 6, "act_bwd: bad arguments");
     dim3 grid(grid_for(n / 4, 256, 16384)), block(256);
     if (dt == M4D_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (bf16_t*)dy, (const bf16_t*)pre, n, act);
     else hipLaunchKernelGGL(act_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)dy, (const float*)pre, n, act);

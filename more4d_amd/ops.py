@@ -524,6 +524,7 @@ def rmsnorm_silu_cl_bwd(x, gamma, dy, *, silu=True):
     dg = torch.zeros(C, device=x.device, dtype=torch.float32)
     check(_lib.load().m4d_rmsnorm_silu_cl_bwd(dt_code(x.dtype), _ptr(x), ldx, _ptr(gamma), _ptr(dy), ldd, _ptr(dx), C, _ptr(dg), P, C,
                                               int(silu), _stream()), "m4d_rmsnorm_silu_cl_bwd")
+    # (argument order of the ABI: x, x_ld, gamma, dy, dy_ld, dx, dx_ld, dgamma, P, C, silu)
     return dx, dg
 
 
@@ -568,9 +569,11 @@ def groupnorm_cl_bwd(x, weight, bias, dy, *, F, HW, groups=32, eps=1e-6, silu=Tr
     dx = torch.empty_like(x)
     dwt = torch.zeros(C, device=x.device, dtype=torch.float32)
     dbs = torch.zeros(C, device=x.device, dtype=torch.float32)
-    ws = torch.zeros((F * groups * 4,), device=x.device, dtype=torch.float32)
-    check(_lib.load().m4d_groupnorm_cl_bwd(dt_code(x.dtype), _ptr(x), _ptr(weight), _ptr(bias), _ptr(dy), _ptr(dx), _ptr(dwt), _ptr(dbs),
-                                           _ptr(ws), F, HW, C, groups, float(eps), int(silu), _stream()), "m4d_groupnorm_cl_bwd")
+    lib = _lib.load()
+    n = lib.m4d_groupnorm_cl_bwd_workspace(F, HW, groups)
+    ws = torch.empty((n,), device=x.device, dtype=torch.float32)
+    check(lib.m4d_groupnorm_cl_bwd(dt_code(x.dtype), _ptr(x), _ptr(weight), _ptr(bias), _ptr(dy), _ptr(dx), _ptr(dwt), _ptr(dbs),
+                                   _ptr(ws), n, F, HW, C, groups, float(eps), int(silu), _stream()), "m4d_groupnorm_cl_bwd")
     return dx, dwt, dbs
 
 
