@@ -203,7 +203,7 @@ def test_train_vae_step_bf16_budget():
     gradients: bf16 activations through a 30-conv decoder give percent-level element errors, the update direction must agree."""
     z, fwd, named, _ = _train_step("B", BF)
     assert rms_rel_err(fwd["recon"].detach().float().cpu(), z["B/recon"]) < 8e-2
-    names = [k[8:] for k in z if k.startswith("B/grad/") and not k.startswith("B/grad/vae.model.conv1")]
+    names = [k[7:] for k in z if k.startswith("B/grad/") and not k.startswith("B/grad/vae.model.conv1")]
     cos = []
     for n in names:
         g = grad_sample(named[n].grad.float().cpu()).double()
