@@ -35,7 +35,7 @@ def test_gemm_full_shape_sampled_rows_and_linearity():
         out = ops.gemm_bt(a, w, b)
         rows = torch.tensor([0, 1, 255, 256, 257, 21839, 21840, 43519, 43520, 43679], device=DEV)
         ref = a[rows].float() @ w.float().t() + b.float()
-        assert rel(out[rows].float(), ref) < 1e-2                      # bf16 output rounding
+        assert rel(out[rows].float(), ref) < 8e-3                      # bf16 output rounding (2^-8 of the largest value)
         a2 = (torch.randn(M, K, generator=gen(4), device=DEV) * 0.5).to(BF)
         s = ops.gemm_bt((a.float() + a2.float()).to(BF), w)
         parts = ops.gemm_bt(a, w, epilogue=ops.EPI_STORE_F32) + ops.gemm_bt(a2, w, epilogue=ops.EPI_STORE_F32)
@@ -63,12 +63,12 @@ def test_attention_full_length_sampled_queries_and_invariances():
         sl = slice(h * D, (h + 1) * D)
         s = (q[qs, sl].float() @ k[:, sl].float().t()) / math.sqrt(D)
         ref = torch.softmax(s, -1) @ vt[sl].float().t()
-        assert rel(out[qs, sl].float(), ref) < 2e-2
+        assert rel(out[qs, sl].float(), ref) < 8e-3
         assert rel(lse[0, h, qs], torch.logsumexp(s, -1) * 1.4426950408889634) < 1e-4
     # (b) key permutation
     perm = torch.randperm(L, generator=gen(4), device=DEV)
     outp = ops.attention(q, [KV(k[perm].contiguous(), vt[:, perm].contiguous(), L * C, C, L, B * L, L)], **kw).view(L, C)
-    assert rel(outp.float(), out.float()) < 2e-2
+    assert rel(outp.float(), out.float()) < 8e-3
     # (c) four ragged segments == one segment
     Ls = 5464
     segs = []
@@ -80,13 +80,13 @@ def test_attention_full_length_sampled_queries_and_invariances():
         vv[:, :n] = vt[:, r * Ls:r * Ls + n]
         segs.append(KV(kk, vv, Ls * C, C, Ls, Ls, n))
     outs = ops.attention(q, segs, **kw).view(L, C)
-    assert rel(outs.float(), out.float()) < 2e-2
+    assert rel(outs.float(), out.float()) < 8e-3
     # (d) local shard + remote shards merged through the LSEs
     la, lb = torch.empty_like(lse), torch.empty_like(lse)
     oa = ops.attention(q, segs[:1], lse=la, **kw)
     ob = ops.attention(q, segs[1:], lse=lb, **kw)
     ops.attn_merge_(oa, la, ob, lb, B=B, L=L, heads=HEADS, head_dim=D)
-    assert rel(oa.view(L, C).float(), out.float()) < 2e-2 and rel(la, lse) < 1e-4
+    assert rel(oa.view(L, C).float(), out.float()) < 8e-3 and rel(la, lse) < 1e-4
 
 
 def test_norm_kernels_full_rows_sampled():
@@ -100,14 +100,14 @@ def test_norm_kernels_full_rows_sampled():
     for b in range(B):
         xr = x[b, rows]
         ref = torch.nn.functional.layer_norm(xr, (C,), eps=1e-6) * (1 + e[b, 1]) + e[b, 0]
-        assert rel(y[b, rows].float(), ref) < 1e-2
+        assert rel(y[b, rows].float(), ref) < 8e-3
     qk = torch.randn(B * L, C, generator=gen(3), device=DEV).to(BF)
     w = 1 + 0.1 * torch.randn(C, generator=gen(4), device=DEV)
     got = qk.clone()
     ops.rmsnorm_rope(got, w, head_dim=D, eps=1e-6)           # no rope tables: pure WanRMSNorm over the full 5120 row
     xr = qk[rows].float()
     ref = (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF).float() * w
-    assert rel(got[rows].float(), ref) < 1e-2
+    assert rel(got[rows].float(), ref) < 8e-3
 
 
 def test_block_full_size_batch_consistency_and_determinism():
@@ -197,12 +197,12 @@ def test_attention_backward_full_length_sampled():
         # sampled queries: full rows of P and dS
         P = torch.exp(qf[idx] @ kf.t() * scale - lse_nat[idx, None])   # [6, L]
         dS = P * (gf[idx] @ vf.t() - delta[idx, None]) * scale
-        assert rel(dq[idx, sl].float(), dS @ kf) < 3e-2
+        assert rel(dq[idx, sl].float(), dS @ kf) < 1e-2
         # sampled keys: full columns
         Pc = torch.exp(qf @ kf[idx].t() * scale - lse_nat[:, None])    # [L, 6]
         dSc = Pc * (gf @ vf[idx].t() - delta[:, None]) * scale
-        assert rel(dv[idx, sl].float(), Pc.t() @ gf) < 3e-2
-        assert rel(dk[idx, sl].float(), dSc.t() @ qf) < 3e-2
+        assert rel(dv[idx, sl].float(), Pc.t() @ gf) < 1e-2
+        assert rel(dk[idx, sl].float(), dSc.t() @ qf) < 1e-2
 
 
 def test_linear_backward_full_token_axis_sampled():
@@ -214,7 +214,7 @@ def test_linear_backward_full_token_axis_sampled():
     dy = (torch.randn(L, C, generator=gen(3), device=DEV) * 0.1).to(BF)
     dx, dw, db = linear_bwd(x, w, dy)
     r = torch.tensor([0, 255, 256, 5119], device=DEV)
-    assert rel(dw[r].float(), dy[:, r].float().t() @ x.float()) < 1e-2
+    assert rel(dw[r].float(), dy[:, r].float().t() @ x.float()) < 8e-3
     t = torch.tensor([0, 21583, 21584, 21839], device=DEV)
-    assert rel(dx[t].float(), dy[t].float() @ w.float()) < 1e-2
+    assert rel(dx[t].float(), dy[t].float() @ w.float()) < 8e-3
     assert rel(db, dy.float().sum(0)) < 1e-4

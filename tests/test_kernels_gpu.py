@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
 F32_TOL = 1e-4
-BF16_TOL = 2.5e-2
+BF16_TOL = 8e-3   # bf16 OUTPUT rounding bounds max|err|/max|ref| at 2^-8 = 3.9e-3; operands are compared after the same bf16 quantisation
 
 
 def ops():
@@ -90,7 +90,7 @@ def test_gemm_large_k_accumulation():
     a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
     ref = q(a, torch.bfloat16).double() @ q(w, torch.bfloat16).double().t()
     out = o.gemm_bt(a.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), None, epilogue=o.EPI_STORE_F32)
-    assert rel_err(out.cpu(), ref.float()) < 1.5e-2   # bf16 rounding of the result only
+    assert rel_err(out.cpu(), ref.float()) < BF16_TOL   # bf16 rounding of the result only
 
 
 def test_gemm_rejects_bad_args():
@@ -168,7 +168,7 @@ def test_rmsnorm_rope(dt, C, hd):
     dq, dk = xq.to(DEV, dt).clone(), xk.to(DEV, dt).clone()
     o.rmsnorm_rope(dq, wq.to(DEV), dk, wk.to(DEV), head_dim=hd, eps=1e-6, cos=cos, sin=sin, rows_per_sample=L,
                    rope_len=S)
-    tol = 2e-5 if dt == torch.float32 else 1e-2
+    tol = 2e-5 if dt == torch.float32 else BF16_TOL
     assert rel_err(dq.float().cpu(), ref(xq, wq)) < tol
     assert rel_err(dk.float().cpu(), ref(xk, wk)) < tol
     # norm only (cross-attention), single tensor, strided rows
@@ -412,6 +412,6 @@ def test_attn_merge_equals_joint_softmax(dtype, hd, heads, Lq, La, Lb):
         oa = ops.attention(q, [sa], lse=la, **kw)
     ob = ops.attention(q, [sb], lse=lb, **kw)
     ops.attn_merge_(oa, la, ob, lb, B=B, L=Lq, heads=heads, head_dim=hd)
-    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    tol = 1e-5 if dtype == torch.float32 else BF16_TOL
     assert rel_err(oa.float().cpu(), joint.float().cpu()) < tol
     assert rel_err(la.cpu(), lse_j.cpu()) < 1e-5
