@@ -136,12 +136,34 @@ def secondary_figures(model, cfg, dev):
         r = bench_vae.run(49, 480, 832, iters=2, dev=dev, verbose=False)
         out["vae_roundtrip"] = {"ms": r["roundtrip_ms"], "parts_ms": r["ms"], "tflops": r["tflops"], "finite": r["finite"],
                                 "workload": "enc-adaptor + encode + decode + dec-adaptor, 49x480x832x3 trajectories, bf16"}
+        px = 480 * 832
+        fl = px * (6.657e6 + 48 * 5.003e6) + px * (10.748e6 + 48 * 8.445e6)
+        tf = fl / ((r["ms"]["encode"] + r["ms"]["decode"]) / 1e3) / 1e12
+        out["roofline_vae"] = {"kernel": "conv_cl256_kernel (78 % of VAE kernel time) inside vae.encode + vae.decode, whole-call FLOPs / wall time",
+                               "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+                               "algorithmic_tflop": fl / 1e12}
     except Exception as ex:
         out["vae_roundtrip"] = {"error": repr(ex)}
     torch.cuda.empty_cache()
     try:
         import bench_train
-        r = bench_train.run_train(model, cfg, dev, steps=2, warmup=1)
+        from more4d_amd import ops
+        import more4d_amd.autograd as ag
+        kt = KernelTimer()
+
+        def bwd_flops(q, k, v, o, d_o, lse, **kk):      # 10 L^2 d per head: S, dP, dV, dQ, dK (2 L^2 d each)
+            return 10 * kk["B"] * kk["Lq"] * kk["Lk"] * kk["heads"] * kk["head_dim"]
+        orig = kt.wrap(ops, "attention_bwd", bwd_flops)
+        try:
+            r = bench_train.run_train(model, cfg, dev, steps=2, warmup=1)
+        finally:
+            ops.attention_bwd = orig
+        ab = kt.summary().get("attention_bwd", {})
+        out["roofline_attention_bwd"] = {
+            "kernel": "attn_bwd128_kernel<dQ|dK|dV> via m4d_attention_bwd (self + cross, 3 train steps incl. warm-up)", "bound": "mfma",
+            "achieved": ab.get("tflops", 0.0), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ab.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
+            "launches": ab.get("launches", 0), "flops_convention": "10 B Lq Lk heads head_dim per call"}
+        del ag
         out["train_step"] = {"s_per_step": r["value"], "mfma_frac": r["mfma_frac"], "max_mem_gb": r["max_mem_gb"],
                              "stored_blocks": r["stored_blocks"],
                              "workload": "14B DiT fwd + bwd (+ recompute where activations are not stored) + clip + AdamW, batch 1, "
@@ -149,6 +171,76 @@ def secondary_figures(model, cfg, dev):
     except Exception as ex:
         out["train_step"] = {"error": repr(ex)}
     return out
+
+
+PROBE_SHAPES = ((5120, 5120, 6), (13824, 5120, 1), (5120, 13824, 1))      # (N, K, launches per DiT block) of gemm_bt256p_kernel
+
+
+def pmc_probe():
+    """`bench.py --pmc-probe` (run by measure_traffic under rocprofv3): the dominant kernel at the bench's shapes — M = 43 680
+    rows of the CFG pair, the per-block mix of PROBE_SHAPES — on N(0,1)-scaled operands, nothing else on the device."""
+    from more4d_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    M = 2 * 21840
+    for N, K, reps in PROBE_SHAPES:
+        a = (torch.randn(M, K, generator=g, device=dev) * 0.5).bfloat16()
+        w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).bfloat16()
+        b = torch.zeros(N, device=dev, dtype=torch.bfloat16)
+        for _ in range(reps):
+            ops.gemm_bt(a, w, b)
+        torch.cuda.synchronize()
+        del a, w
+    return 0
+
+
+def measure_traffic(timeout=240):
+    """HBM-side traffic of the dominant kernel from the PMC counters, collected as MI355X_MICROARCH.md prescribes: separate
+    rocprofv3 passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), --kernel-trace only; FETCH_SIZE doubled (gfx950
+    tallies 128-byte requests of wide coalesced reads at 64 B), WRITE_SIZE as reported; both count Infinity-Cache hits, i.e.
+    they are L2-miss traffic.  Returns bytes per launch, averaged over the per-block launch mix, next to the algorithmic bytes."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="m4d_pmc_")
+    env = dict(os.environ, TMPDIR=tmp)
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-probe"]
+            r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode})", "stderr": r.stderr[-300:]}
+            vals = {}
+            for row in csv.DictReader(open(files[0])):
+                if "gemm_bt256p_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    vals[row["Dispatch_Id"]] = vals.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not vals:
+                return None, {"error": f"no gemm_bt256p_kernel rows in the {counter} pass"}
+            per[counter] = sum(vals.values()) / len(vals) * 1024.0          # the counters are reported in KiB
+            per[counter + "_launches"] = len(vals)
+    except Exception as ex:
+        return None, {"error": repr(ex)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    M = 2 * 21840
+    nl = sum(r for _, _, r in PROBE_SHAPES)
+    algo = sum(r * 2 * (M * K + N * K + M * N) for N, K, r in PROBE_SHAPES) / nl      # bf16 A + W read once, out written once
+    fetch, write = 2.0 * per["FETCH_SIZE"], per["WRITE_SIZE"]
+    return fetch + write, {
+        "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "algorithmic_bytes_per_launch": algo,
+        "counter_over_algorithmic": (fetch + write) / algo, "launches_profiled": per["FETCH_SIZE_launches"],
+        "note": "rocprofv3 --kernel-trace --pmc, one pass per counter, inside bench.py after the timed region (bench.py --pmc-probe: the "
+                "kernel alone at the bench shapes); FETCH_SIZE x2 (gfx950 correction of MI355X_MICROARCH.md), WRITE_SIZE raw; both are "
+                "L2-miss (fabric-side) bytes incl. Infinity-Cache hits, so the ratio is re-fetch through L2, not DRAM traffic"}
 
 
 def standin_group(spw):
@@ -270,6 +362,8 @@ def main():
                     help="denoise (default, BASELINE metric): the 4D-STraG denoise step, N>1 = T-sharded strong scaling; "
                          "train: BASELINE configs[4], one DiT train step per GPU, N>1 = data parallel with bucketed gradient "
                          "reduce-scatter + parameter all-gather over RCCL (weak scaling; value = samples/s)")
+    ap.add_argument("--pmc-probe", action="store_true", help="internal: the dominant kernel alone, for the rocprofv3 counter passes")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring up the N ranks (RCCL on GPUs, gloo without), all-reduce a one per rank, print the count")
     ap.add_argument("--parallelism", choices=["auto", "sp", "cfg-sp"], default="auto",
@@ -277,6 +371,8 @@ def main():
                          "halves of the world, tokens sharded inside each half (auto: cfg-sp when N is even)")
     args = ap.parse_args()
 
+    if args.pmc_probe:
+        return pmc_probe()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))       # plain `python bench.py --gpus N`: become the launcher of N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -436,13 +532,12 @@ def main():
             out["roofline"] = {
                 "kernel": "gemm_bt256p_kernel via m4d_gemm_bt (all DiT projections / FFN, bf16; flops-weighted over its launches)",
                 "bound": "mfma", "achieved": gk.get("tflops", 0.0), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                "frac": gk.get("tflops", 0.0) / MFMA_BF16_PEAK_TF, "traffic": None,
+                "frac": gk.get("tflops", 0.0) / MFMA_BF16_PEAK_TF, "traffic": None, "traffic_unit": "bytes per launch",
                 "launches": gk.get("launches", 0), "avg_launch_ms": gk.get("ms", 0.0) / max(1, gk.get("launches", 1)),
                 "share_of_step_time": gk.get("ms", 0.0) / (dt * 1e3),
-                "traffic_note": "PMC passes are separate rocprofv3 runs (tools/prof.sh), not collected inside bench.py: "
-                                "profiles/r01k_pmc_summary.md — FETCH_SIZE 2.79 GiB (x2-corrected) + WRITE_SIZE 0.36 GiB per launch, "
-                                "MFMA pipe busy 58.7 % of SIMD cycles",
             }
+            if world == 1 and not args.no_traffic:
+                out["roofline"]["traffic"], out["roofline"]["traffic_detail"] = measure_traffic()
             ak = ks.get("attention", {})
             out["roofline_attention"] = {
                 "kernel": "attn128p_kernel (self) + attn128_kernel<4> (cross) via m4d_attention", "bound": "mfma", "achieved": ak.get("tflops", 0.0),

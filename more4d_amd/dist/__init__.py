@@ -23,6 +23,11 @@ class SequenceParallelGroup:
     # self-attention attends the local K/V shard first (overlapping the all-gather) and merges the remote part afterwards
     # (m4d_attn_merge); M4D_SP_LOCAL_FIRST=0 restores the single attention call over all gathered segments
     local_first = os.environ.get("M4D_SP_LOCAL_FIRST", "1") != "0"
+    # "allgather" (north_star: RCCL all-gather of K / V^T per layer) | "ulysses": head-split all-to-all — every rank attends ALL
+    # tokens for heads/W of the heads; q, k, v^T go out and o comes back: 4 Ls C elements per rank and layer instead of the
+    # 2 (W-1) Ls C an all-gather receives (3.5x fewer bytes at W = 8).  Selectable for A/B on a real node:
+    # init_sequence_parallel(mode=...) or M4D_SP_MODE.
+    mode = os.environ.get("M4D_SP_MODE", "allgather")
 
     def __init__(self, group=None):
         self.group = group
@@ -42,6 +47,19 @@ class SequenceParallelGroup:
             dist.all_gather_into_tensor(dst, src, group=self.group)
         except (RuntimeError, NotImplementedError, AttributeError):
             dist.all_gather(list(dst.unbind(0)), src, group=self.group)
+
+    def all_to_all(self, x):
+        """x [W, ...]: chunk j goes to rank j; returns [W, ...] whose chunk j came from rank j (one RCCL all-to-all)."""
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        try:
+            dist.all_to_all_single(out, x, group=self.group)
+        except (RuntimeError, NotImplementedError, AttributeError):
+            parts = [torch.empty_like(x) for _ in range(self.world_size)]      # backends without all-to-all (CPU tests)
+            dist.all_gather(parts, x, group=self.group)
+            for j in range(self.world_size):
+                out[j].copy_(parts[j][self.rank])
+        return out
 
     def gather_start(self, x):
         """Begin an all-gather of this rank's shard; returns (gathered buffer [W, *x.shape], work handle).  The
@@ -83,8 +101,9 @@ class SequenceParallelGroup:
         return segs
 
 
-def init_sequence_parallel(group=None, cfg_parallel=False):
+def init_sequence_parallel(group=None, cfg_parallel=False, mode=None):
     """Make `group` (default: WORLD) the sequence-parallel group.  torch.distributed must be initialised.
+    mode: "allgather" (default) | "ulysses" (see SequenceParallelGroup.mode).
 
     cfg_parallel=True (even world size): the unconditional branch of classifier-free guidance runs on ranks
     [0, W/2), the conditional branch on [W/2, W); each half is its own sequence-parallel group (W/2 = 1: no token
@@ -94,6 +113,10 @@ def init_sequence_parallel(group=None, cfg_parallel=False):
     x 4-way T split")."""
     global _SP_GROUP, _CFG
     _CFG = None
+    if mode is not None:
+        if mode not in ("allgather", "ulysses"):
+            raise ValueError(f"unknown sequence-parallel mode {mode!r}")
+        SequenceParallelGroup.mode = mode
     if cfg_parallel:
         if group is not None:
             raise ValueError("cfg_parallel builds its own groups from WORLD")

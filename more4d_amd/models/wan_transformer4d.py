@@ -134,6 +134,9 @@ class WanSelfAttention(nn.Module):
             vt = ops.gemm_bt(self.v.weight, xn, self.v.bias, bias_on_m=True)          # V^T [C, B*Lp]
             ops.rmsnorm_rope(q, wq, k, wk, **rope)
             segs = [KV(k, vt, Lp * C, C, Lp, B * Lp, c.key_len)]
+        elif c.sp.mode == "ulysses":
+            o = self._ulysses(xn, wq, wk, rope, c)
+            segs = None
         else:
             # T-sharded: K and V^T are all-gathered over xGMI while the next projections run (async collectives)
             k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
@@ -168,6 +171,39 @@ class WanSelfAttention(nn.Module):
         ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=gate,
                     gate_stride=gate_stride, rows_per_sample=Lp)
         return xres
+
+
+    def _ulysses(self, xn, wq, wk, rope, c):
+        """Head-split sequence parallelism: project + norm + RoPE on the local tokens (WanRMSNorm runs over the full 5120-wide
+        row, so it stays in front of the split), one all-to-all each for q, k, V^T (chunk j = the heads of rank j), attention of
+        ALL tokens for the local heads with one K/V segment per source rank, one all-to-all back.  Buffers travel token-major
+        ([W, Ls, B, c]) so that the gathered queries / outputs are plain strided [B, L, c] views."""
+        B, Lp, C = xn.shape
+        n, d, W = self.num_heads, self.head_dim, c.sp.world_size
+        if n % W:
+            raise ValueError(f"ulysses needs the head count ({n}) to be a multiple of the sequence-parallel world ({W})")
+        nl = n // W
+        cl = nl * d
+        q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
+        k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
+        vt = ops.gemm_bt(self.v.weight, xn, self.v.bias, bias_on_m=True)           # [C, B*Lp]: rows already grouped by head
+        ops.rmsnorm_rope(q, wq, k, wk, **rope)
+
+        def out_layout(t):       # [B*Lp, C] -> [W, Lp, B, cl]
+            return t.view(B, Lp, W, cl).permute(2, 1, 0, 3).contiguous()
+        qg = c.sp.all_to_all(out_layout(q))                                        # [W(src), Lp, B, cl]
+        kg = c.sp.all_to_all(out_layout(k))
+        vg = c.sp.all_to_all(vt.view(W, cl, B * Lp))                               # [W(src), cl, B*Lp]
+        segs = []
+        for r in range(W):
+            nk = max(0, min(Lp, c.key_len - r * Lp))
+            segs.append(KV(kg[r].reshape(-1), vg[r], cl, B * cl, Lp, B * Lp, nk))
+        L = W * Lp
+        og = torch.empty((L, B, cl), device=q.device, dtype=q.dtype)
+        ops.attention(qg.view(L, B, cl), [s for s in segs if s.len > 0], B=B, Lq=L, heads=nl, head_dim=d, q_bs=cl, q_ls=B * cl,
+                      out=og.permute(1, 0, 2))
+        ob = c.sp.all_to_all(og.view(W, Lp, B, cl))                                # [W(head group), Lp, B, cl]
+        return ob.permute(2, 1, 0, 3).reshape(B, Lp, C)
 
 
 class ContextCache:

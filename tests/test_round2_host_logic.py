@@ -280,3 +280,84 @@ def test_teacache_matches_reference_run(monkeypatch, tag):
     assert not all(calc) and any(calc[1:])
     assert rel_err(traj, z[f"{tag}_traj"]) < 2e-4
     assert rel_err(traj[-1], z[f"{tag}_final"]) < 2e-4
+
+
+@pytest.mark.parametrize("mode,world", [("allgather", 2), ("allgather", 3), ("ulysses", 2), ("ulysses", 4)])
+def test_sequence_parallel_schedules_in_process(monkeypatch, mode, world):
+    """The N-rank token-sharded forward (all-gather of K / V^T with the local-first merge, and the Ulysses head-split all-to-all)
+    driven by N threads over the in-process group (more4d_amd.dist.emulation): every rank's output == the single-rank output ==
+    the reference's (ragged: 197 tokens + ref row over 2 / 3 / 4 ranks, padded key rows masked)."""
+    import copy
+    from more4d_amd.dist import SequenceParallelGroup
+    from more4d_amd.dist.emulation import run_ranks
+    from more4d_amd.models import WanTransformer4DModel
+    cpu_ops.install(monkeypatch)
+    monkeypatch.setattr(SequenceParallelGroup, "mode", mode)
+    z = load_npz("dit_tiny.npz")
+    m = WanTransformer4DModel(**TINY)
+    m.load_state_dict(fill(load_keys("dit_tiny_keys.json"), 1234))
+    m.eval()
+    kw = dict(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"], y=z["y"],
+              full_ref=z["full_ref"])
+    with torch.no_grad():
+        single = m(**kw)
+    assert rel_err(single, z["out_ref"]) < 1e-4
+
+    def rank_fn(group):
+        mr = copy.copy(m)
+        mr.sp_world_size, mr.sp_world_rank, mr._sp = group.world_size, group.rank, group
+        mr.all_gather = group.all_gather
+        with torch.no_grad():
+            return mr(**kw)
+    outs = run_ranks(world, rank_fn)
+    for o in outs:
+        assert rel_err(o, single) < 1e-5
+
+
+def _ulysses_gloo_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import more4d_amd.ops as real
+        for n in cpu_ops.NAMES:
+            setattr(real, n, getattr(cpu_ops, n))
+        from more4d_amd.dist import init_sequence_parallel
+        from more4d_amd.models import WanTransformer4DModel
+        z = load_npz("dit_tiny.npz")
+        m = WanTransformer4DModel(**TINY)
+        m.load_state_dict(fill(load_keys("dit_tiny_keys.json"), 1234))
+        m.eval()
+        g = init_sequence_parallel(mode="ulysses")
+        x = torch.arange(world * 3, dtype=torch.float32).view(world, 3) + 100 * rank
+        got = g.all_to_all(x)
+        want = torch.stack([torch.arange(world * 3, dtype=torch.float32).view(world, 3)[rank] + 100 * j for j in range(world)])
+        m.enable_multi_gpus_inference()
+        with torch.no_grad():
+            out = m(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"], y=z["y"],
+                    full_ref=z["full_ref"])
+        if rank == 0:
+            q.put((bool(torch.equal(got, want)), float(rel_err(out, z["out_ref"]))))
+    finally:
+        from more4d_amd.dist import SequenceParallelGroup
+        SequenceParallelGroup.mode = "allgather"
+        dist.destroy_process_group()
+
+
+def test_ulysses_under_gloo_world2():
+    """The all-to-all plumbing of SequenceParallelGroup over a real process group (gloo) + the Ulysses forward == the reference."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_ulysses_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, err = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok and err < 1e-4
