@@ -30,6 +30,7 @@ struct ConvArgs {
     int ups, tsplit;
     int64_t M, K;
     int tiles_m, tiles_n;
+    int abl;               // timing ablations (tool builds only)
 };
 
 constexpr int ROWB = 128, BM = 128, BN = 128;
@@ -372,6 +373,28 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
     }
 }
 
+#include "conv_halo.h"
+
+template <int KT, int KH, int TH, int TW>
+int launch_halo(ConvArgs& p, hipStream_t st) {
+    using namespace halo;
+    constexpr int HH = TH + KH - 1, PITCH = (TW + KW - 1 + 15) / 16 * 16, NPIX = KT * HH * PITCH;
+    constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + 7) / 8 * 8;
+    constexpr int LDS = HINSTR * 1024 + 2 * KW * WTAP;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            m4d_set_error("conv_cl: cannot enable %d bytes of LDS", LDS);
+            return -3;
+        }
+        configured = true;
+    }
+    p.tiles_m = p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
+    p.tiles_n = (p.Cout + NB - 1) / NB;
+    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, st, p);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
@@ -397,11 +420,18 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
     p.M = (int64_t)To * Ho * Wo;
     p.K = (int64_t)kt * kh * kw * Cin;
+    p.abl = 0;
+#ifdef M4D_ABLATIONS
+    { M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0); p.abl = conv_abl; }
+#endif
     // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
     const int64_t xbytes = (int64_t)Tin * Hin * Win * x_pixel_stride * 2;
-    M4D_ENV_ONCE(conv_variant, "M4D_CONV_VARIANT", 2);
-    const bool v2_shape = conv_variant == 2 && dt == M4D_BF16 && st == 1 && sh == 1 && sw == 1 && !ups && !tsplit && kt <= 8 &&
+    M4D_ENV_ONCE(conv_variant, "M4D_CONV_VARIANT", 3);     // 3 LDS-halo kernel where it applies (default) | 2 DMA-gather implicit GEMM | 1 register-staged
+    const bool v2_shape = conv_variant >= 2 && dt == M4D_BF16 && st == 1 && sh == 1 && sw == 1 && !ups && !tsplit && kt <= 8 &&
                           kh <= 8 && kw <= 8 && p.M >= 1024;
+    const bool halo_shape = conv_variant == 3 && v2_shape && kw == 3 && kh == 3 && (kt == 3 || kt == 1) && pad_t == 0 && pad_h == 1 &&
+                            pad_w == 1 && Ho == Hin && Wo == Win && To == Tin - kt + 1 && Cin % 16 == 0 && Cout >= 32 && Cout % 8 == 0 &&
+                            out_ld % 8 == 0 && (!resid || resid_ld % 8 == 0);
     if (v2_shape && xbytes >= (1ll << 30) && kt == 1 && pad_t == 0 && To == Tin) {
         // 2-D convolution over many frames (the adaptors: 49 x 480 x 832 x 128): frames are independent, so launch groups of
         // frames whose input fits the kernel's 31-bit offsets
@@ -415,6 +445,15 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
                                        st, sh, sw, pad_t, pad_h, pad_w, nf, Ho, Wo, ups, tsplit, stream);
             if (rc) return rc;
         }
+        return 0;
+    }
+    if (halo_shape && xbytes < (1ll << 30)) {
+        const bool wide = (Wo % 32 == 0) || Wo >= 256;        // 8 x 32 patches; narrow maps (104, 208 columns) use 16 x 16
+        int rc;
+        if (kt == 3) rc = wide ? launch_halo<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo<3, 3, 16, 16>(p, (hipStream_t)stream);
+        else rc = wide ? launch_halo<1, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo<1, 3, 16, 16>(p, (hipStream_t)stream);
+        if (rc) return rc;
+        M4D_CHECK_LAUNCH("conv_cl");
         return 0;
     }
     if (v2_shape && xbytes < (1ll << 30)) {

@@ -1,0 +1,241 @@
+// conv_halo_kernel — the production 3x3(x3) convolution of the VAE / adaptors (bf16, stride 1, zero padding 1 in H and W, "valid"
+// in T over the caller's [tail + chunk] staging buffer).  Included by conv.hip.
+//
+// Why a second formulation: as an implicit GEMM (conv_cl256_kernel) every K-tile re-fetches its 256 x 64 activation tile through
+// the global->LDS DMA path although each input pixel feeds 27 taps — 85 FLOP per DMA byte against the 128 of the 256^2 GEMM tile,
+// with ~90 VALU instructions of gather bookkeeping per 16 MFMAs: 17 % of the MFMA peak over a whole encode / decode
+// (profiles/r02a_vae_kernel_stats.csv).  Here a workgroup owns a TH x TW patch of output pixels of one frame and all taps:
+//   * per 16-channel chunk the patch's HALO (KT frames x (TH+2) x (TW+2) pixels x 16 channels) is DMA'd into LDS ONCE and the
+//     27 taps read it at shifted addresses: every MFMA B-fragment (32 pixels x 16 channels) is one ds_read_b128 at
+//     lane_base[dw] + (dt, dh) offset — no per-tap address arithmetic, no validity masks (out-of-image halo pixels were
+//     DMA'd from a zero page), ~200 FLOP per DMA byte;
+//   * the weight tile streams through a double buffer one (dt, dh) row of 3 taps at a time, one barrier per 12 MFMAs per wave;
+//   * TWO workgroups share a CU (72-80 KiB of LDS and <= 128 VGPRs each): ablations of the first version (one workgroup per CU,
+//     double-buffered halo, tools/abl_conv.sh) showed its phases running back to back — MFMA stream 27 %, fragment reads 16 %,
+//     DMA waits 16 %, prologue + uncoalesced epilogue 45 % of the kernel — so the latency of one workgroup's halo load, barrier
+//     or store tail is covered by the other workgroup's MFMAs instead of by deeper buffering inside one workgroup;
+//   * the epilogue goes through LDS (the halo buffer is free by then): 8-byte stores of 32 different pixels per instruction
+//     became 256-byte row segments.
+// LDS layout: halo pixel = 32 B (two 16-byte chunks), row pitch a multiple of 16 pixels; chunk c of pixel px lives at slot
+// c ^ ((px >> 3) & 1): the 16 lanes a ds_read_b128 services per cycle (lanes {0-3,12-15,20-27} of 32 consecutive pixels, or 2 x 16)
+// then cover all sixteen 16-byte bank slots.  Weight rows (one output channel, 16 input channels of one tap) use the same rule.
+// The DMA writes LDS lane-linearly, so the swizzle is applied to the per-lane SOURCE address.
+#pragma once
+
+namespace halo {
+constexpr int NB = 128;                // output channels per workgroup
+constexpr int CK = 16;                 // input channels per chunk = one MFMA K step
+constexpr int PXB = CK * 2;            // bytes per halo pixel
+constexpr int WTAP = NB * PXB;         // bytes of one tap of the weight tile
+constexpr int KW = 3;
+}  // namespace halo
+
+template <int KT, int KH, int TH, int TW>
+__global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+#if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins exist only in the device pass; the host pass needs just the stub)
+    using namespace halo;
+    typedef bf16_t T;
+    constexpr int HH = TH + KH - 1;
+    constexpr int PITCH = (TW + KW - 1 + 15) / 16 * 16;
+    constexpr int NPIX = KT * HH * PITCH;
+    constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + 7) / 8 * 8;    // 1 KiB wave-instructions per halo, a multiple of the 8 waves
+    constexpr int HPW = HINSTR / 8;
+    constexpr int HALO_BYTES = HINSTR * 1024;
+    constexpr int WG_BYTES = KW * WTAP;                            // one (dt, dh) group of 3 taps
+    constexpr int WINSTR = WG_BYTES / 1024;                        // 12
+    constexpr int NG = KT * KH;
+    constexpr int ROWS_PER_MT = 32 / TW > 0 ? 32 / TW : 1;         // image rows covered by one 32-pixel MFMA tile (TW = 32: 1, TW = 16: 2)
+    static_assert(TH * TW == 256 && (TW == 32 || TW == 16), "256 output pixels per workgroup");
+    static_assert(HALO_BYTES + 2 * WG_BYTES >= 8 * 32 * 64 * 2, "the epilogue stages 8 x (32 x 64) bf16 blocks in the workgroup's LDS");
+
+    const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tn = bid % p.tiles_n;
+    int tm = bid / p.tiles_n;
+    const int tw = tm % tiles_w; tm /= tiles_w;
+    const int th = tm % tiles_h;
+    const int to = tm / tiles_h;
+    const int h0 = th * TH, w0 = tw * TW;
+    const int n0 = tn * NB;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- per-lane DMA sources: 32-bit byte offsets into raw buffer descriptors of x / w.  `buffer_load_dwordx4 ... lds` writes ZEROS
+    // for an offset past the end of the buffer (probed: tools/probes/buffer_lds_oob.hip), so halo pixels outside the image are
+    // just offset -1: no zero page, no select, no 64-bit per-lane addresses ----
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.x), (short)0, (int)((int64_t)p.Tin * p.Hin * p.Win * p.xs * 2), 0x00027000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
+    int hoff[HPW];
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+        const int q = (i * 8 + wave) * 64 + lane;
+        const int px = q >> 1, physc = q & 1;
+        const int fdt = px / (HH * PITCH), r = px % (HH * PITCH);
+        const int hh = r / PITCH, ww = r % PITCH;
+        const int c = physc ^ ((ww >> 3) & 1);
+        const int ti = to + fdt, hi_ = h0 - 1 + hh, wi = w0 - 1 + ww;
+        const bool ok = px < NPIX && ww < TW + KW - 1 && ti < p.Tin && hi_ >= 0 && hi_ < p.Hin && wi >= 0 && wi < p.Win;
+        hoff[i] = ok ? (int)((((int64_t)ti * p.Hin + hi_) * p.Win + wi) * p.xs * 2) + c * 16 : -1;
+    }
+    int woff[2];          // (weights of one layer are far below 2 GiB)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (i * 8 + wave) * 64 + lane;
+        const int tig = q >> 8, n = (q & 255) >> 1, physc = q & 1;
+        const int c = physc ^ ((n >> 3) & 1);
+        const int64_t row = min(n0 + n, p.Cout - 1);
+        woff[i] = (int)((row * p.K + tig * p.Cin + c * 8) * 2);
+    }
+    auto issue_halo = [&](int ck0) {
+        char* dst = conv_dyn_smem;
+#pragma unroll
+        for (int i = 0; i < HPW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * 8 + wave) * 1024), 16, hoff[i], ck0 * 2, 0, 0);
+    };
+    auto issue_w = [&](int buf, int ck0, int g) {
+        if (M4D_ABL(p) & 4) return;
+        char* dst = conv_dyn_smem + HALO_BYTES + buf * WG_BYTES;
+        const int koff = (g * KW * p.Cin + ck0) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (i * 8 + wave < WINSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDS_AS void*)(dst + (i * 8 + wave) * 1024), 16, woff[i], koff, 0, 0);
+    };
+
+    // ---- per-lane fragment addresses ----
+    // MFMA "B" operand (activations): lane (li, hi) = pixel li of the wave's 32-pixel tile mi, 8 channels of chunk hi
+    unsigned abase[2][KW];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int mt = wm * 2 + mi;                                   // 32-pixel tile index inside the patch (0..7)
+        const int row = TW == 32 ? mt : mt * ROWS_PER_MT + li / TW;
+        const int col = TW == 32 ? li : li % TW;
+#pragma unroll
+        for (int dw = 0; dw < KW; ++dw) {
+            const int cc = col + dw;
+            abase[mi][dw] = (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
+        }
+    }
+    unsigned wfrag[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = wn * 64 + ni * 32 + li;
+        wfrag[ni] = (unsigned)(n * PXB + ((hi ^ ((n >> 3) & 1)) << 4));
+    }
+
+    f32x16 acc[2][2];   // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)conv_dyn_smem;
+    const int nchunk = p.Cin / CK;
+    const int total = nchunk * NG;
+    issue_w(0, 0, 0);
+    issue_halo(0);
+    int s = 0;
+#pragma unroll 1
+    for (int ci = 0; ci < nchunk; ++ci) {
+#pragma unroll 1
+        for (int g = 0; g < NG; ++g, ++s) {       // (kept rolled: unrolled, hipcc hoists 54 fragment addresses and spills)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my share of weight group s (and of the halo at g == 0)
+            if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
+            if (g == 0 && ci > 0) {
+                // every wave is done with the previous chunk's halo: overwrite it (the co-resident workgroup computes meanwhile)
+                if (!(M4D_ABL(p) & 8)) issue_halo(ci * CK);
+                if (s + 1 < total) issue_w((s + 1) & 1, (NG == 1 ? ci + 1 : ci) * CK, NG == 1 ? 0 : 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2) : "memory");      // the halo instructions are older than the weight ones
+                if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
+            } else if (s + 1 < total) {
+                const int g1 = g + 1 == NG ? 0 : g + 1;
+                issue_w((s + 1) & 1, (g + 1 == NG ? ci + 1 : ci) * CK, g1);
+            }
+            const int fdt = g / KH, dh = g % KH;
+            const unsigned hb = lds_base + (unsigned)((fdt * HH + dh) * PITCH * PXB);
+            const unsigned wb = lds_base + HALO_BYTES + (s & 1) * WG_BYTES;
+#pragma unroll
+            for (int dw = 0; dw < KW; ++dw) {
+                bf16x8 fa[2], fw[2];
+                if (!(M4D_ABL(p) & 2)) {
+                    const unsigned w0_ = wb + dw * WTAP + wfrag[0], w1_ = wb + dw * WTAP + wfrag[1];
+                    const unsigned a0_ = hb + abase[0][dw], a1_ = hb + abase[1][dw];
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[0]) : "v"(w0_));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[1]) : "v"(w1_));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(a0_));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[1]) : "v"(a1_));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        if (!(M4D_ABL(p) & 1)) mma32(fw[ni], fa[mi], acc[ni][mi]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue through LDS: each wave parks 32 pixels x 64 channels (+bias, rounded to T) at a time in its own 4 KiB block of
+    // the (now free) buffers, pixel-major with an XOR swizzle, and writes them back out as 128-byte row segments ----
+    const T* bias = (const T*)p.bias;
+    const T* resid = (const T*)p.resid;
+    __syncthreads();                                       // all fragment reads of the last step are done
+    if (M4D_ABL(p) & 32) return;                           // ablation: no epilogue
+    char* blk = conv_dyn_smem + wave * 4096;               // [32 pixels][64 channels] bf16, 128-byte rows, 16-byte chunk c at c ^ (px & 7)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int nl = ni * 32 + rq * 8 + hi * 4;              // channel inside the wave's 64
+                const int nb = n0 + wn * 64 + nl;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][rq * 4 + e];
+                if (bias && nb < p.Cout) v += load4(bias + nb);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                *reinterpret_cast<bf16x4*>(blk + li * 128 + (((nl >> 3) ^ (li & 7)) << 4) + (nl & 7) * 2) = o;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave reads back only its own block
+        // read back: one instruction = 8 pixels x 128 bytes; lane -> (pixel j*8 + lane/8, chunk lane%8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pl = j * 8 + (lane >> 3), ch = lane & 7;
+            const int mt = wm * 2 + mi;
+            const int row = TW == 32 ? mt : mt * ROWS_PER_MT + pl / TW;
+            const int col = TW == 32 ? pl : pl % TW;
+            const int ho = h0 + row, wo = w0 + col;
+            const int nb = n0 + wn * 64 + ch * 8;
+            uint4 raw = *reinterpret_cast<const uint4*>(blk + pl * 128 + ((ch ^ (pl & 7)) << 4));
+            if (ho >= p.Ho || wo >= p.Wo || nb >= p.Cout) continue;
+            const int64_t m = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
+            if (resid) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(resid + m * p.ldr + nb);
+                const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw);
+                const bf16_t* b = reinterpret_cast<const bf16_t*>(&rr);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)b[e]);        // conv output is T, then x + h (:224)
+                raw = *reinterpret_cast<const uint4*>(&o);
+            }
+            *reinterpret_cast<uint4*>((T*)p.out + m * p.ldo + nb) = raw;          // (Cout % 8 == 0 on this path)
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+#endif
+}
