@@ -30,11 +30,12 @@ struct PadTArgs {
 
 template <typename T>
 __global__ __launch_bounds__(256) void pad_transpose_kernel(PadTArgs p) {
-    __shared__ T tile[64][66];
+    constexpr int EPV = 16 / sizeof(T);                 // elements per 16-byte vector
+    __shared__ __attribute__((aligned(16))) T tile[64][64 + EPV];
     const int s = blockIdx.z, c0 = blockIdx.y * 64;
     const int64_t q0 = (int64_t)blockIdx.x * 64;
     const int t = threadIdx.x;
-    {   // load: pixel t/4, 16 channels starting at (t%4)*16
+    {   // load: pixel t/4, 16 channels starting at (t%4)*16, as 16-byte vectors when the source allows it
         const int px = t >> 2, cpart = (t & 3) * 16;
         const int64_t q = q0 + px + s;
         const int64_t hw = (int64_t)p.Hp * p.Wp;
@@ -42,22 +43,39 @@ __global__ __launch_bounds__(256) void pad_transpose_kernel(PadTArgs p) {
         const int r = (int)(q - fr * hw);
         const int h = r / p.Wp - p.pad_top, w = r % p.Wp - p.pad_left;
         const bool ok = fr < p.T && h >= 0 && h < p.H && w >= 0 && w < p.W;
-        const T* sp = (const T*)p.src + ((fr * p.H + h) * (int64_t)p.W + w) * p.ps;
+        const T* sp = (const T*)p.src + ((fr * p.H + h) * (int64_t)p.W + w) * p.ps + c0 + cpart;
+        const bool vec = (p.ps % EPV) == 0 && (((uintptr_t)p.src) & 15) == 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int c = c0 + cpart + e;
-            tile[px][cpart + e] = (ok && c < p.C) ? sp[c] : (T)0.f;
+        for (int v = 0; v < 16 / EPV; ++v) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            const int c = c0 + cpart + v * EPV;
+            if (ok && c + EPV <= p.C && vec) raw = *reinterpret_cast<const uint4*>(sp + v * EPV);
+            else if (ok && c < p.C) {
+                T tmp[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) tmp[e] = (c + e < p.C) ? sp[v * EPV + e] : (T)0.f;
+                raw = *reinterpret_cast<const uint4*>(tmp);
+            }
+            *reinterpret_cast<uint4*>(&tile[px][cpart + v * EPV]) = raw;
         }
     }
     __syncthreads();
-    {   // store: channel t/4, 16 consecutive q starting at (t%4)*16
+    {   // store: channel t/4, 16 consecutive q starting at (t%4)*16 (16-byte aligned: q0 and ld_out are multiples of 8)
         const int ch = t >> 2, qpart = (t & 3) * 16;
         const int c = c0 + ch;
         if (c < p.C) {
             T* op = (T*)p.out + ((int64_t)s * p.C + c) * p.ld_out + q0 + qpart;
+            const bool vec = (p.ld_out % EPV) == 0 && (((uintptr_t)p.out) & 15) == 0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (q0 + qpart + e < p.cols) op[e] = tile[qpart + e][ch];
+            for (int v = 0; v < 16 / EPV; ++v) {
+                T tmp[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) tmp[e] = tile[qpart + v * EPV + e][ch];
+                if (vec && q0 + qpart + v * EPV + EPV <= p.cols) *reinterpret_cast<uint4*>(op + v * EPV) = *reinterpret_cast<const uint4*>(tmp);
+                else
+                    for (int e = 0; e < EPV; ++e)
+                        if (q0 + qpart + v * EPV + e < p.cols) op[v * EPV + e] = tmp[e];
+            }
         }
     }
 }

@@ -340,3 +340,43 @@ def test_guided_dit_gradients():
         with torch.no_grad():           # inference with the same features: same prediction as the training forward
             out = m(**kw)
         assert rel_err(out.float().cpu(), pred.detach().float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_sharded_data_parallel_flat_buckets_on_device():
+    """more4d_amd.dist.data_parallel on the MI355X at world size 1 (no collective: the same code path minus RCCL): parameters and
+    gradients live in flat buckets, the fused clip + AdamW kernel updates the bucket slices — two steps must equal two steps of the
+    per-parameter optimizer on an identical model (same kernels, different memory layout)."""
+    from more4d_amd.dist.data_parallel import ShardedDataParallel
+    from more4d_amd.models import WanTransformer4DModel
+    from more4d_amd.optim import AdamW, clip_grad_norm_
+    from weights import fill
+    from util import load_keys, load_npz
+    TINY_ = dict(model_type="i2v", in_dim=64, dim=128, ffn_dim=512, num_heads=4, num_layers=2, text_dim=64, text_len=32,
+                 freq_dim=256, out_dim=16, add_ref_conv=True, use_dino_guidance=False, cross_attn_norm=True)
+    z = load_npz("dit_tiny.npz")
+    sd0 = fill(load_keys("dit_tiny_keys.json"), 1234)
+    kw = dict(x=z["x"].to("cuda"), t=z["t"].to("cuda"), context=[z["ctx0"].to("cuda"), z["ctx1"].to("cuda")], seq_len=int(z["seq_len_pad"]),
+              clip_fea=z["clip"].to("cuda"), y=z["y"].to("cuda"), full_ref=z["full_ref"].to("cuda"))
+    tgt = torch.randn(z["x"].shape, generator=torch.Generator().manual_seed(0)).to("cuda")
+    hp = dict(lr=1e-3, weight_decay=3e-2, eps=1e-10)
+
+    def make():
+        m = WanTransformer4DModel(**TINY_)
+        m.load_state_dict(sd0)
+        return m.to("cuda").train()
+    a, b = make(), make()
+    dp = ShardedDataParallel(a, bucket_bytes=400_000, **hp)
+    assert len(dp.buckets) > 2 and all(torch.equal(p.detach().cpu(), sd0[n]) for n, p in a.named_parameters())
+    opt = AdamW(b.parameters(), **hp)
+    for _ in range(2):
+        ((a(**kw).float() - tgt) ** 2).mean().backward()
+        total = dp.reduce_gradients()
+        dp.step(max_norm=0.05, total_norm=total)
+        dp.zero_grad()
+        ((b(**kw).float() - tgt) ** 2).mean().backward()
+        tb = clip_grad_norm_(b.parameters(), 0.05, optimizer=opt)
+        opt.step()
+        opt.zero_grad()
+        assert abs(float(total) - float(tb)) < 1e-5 * float(tb)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 1e-6 * max(1.0, float(pb.detach().abs().max())), n
