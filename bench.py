@@ -139,7 +139,7 @@ def secondary_figures(model, cfg, dev):
         px = 480 * 832
         fl = px * (6.657e6 + 48 * 5.003e6) + px * (10.748e6 + 48 * 8.445e6)
         tf = fl / ((r["ms"]["encode"] + r["ms"]["decode"]) / 1e3) / 1e12
-        out["roofline_vae"] = {"kernel": "conv_cl256_kernel (78 % of VAE kernel time) inside vae.encode + vae.decode, whole-call FLOPs / wall time",
+        out["roofline_vae"] = {"kernel": "conv_halo_kernel (70 % of VAE kernel time) inside vae.encode + vae.decode, whole-call FLOPs / wall time",
                                "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
                                "algorithmic_tflop": fl / 1e12}
     except Exception as ex:
@@ -329,7 +329,7 @@ def train_mode(args, world, rank, local_rank, dev, rccl_ranks, overrides):
                                    "and state); random-init weights", "layers": args.layers, "parallelism": r["data_parallel"],
                        "spatial_guidance": bool(args.guidance)},
             "valid": args.layers == 40 and not overrides and math.isfinite(r["loss"]), "env_overrides": overrides,
-            "rccl_ranks": rccl_ranks, "collectives": exposed, "model_tflop_per_sample": r["model_tflop"], "mfma_frac_whole_step": r["mfma_frac"],
+            "rccl_ranks": rccl_ranks, "model_tflop_per_sample": r["model_tflop"], "mfma_frac_whole_step": r["mfma_frac"],
             "max_mem_gb": r["max_mem_gb"], "stored_blocks": r["stored_blocks"], "loss": r["loss"],
             "optimizer_state_gb_per_rank": r.get("optimizer_state_gb_per_rank")}))
     if world > 1:
