@@ -54,6 +54,15 @@ typedef enum {
 int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                 int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                 const float* gate, int64_t gate_stride, int64_t rows_per_sample, m4d_stream stream);
+/* m4d_gemm_bt with a caller-owned workspace (bytes from m4d_gemm_bt_workspace_bytes; NULL or too small = the plain single launch).
+ * When the 256 x 256 tile grid leaves a partial last round on the 256 CUs (M = 43 680, N = 5120: 3 420 tiles = 13.36 rounds), the
+ * tiles of that round are split along K so that the whole chip works on them; a small kernel sums the float32 slabs in a fixed
+ * order (deterministic) and applies the epilogue.  Same results up to the summation order of the split tiles.  Enabled only with
+ * M4D_GEMM_TAIL=1 (measured: no gain at the power limit, see csrc/gemm.hip); otherwise identical to m4d_gemm_bt. */
+int64_t m4d_gemm_bt_workspace_bytes(m4d_dtype dt, int64_t M, int64_t N, int64_t K);
+int m4d_gemm_bt_ws(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, int bias_on_m, void* out,
+                   int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const float* gate, int64_t gate_stride,
+                   int64_t rows_per_sample, void* ws, int64_t ws_bytes, m4d_stream stream);
 
 /* Weight pre-shuffle for the production GEMM.  m4d_pack_frag re-lays a row-major bf16 matrix W[rows, K] (an nn.Linear
  * weight) out ONCE into MFMA fragment order: out[rb = row/32][kb = k/16][lane][8], lane (li, hi) holding

@@ -37,6 +37,9 @@ SIGNATURES = {
     "m4d_last_error": (c_char_p, []),
     "m4d_gemm_bt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64,
                             c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]),
+    "m4d_gemm_bt_workspace_bytes": (c_int64, [c_int, c_int64, c_int64, c_int64]),
+    "m4d_gemm_bt_ws": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64,
+                               c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "m4d_pack_frag_elems": (c_int64, [c_int64, c_int64]),
     "m4d_pack_frag": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p]),
     "m4d_gemm_bt_packed": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64,

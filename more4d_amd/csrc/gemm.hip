@@ -458,9 +458,75 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256pp_kernel(GemmArgs p) {
 
 }  // namespace
 
-extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
-                           int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
-                           const float* gate, int64_t gate_stride, int64_t rows_per_sample, m4d_stream stream) {
+namespace {
+
+// Sums the K-slices of the tail tiles and applies the real epilogue (same semantics as epilogue_tile): one workgroup per
+// (tile, 16-row strip); thread -> 4 consecutive columns.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tail_fixup_kernel(GemmArgs p) {
+    const int tile = blockIdx.x >> 4, strip = blockIdx.x & 15;
+    int tm, tn;
+    {
+        GemmArgs q = p;
+        q.ksplit = 1; q.tile_base = p.tile_base;
+        tile_coords(q, tm, tn, tile);
+    }
+    const int64_t m_lo = (int64_t)tm * 256, n_lo = (int64_t)tn * 256;
+    const int64_t m0 = min(m_lo, p.M - 256), n0 = min(n_lo, p.N - 256);
+    const T* bias = (const T*)p.bias;
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int r = strip * 16 + i / 64, c4 = (i % 64) * 4;
+        const int64_t m = m0 + r, nb = n0 + c4;
+        if (m < m_lo || nb < n_lo) continue;               // rows / columns of the inward-shifted edge tile that belong to the neighbour
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < p.ksplit; ++sp) v += load4(p.ws + ((int64_t)tile * p.ksplit + sp) * 65536 + r * 256 + c4);
+        if (bias) { if (p.bias_on_m) v += (float)bias[m]; else v += load4(bias + nb); }
+        if (p.epilogue == M4D_EPI_GELU_TANH) { for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]); }
+        else if (p.epilogue == M4D_EPI_GELU_ERF) { for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]); }
+        else if (p.epilogue == M4D_EPI_SILU) { for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]); }
+        if (p.epilogue == M4D_EPI_RESID_GATE) {
+            float* dst = (float*)p.out + m * p.ldc + nb;
+            f32x4 x = load4(dst);
+            f32x4 g = {1.f, 1.f, 1.f, 1.f};
+            if (p.gate) g = load4(p.gate + (m / p.rows_per_sample) * p.gate_stride + nb);
+            for (int e = 0; e < 4; ++e) x[e] += round_through<T>(v[e]) * g[e];
+            store4(dst, x);
+        } else if (p.epilogue == M4D_EPI_STORE_F32) {
+            for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
+            store4((float*)p.out + m * p.ldc + nb, v);
+        } else {
+            store4((T*)p.out + m * p.ldc + nb, v);
+        }
+    }
+}
+
+// (full tiles, K-slices per tail tile) minimising  full/256 + ceil(tail*S/256)/S  (+ 6 % per split for the slab traffic and the
+// shorter K loops); S = 1 means a single ordinary launch
+inline int tail_split(int64_t nwg, int64_t nk, int ncu) {
+    const int64_t tail = nwg % ncu;
+    if (nwg < ncu || tail == 0) return 1;
+    int best = 1;
+    double best_t = 1.0;
+    for (int S = 2; S <= 8; ++S) {
+        if (nk / S < 8) break;
+        const double t = (double)((tail * S + ncu - 1) / ncu) / S * 1.06 + 0.03;
+        if (t < best_t - 0.05) { best_t = t; best = S; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int64_t m4d_gemm_bt_workspace_bytes(m4d_dtype dt, int64_t M, int64_t N, int64_t K) {
+    if (dt != M4D_BF16 || K % 64 || M < 512 || N < 512) return 0;
+    const int64_t nwg = ((M + 255) / 256) * ((N + 255) / 256);
+    const int S = tail_split(nwg, K / 64, 256);
+    return S > 1 ? (nwg % 256) * S * 65536 * 4 : 0;
+}
+
+static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                        int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                        const float* gate, int64_t gate_stride, int64_t rows_per_sample, void* ws, int64_t ws_bytes, m4d_stream stream) {
     const int es = dt == M4D_BF16 ? 2 : 4;
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "gemm_bt: bad dtype %d", (int)dt);
     M4D_CHECK_ARG(A && W && out, "gemm_bt: null pointer");
@@ -477,6 +543,7 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
     p.gate_stride = gate_stride; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : M;
     p.epilogue = epilogue; p.bias_on_m = bias_on_m;
     p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0;
+    p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr;
     p.abl = 0;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(abl_env, "M4D_GEMM_ABL", 0); p.abl = abl_env; }
@@ -501,7 +568,21 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
         p.tiles_m = (int)((M + BM2 - 1) / BM2); p.tiles_n = (int)((N + BN2 - 1) / BN2);
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
         M4D_CHECK_ARG(nwg < (1ll << 31), "gemm_bt: too many tiles");
-        if (variant == 4) hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)nwg), dim3(512), 2 * P_BUF, st, p);
+        // M4D_GEMM_TAIL=1: split-K over the partial last tile round (needs the workspace).  OFF by default: same-box A/B inside bench.py
+        // showed NO gain (1 663 / 1 660 vs 1 663 / 1 665 ms per step) although the 5120-wide GEMMs idle 4.6 % of their CU-rounds —
+        // the step runs at the 1.4 kW power limit, so an idle partial round is paid back as clock on the full
+        // ones — and it costs the bit-identical results of equal samples in one batch (split tiles sum K in a different order).
+        M4D_ENV_ONCE(tail_mode, "M4D_GEMM_TAIL", 0);
+        const int S = (variant == 4 && ws && tail_mode) ? tail_split(nwg, K / 64, 256) : 1;
+        if (S > 1 && ws_bytes >= (nwg % 256) * S * 65536 * 4) {
+            const int tail = (int)(nwg % 256), full = (int)(nwg - tail);
+            p.remap_n = full;
+            hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)full), dim3(512), 2 * P_BUF, st, p);
+            GemmArgs q = p;
+            q.remap_n = 0; q.tile_base = full; q.ksplit = S; q.ws = (float*)ws;
+            hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)(tail * S)), dim3(512), 2 * P_BUF, st, q);
+            hipLaunchKernelGGL(gemm_tail_fixup_kernel<bf16_t>, dim3((unsigned)(tail * 16)), dim3(256), 0, st, q);
+        } else if (variant == 4) hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)nwg), dim3(512), 2 * P_BUF, st, p);
         else if (variant == 3) hipLaunchKernelGGL(gemm_bt256s_kernel, dim3((unsigned)nwg), dim3(512), 5 * SLOT3, st, p);
         else if (variant == 1) hipLaunchKernelGGL(gemm_bt256_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE2_BYTES, st, p);
         else hipLaunchKernelGGL(gemm_bt256pp_kernel, dim3((unsigned)nwg), dim3(512), 4 * SLOT_BYTES, st, p);
@@ -515,6 +596,22 @@ extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void*
     }
     M4D_CHECK_LAUNCH("gemm_bt");
     return 0;
+}
+
+extern "C" int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                           int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                           const float* gate, int64_t gate_stride, int64_t rows_per_sample, m4d_stream stream) {
+    return gemm_bt_impl(dt, A, lda, W, ldw, bias, bias_on_m, out, ldc, M, N, K, epilogue, gate, gate_stride, rows_per_sample, nullptr, 0, stream);
+}
+
+// m4d_gemm_bt with a caller-owned workspace (m4d_gemm_bt_workspace_bytes; may be NULL / too small: plain single launch): when the
+// 256 x 256 tile grid leaves a partial last round on the 256 CUs, the tiles of that round are split along K so that the whole
+// chip works on them, and a small kernel sums the float32 slabs and applies the epilogue.
+extern "C" int m4d_gemm_bt_ws(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                              int bias_on_m, void* out, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                              const float* gate, int64_t gate_stride, int64_t rows_per_sample, void* ws, int64_t ws_bytes, m4d_stream stream) {
+    M4D_CHECK_ARG(ws == nullptr || ((uintptr_t)ws % 16) == 0, "gemm_bt_ws: workspace must be 16-byte aligned");
+    return gemm_bt_impl(dt, A, lda, W, ldw, bias, bias_on_m, out, ldc, M, N, K, epilogue, gate, gate_stride, rows_per_sample, ws, ws_bytes, stream);
 }
 
 
@@ -536,6 +633,7 @@ extern "C" int m4d_gemm_bt_batched(m4d_dtype dt, const void* A, int64_t lda, int
     p.lda = lda; p.ldw = ldw; p.ldc = N; p.M = M; p.N = N; p.K = K;
     p.gate_stride = 0; p.rows_per_sample = M; p.epilogue = M4D_EPI_STORE_F32; p.bias_on_m = 0;
     p.nb1 = nb1; p.a_bs1 = a_bs1; p.a_bs2 = a_bs2; p.w_bs1 = w_bs1; p.w_bs2 = w_bs2; p.abl = 0;
+    p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(nb1 * nb2)), block(256);
     if (dt == M4D_BF16) hipLaunchKernelGGL(gemm_bt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);

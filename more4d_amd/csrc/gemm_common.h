@@ -17,6 +17,10 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int64_t a_bs1, a_bs2, w_bs1, w_bs2;   // batched launches (gridDim.y = nb1 * nb2): element offsets of batch (i1, i2); out += batch * M * ldc
     int nb1;                               // 0 = not batched
+    // split-K tail (m4d_gemm_bt_ws): the launch over the full tile rounds uses `remap_n` (< tiles_m*tiles_n) logical tiles; the tail
+    // launch has ksplit > 0: block b computes K-slice b % ksplit of logical tile tile_base + b / ksplit into its float32 slab of `ws`
+    int remap_n, tile_base, ksplit;
+    float* ws;
     int abl;   // timing ablations (tools only; results wrong when != 0): 1 no DMA, 2 frags once, 4 no barriers, 8 no MFMA
 };
 
@@ -26,9 +30,12 @@ M4D_DEV int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >>
 
 // XCD-aware, banded tile order -> (tm, tn)
 M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn, int bid) {
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.ksplit > 0) bid = p.tile_base + bid / p.ksplit;      // tail launch: logical tile id, no XCD remap
+    else {
+        const int nwg = p.remap_n > 0 ? p.remap_n : p.tiles_m * p.tiles_n;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     constexpr int GM = 8;
     const int band = bid / (GM * p.tiles_n);
     const int band_rows = min(GM, p.tiles_m - band * GM);

@@ -66,8 +66,10 @@ M4D_DEV void epilogue_half_lds(const GemmArgs& p, char* wl, const f32x16& a00, c
                     for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
                 }
                 if (f32out) {
+                    if (!p.nb1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
+                    }
                     if (grow) v = v * load4(grow + nb);
                     const int ch = nl >> 2;                                   // 16 chunks of 4 floats per 256-byte row
                     *reinterpret_cast<f32x4*>(wl + r * 256 + ((ch ^ (r & 15)) << 4)) = v;
@@ -134,9 +136,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
         oa = (unsigned)((((u >> 6) * 128 + (u & 63)) * p.lda + lc * 8) * 2);
         ow = (unsigned)((((u >> 5) * 64 + (u & 31)) * p.ldw + lc * 8) * 2);
     }
-    const char* baseA = uniform_ptr((const char*)p.A + m0 * p.lda * 2);
-    const char* baseW = uniform_ptr((const char*)p.W + n0 * p.ldw * 2);
-    const int nk = (M4D_ABL(p) & 128) ? 2 : (int)(p.K / 64);   // ablation 128: two K-tiles only (per-tile fixed cost)
+    int nk = (M4D_ABL(p) & 128) ? 2 : (int)(p.K / 64);   // ablation 128: two K-tiles only (per-tile fixed cost)
+    int64_t k0 = 0;
+    if (p.ksplit > 0) {
+        // split-K tail: this workgroup owns K-tiles [kb, ke) of the tile and leaves its unrounded float32 partial sums in its own
+        // 256 x 256 slab of the workspace (summed, biased, activated and stored by gemm_tail_fixup_kernel)
+        const int sp = blockIdx.x % p.ksplit;
+        const int kb = (int)((int64_t)nk * sp / p.ksplit), ke = (int)((int64_t)nk * (sp + 1) / p.ksplit);
+        k0 = (int64_t)kb * 64;
+        nk = ke - kb;
+        p.out = p.ws + (int64_t)blockIdx.x * (BM2 * BN2) - (m0 * BN2 + n0);     // element (m, n) -> slab[(m - m0) * 256 + (n - n0)]
+        p.ldc = BN2;
+        p.epilogue = M4D_EPI_STORE_F32; p.bias = nullptr; p.nb1 = 1;             // nb1 != 0: keep the accumulators unrounded
+    }
+    const char* baseA = uniform_ptr((const char*)p.A + (m0 * p.lda + k0) * 2);
+    const char* baseW = uniform_ptr((const char*)p.W + (n0 * p.ldw + k0) * 2);
     // one unit = two DMA instructions per lane: rows r0 + (lane's row) and r1 + (lane's row) of the operand tile
     auto stage = [&](const char* base, int64_t ld, unsigned voff, int r0, int r1, int slot_off, int kt) {
         const int kc = kt < nk ? kt : nk - 1;
@@ -270,5 +284,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bt256p_kernel(GemmArgs p) {
     if (wm == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count of the two groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail stagings must land before the LDS is re-used
     __builtin_amdgcn_s_barrier();                      // ... by anyone: the epilogue transposes through the same LDS
-    P_STORE_TILE(m0, n0, m_lo, n_lo);
+    if (p.ksplit > 0) { P_STORE_TILE(m0, n0, m0, n0); }     // the whole slab; the fixup applies the edge masks
+    else { P_STORE_TILE(m0, n0, m_lo, n_lo); }
 }

@@ -107,9 +107,25 @@ def gemm_bt(a, w, bias=None, *, out=None, epilogue=EPI_STORE, gate=None, gate_st
     if gate is not None and gate.dtype != torch.float32:
         raise TypeError("gemm_bt: gate must be float32")
     lib = _lib.load()
-    check(lib.m4d_gemm_bt(dt_code(a.dtype), _ptr(a), lda, _ptr(w), ldw, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
-                          M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _stream()), "m4d_gemm_bt")
+    nws = lib.m4d_gemm_bt_workspace_bytes(dt_code(a.dtype), M, N, K)
+    ws = _gemm_workspace(a.device, nws) if nws else None
+    check(lib.m4d_gemm_bt_ws(dt_code(a.dtype), _ptr(a), lda, _ptr(w), ldw, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
+                             M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _ptr(ws), nws if ws is not None else 0,
+                             _stream()), "m4d_gemm_bt_ws")
     return out
+
+
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device, nbytes):
+    """Per-device split-K workspace of m4d_gemm_bt_ws (grown on demand; GEMMs on one stream are ordered, so one buffer serves all)."""
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _GEMM_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        _GEMM_WS[key] = buf
+    return buf
 
 
 def _gemm_bt_packed(a, w, bias, *, out, epilogue, gate, gate_stride, rows_per_sample, bias_on_m):
