@@ -121,6 +121,9 @@ typedef struct {
     int64_t vt_bs[M4D_MAX_KV_SEGS], vt_ls[M4D_MAX_KV_SEGS];
     int64_t len[M4D_MAX_KV_SEGS];
     int32_t nseg;
+    int32_t new_softmax;   /* bit s set: segment s starts a NEW softmax whose (normalised) output is added to that of the segments
+                              before it — WanI2VCrossAttention's text + image branches (wan_transformer4d.py:533-552) in one launch,
+                              sharing the query tile; bf16 / head_dim 128 only, not with lse.  0 = one softmax over all segments. */
 } m4d_kv_segs;
 
 int m4d_attention(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, const m4d_kv_segs* kv, void* out,

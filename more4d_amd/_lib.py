@@ -19,7 +19,7 @@ class KvSegs(Structure):
     _fields_ = [("k", c_void_p * MAX_KV_SEGS), ("vt", c_void_p * MAX_KV_SEGS),
                 ("k_bs", c_int64 * MAX_KV_SEGS), ("k_ls", c_int64 * MAX_KV_SEGS),
                 ("vt_bs", c_int64 * MAX_KV_SEGS), ("vt_ls", c_int64 * MAX_KV_SEGS),
-                ("len", c_int64 * MAX_KV_SEGS), ("nseg", c_int32)]
+                ("len", c_int64 * MAX_KV_SEGS), ("nseg", c_int32), ("new_softmax", c_int32)]
 
 
 class AttnBwdArgs(Structure):

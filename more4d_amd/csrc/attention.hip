@@ -365,9 +365,44 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
         cur_dma = key0 + KVB <= p.kv.len[seg];
         if (cur_dma) dma_tile(0, seg, key0);
     }
+    // store (or add) this query row's normalised output; also closes a softmax group (kv.new_softmax)
+    auto flush = [&](bool add) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        if (p.lse && qvalid && hi == 0) p.lse[((int64_t)b * p.heads + h) * p.Lq + qrow] = m_run + log2f(l_tot);
+        if (qvalid) {
+            T* op = (T*)p.out + b * p.o_bs + qrow * p.o_ls + (int64_t)h * D + hi * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = o[d][rq * 4 + e] * inv;
+                    T* dst = op + d * 32 + rq * 8;
+                    if (add) {
+                        f32x4 prev = load4(dst);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]) + prev[e];
+                    }
+                    store4(dst, v);
+                }
+        }
+    };
+    bool group_add = p.accumulate != 0;
     while (seg < p.kv.nseg) {
         const int stage = it & 1;
         const int64_t cur_len = p.kv.len[seg], cur_k0 = key0;
+        if (it > 0 && cur_k0 == 0 && ((p.kv.new_softmax >> seg) & 1)) {
+            // a new softmax starts with this segment: park the finished one in the output (its tile stream goes on underneath)
+            flush(group_add);
+            group_add = true;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+            m_run = -INFINITY; l_run = 0.f;
+        }
         if (cur_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else reg_tile(stage, seg, cur_k0);
         __syncthreads();
@@ -484,27 +519,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
         ++it;
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    if (p.lse && qvalid && hi == 0) p.lse[((int64_t)b * p.heads + h) * p.Lq + qrow] = m_run + log2f(l_tot);
-    if (qvalid) {
-        T* op = (T*)p.out + b * p.o_bs + qrow * p.o_ls + (int64_t)h * D + hi * 4;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = o[d][rq * 4 + e] * inv;
-                T* dst = op + d * 32 + rq * 8;
-                if (p.accumulate) {
-                    f32x4 prev = load4(dst);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]) + prev[e];
-                }
-                store4(dst, v);
-            }
-    }
+    flush(group_add);
 }
 
 #include "attention_phased.h"
@@ -516,7 +531,8 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
     M4D_ENV_ONCE(force_generic, "M4D_ATTN_GENERIC", 0);
     M4D_ENV_ONCE(force_w4, "M4D_ATTN_W4", 0);
     M4D_ENV_ONCE(force_lockstep, "M4D_ATTN_LOCKSTEP", 0);
-    if (sizeof(T) == 2 && D == 128 && !force_generic) {
+    if (p.kv.new_softmax != 0 && !(sizeof(T) == 2 && D == 128)) return -2;      // grouped softmaxes: lockstep bf16 kernels only
+    if (sizeof(T) == 2 && D == 128 && (!force_generic || p.kv.new_softmax != 0)) {
         int64_t keys = 0;
         for (int i = 0; i < p.kv.nseg; ++i) keys += p.kv.len[i] > 0 ? p.kv.len[i] : 0;
         // 256-query workgroups (8 waves share each K/V tile) for long self-attention; short key loops (cross-attention)
@@ -528,7 +544,7 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             if (p.kv.len[i] > 0 && (p.kv.k_ls[i] != p.kv.k_ls[0] || p.kv.vt_ls[i] != p.kv.vt_ls[0])) same_strides = false;
         if (p.kv.len[0] <= 0) same_strides = p.kv.nseg == 1;
         M4D_ENV_ONCE(wide_mode, "M4D_ATTN_WIDE", 0);   // 1: 64-queries-per-wave kernel (attention_wide.h); same-box A/B: phased 1048 vs wide 1020 TF sustained
-        if (w8 && same_strides && keys >= 4 * 64 + 64 * p.kv.nseg && wide_mode) {
+        if (w8 && same_strides && keys >= 4 * 64 + 64 * p.kv.nseg && wide_mode && !p.kv.new_softmax) {
             // 64 queries per wave: half the LDS traffic per MFMA, softmax interleaved into the MFMA stream (attention_wide.h)
             static bool configured_w = false;
             if (!configured_w) {
@@ -552,7 +568,7 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
 #else
             hipLaunchKernelGGL(attn128w_kernel<0>, gw, dim3(256), 4 * 32768, st, q);
 #endif
-        } else if (w8 && same_strides && !force_lockstep) {
+        } else if (w8 && same_strides && !force_lockstep && !p.kv.new_softmax) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
             static bool configured = false;
             if (!configured) {
@@ -611,6 +627,8 @@ static int attention_impl(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_l
         total += kv->len[s];
     }
     M4D_CHECK_ARG(total > 0, "attention: no keys");
+    M4D_CHECK_ARG(kv->new_softmax == 0 || (lse == nullptr && (kv->new_softmax & 1) == 0 && kv->new_softmax < (1 << kv->nseg)),
+                  "attention: new_softmax marks segments 1.. of a call without lse");
     M4D_CHECK_ARG(q_ls % 8 == 0 && q_bs % 8 == 0 && o_ls % 8 == 0 && o_bs % 8 == 0, "attention: q/out strides must be multiples of 8 elements");
     M4D_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)out % 16) == 0, "attention: q/out must be 16-byte aligned");
     AttnArgs p;

@@ -15,6 +15,7 @@ rows for V^T); rows >= seq_len are never used as keys.  V is produced TRANSPOSED
 GEMM (V^T [C, B*Lp]) because the attention kernel consumes V^T tiles (csrc/attention.hip).
 """
 import math
+import os
 import types
 from typing import Optional
 
@@ -64,6 +65,9 @@ def build_rope_tables(freqs, grid, head_dim, device):
                    fr[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
                    fr[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, -1)
     return (z.real.to(torch.float32).contiguous().to(device), z.imag.to(torch.float32).contiguous().to(device))
+
+
+_XATTN_FUSED = os.environ.get("M4D_XATTN_FUSED", "1") != "0"      # A/B switch: 0 = text and image branches as two launches
 
 
 def _f32(p, cache):
@@ -262,10 +266,15 @@ class WanT2VCrossAttention(WanSelfAttention):
         q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
         if self.qk_norm:
             ops.rmsnorm_rope(q, _f32(self.norm_q.weight, c.f32cache), head_dim=d, eps=self.eps)
-        o = ops.attention(q, [kv["txt"]], B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
-        if "img" in kv:  # x + img_x (:552)
-            ops.attention(q, [kv["img"]], B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C, out=o,
-                          accumulate=True)
+        if "img" in kv and q.dtype == torch.bfloat16 and d == 128 and _XATTN_FUSED:
+            # text and image branches (:533-552: two attentions over the same queries, summed) in ONE launch: the query tile is
+            # loaded once, the key-tile stream runs through both segments, and the image softmax is added on top of the text one
+            o = ops.attention(q, [kv["txt"], kv["img"]], B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C, new_softmax=0b10)
+        else:
+            o = ops.attention(q, [kv["txt"]], B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
+            if "img" in kv:  # x + img_x (:552)
+                ops.attention(q, [kv["img"]], B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C, out=o,
+                              accumulate=True)
         ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=None,
                     rows_per_sample=Lp)
         return xres

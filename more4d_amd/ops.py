@@ -210,9 +210,12 @@ class KV:
         self.k, self.vt, self.k_bs, self.k_ls, self.vt_bs, self.vt_ls, self.len = k, vt, k_bs, k_ls, vt_bs, vt_ls, length
 
 
-def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None, lse=None):
+def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None, lse=None,
+              new_softmax=0):
     """softmax(q k^T * scale) v over the concatenation of `segs` (list of KV).  q/out: [B, Lq, heads*head_dim].
-    lse: optional float32 [B, heads, Lq] receiving the log2-domain log-sum-exp (training)."""
+    lse: optional float32 [B, heads, Lq] receiving the log2-domain log-sum-exp (training).
+    new_softmax: bit s set = segment s starts a new softmax whose output is ADDED to the previous ones (one launch for the text +
+    image branches of the i2v cross-attention; bf16, head_dim 128)."""
     _dev(q, out, *[s.k for s in segs], *[s.vt for s in segs])
     C = heads * head_dim
     if q_ls is None:
@@ -225,6 +228,7 @@ def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None
         raise ValueError(f"attention: 1..{_lib.MAX_KV_SEGS} KV segments, got {len(segs)}")
     kv = KvSegs()
     kv.nseg = len(segs)
+    kv.new_softmax = int(new_softmax)
     for i, s in enumerate(segs):
         if s.k.dtype != q.dtype or s.vt.dtype != q.dtype:
             raise TypeError("attention: q/k/v dtype mismatch")

@@ -118,7 +118,21 @@ def rmsnorm_rope(x0, w0, x1=None, w1=None, *, head_dim, eps=1e-6, cos=None, sin=
     return x0, x1
 
 
-def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None, lse=None):
+def attention(q, segs, *, B, Lq, heads, head_dim, out=None, q_bs=None, q_ls=None, accumulate=False, scale=None, lse=None,
+              new_softmax=0):
+    if new_softmax:      # groups of segments, each its own softmax, outputs summed
+        groups, cur = [], []
+        for i, sg in enumerate(segs):
+            if (new_softmax >> i) & 1 and cur:
+                groups.append(cur)
+                cur = []
+            cur.append(sg)
+        groups.append(cur)
+        res = None
+        for gi, gsegs in enumerate(groups):
+            res = attention(q, gsegs, B=B, Lq=Lq, heads=heads, head_dim=head_dim, out=res if gi else out, q_bs=q_bs, q_ls=q_ls,
+                            accumulate=accumulate if gi == 0 else True, scale=scale)
+        return res
     C = heads * head_dim
     if q_ls is None:
         q_ls = C

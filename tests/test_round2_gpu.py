@@ -309,3 +309,41 @@ def test_n_rank_schedule_full_size_bf16(mode, world):
     assert err < 5e-3 and mx < 3e-2
     del m
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("Lq,accumulate", [(300, False), (2100, True)])
+def test_two_softmaxes_in_one_launch(Lq, accumulate):
+    """kv.new_softmax: the text (512 keys) and image (257 keys: ragged last tile) branches of the i2v cross-attention in one launch
+    == two launches (second one accumulating) == fp32 torch; both lockstep kernels (4-wave: short; 8-wave: Lq > 1024 & >= 2048 keys
+    is not reached by 769 keys, so Lq only changes the grid)."""
+    from more4d_amd import ops
+    from more4d_amd.ops import KV
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, n, d = 2, 5, 128
+    C = n * d
+    q = torch.randn(B * Lq, C, generator=g, device=DEV).to(BF)
+    segs, refs = [], []
+    for L in (512, 257):
+        Lp = (L + 7) // 8 * 8
+        k = torch.randn(B * Lp, C, generator=g, device=DEV).to(BF)
+        vt = torch.randn(C, B * Lp, generator=g, device=DEV).to(BF)
+        segs.append(KV(k.view(-1), vt, Lp * C, C, Lp, B * Lp, L))
+        refs.append((k.view(B, Lp, C)[:, :L], vt.view(C, B, Lp)[:, :, :L]))
+    kw = dict(B=B, Lq=Lq, heads=n, head_dim=d, q_bs=Lq * C, q_ls=C)
+    base = torch.randn(B, Lq, C, generator=g, device=DEV).to(BF) if accumulate else None
+    one = ops.attention(q, segs, out=base.clone() if accumulate else None, accumulate=accumulate, new_softmax=0b10, **kw)
+    two = ops.attention(q, [segs[0]], out=base.clone() if accumulate else None, accumulate=accumulate, **kw)
+    ops.attention(q, [segs[1]], out=two, accumulate=True, **kw)
+    assert rel_err(one.float().cpu(), two.float().cpu()) < 8e-3
+    qf = q.view(B, Lq, n, d).float()
+    want = torch.zeros(B, Lq, n, d, device=DEV)
+    for k, vt in refs:
+        kf = k.reshape(B, -1, n, d).float()
+        vf = vt.permute(1, 2, 0).reshape(B, -1, n, d).float()
+        s = torch.einsum("bqhd,bkhd->bhqk", qf, kf) / math.sqrt(d)
+        want += torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), vf)
+    want = want.reshape(B, Lq, C) + (base.float() if accumulate else 0)
+    assert rel_err(one.float().cpu(), want.cpu()) < 1.2e-2
+    with pytest.raises(Exception):
+        ops.attention(q.float(), [KV(s_.k.float(), s_.vt.float(), s_.k_bs, s_.k_ls, s_.vt_bs, s_.vt_ls, s_.len) for s_ in segs],
+                      new_softmax=0b10, **kw)       # fp32 / generic kernels: refused, the model falls back to two launches
