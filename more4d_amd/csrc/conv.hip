@@ -375,24 +375,31 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
 
 #include "conv_halo.h"
 
-template <int KT, int KH, int TH, int TW>
+template <int KT, int KH, int TH, int TW, int NT>
 int launch_halo(ConvArgs& p, hipStream_t st) {
     using namespace halo;
     constexpr int HH = TH + KH - 1, PITCH = (TW + KW - 1 + 15) / 16 * 16, NPIX = KT * HH * PITCH;
     constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + 7) / 8 * 8;
-    constexpr int LDS = HINSTR * 1024 + 2 * KW * WTAP;
+    constexpr int MAIN = HINSTR * 1024 + 2 * KW * NT * 32 * PXB, EPI = 8 * 32 * NT * 64;       // halo + 2 weight groups | epilogue blocks
+    constexpr int LDS = MAIN > EPI ? MAIN : EPI;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             m4d_set_error("conv_cl: cannot enable %d bytes of LDS", LDS);
             return -3;
         }
         configured = true;
     }
     p.tiles_m = p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
-    p.tiles_n = (p.Cout + NB - 1) / NB;
-    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, st, p);
+    p.tiles_n = (p.Cout + NT * 32 - 1) / (NT * 32);
+    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, st, p);
     return 0;
+}
+
+// output channels per workgroup = NT x 32: 96 / 192 / 384 -> 1 / 2 / 4 tiles of 96, everything else tiles of 128
+template <int KT, int KH, int TH, int TW>
+int launch_halo_nt(ConvArgs& p, hipStream_t st) {
+    return ((p.Cout + 31) / 32) % 3 == 0 ? launch_halo<KT, KH, TH, TW, 3>(p, st) : launch_halo<KT, KH, TH, TW, 4>(p, st);
 }
 
 }  // namespace
@@ -450,8 +457,8 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     if (halo_shape && xbytes < (1ll << 30)) {
         const bool wide = (Wo % 32 == 0) || Wo >= 256;        // 8 x 32 patches; narrow maps (104, 208 columns) use 16 x 16
         int rc;
-        if (kt == 3) rc = wide ? launch_halo<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo<3, 3, 16, 16>(p, (hipStream_t)stream);
-        else rc = wide ? launch_halo<1, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo<1, 3, 16, 16>(p, (hipStream_t)stream);
+        if (kt == 3) rc = wide ? launch_halo_nt<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<3, 3, 16, 16>(p, (hipStream_t)stream);
+        else rc = wide ? launch_halo_nt<1, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<1, 3, 16, 16>(p, (hipStream_t)stream);
         if (rc) return rc;
         M4D_CHECK_LAUNCH("conv_cl");
         return 0;

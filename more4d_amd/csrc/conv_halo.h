@@ -15,7 +15,13 @@
 //     DMA waits 16 %, prologue + uncoalesced epilogue 45 % of the kernel — so the latency of one workgroup's halo load, barrier
 //     or store tail is covered by the other workgroup's MFMAs instead of by deeper buffering inside one workgroup;
 //   * the epilogue goes through LDS (the halo buffer is free by then): 8-byte stores of 32 different pixels per instruction
-//     became 256-byte row segments.
+//     became 64 x NT-byte row segments;
+//   * EXACT output-channel tiles: the 8 waves sit along the pixel axis (32 pixels each) and every wave owns all NT 32-channel
+//     column tiles of the workgroup (NT = 3 for 96 / 192 / 384 output channels = 1 / 2 / 4 tiles, NT = 4 for 128): no MFMA runs on padding
+//     channels (the 4 x 2 wave layout with a fixed 128-channel tile wasted 25 % of the MFMAs at 96, 192 and 384 channels),
+//     and one pixel fragment feeds NT MFMAs.  PMC (tools/prof_kernel.sh): the kernel
+//     sits at the POWER limit at ~1.5 GHz (back-to-back launches slow down 1064 -> 1412 us within three launches), so what counts
+//     is energy: fewer MFMAs and less fabric traffic, not only fewer stalls.
 // LDS layout: halo pixel = 32 B (two 16-byte chunks), row pitch a multiple of 16 pixels; chunk c of pixel px lives at slot
 // c ^ ((px >> 3) & 1): the 16 lanes a ds_read_b128 services per cycle (lanes {0-3,12-15,20-27} of 32 consecutive pixels, or 2 x 16)
 // then cover all sixteen 16-byte bank slots.  Weight rows (one output channel, 16 input channels of one tap) use the same rule.
@@ -23,18 +29,18 @@
 #pragma once
 
 namespace halo {
-constexpr int NB = 128;                // output channels per workgroup
 constexpr int CK = 16;                 // input channels per chunk = one MFMA K step
-constexpr int PXB = CK * 2;            // bytes per halo pixel
-constexpr int WTAP = NB * PXB;         // bytes of one tap of the weight tile
+constexpr int PXB = CK * 2;            // bytes per halo pixel / per weight row of one tap
 constexpr int KW = 3;
 }  // namespace halo
 
-template <int KT, int KH, int TH, int TW>
-__global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+template <int KT, int KH, int TH, int TW, int NT>
+__global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      // two workgroups per CU (<= 128 VGPRs)
 #if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins exist only in the device pass; the host pass needs just the stub)
     using namespace halo;
     typedef bf16_t T;
+    constexpr int NB = NT * 32;                                    // output channels per workgroup
+    constexpr int WTAP = NB * PXB;                                 // bytes of one tap of the weight tile
     constexpr int HH = TH + KH - 1;
     constexpr int PITCH = (TW + KW - 1 + 15) / 16 * 16;
     constexpr int NPIX = KT * HH * PITCH;
@@ -42,11 +48,15 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
     constexpr int HPW = HINSTR / 8;
     constexpr int HALO_BYTES = HINSTR * 1024;
     constexpr int WG_BYTES = KW * WTAP;                            // one (dt, dh) group of 3 taps
-    constexpr int WINSTR = WG_BYTES / 1024;                        // 12
+    constexpr int WINSTR = WG_BYTES / 1024;                        // 9 / 12 / 18
+    constexpr int WPW = (WINSTR + 7) / 8;                          // weight DMA instructions per wave (upper bound)
     constexpr int NG = KT * KH;
+    static_assert(NG >= 2, "the halo reload assumes a weight group follows it");
     constexpr int ROWS_PER_MT = 32 / TW > 0 ? 32 / TW : 1;         // image rows covered by one 32-pixel MFMA tile (TW = 32: 1, TW = 16: 2)
+    constexpr int ESW = NT % 2 == 0 ? 7 : 3;                       // epilogue swizzle mask: the XOR must stay inside the pixel's NT*4 chunks
+    constexpr int EROW = NT * 64;                                  // bytes of one pixel's NB channels in the epilogue staging block
     static_assert(TH * TW == 256 && (TW == 32 || TW == 16), "256 output pixels per workgroup");
-    static_assert(HALO_BYTES + 2 * WG_BYTES >= 8 * 32 * 64 * 2, "the epilogue stages 8 x (32 x 64) bf16 blocks in the workgroup's LDS");
+    static_assert(NT == 3 || NT == 4, "two workgroups per CU: 128 VGPRs, <= 80 KiB of LDS (launch_halo sizes it for the epilogue blocks too)");
 
     const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
     const int nwg = p.tiles_m * p.tiles_n;
@@ -65,7 +75,6 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
 
     // ---- per-lane DMA sources: 32-bit byte offsets into raw buffer descriptors of x / w.  `buffer_load_dwordx4 ... lds` writes ZEROS
     // for an offset past the end of the buffer (probed: tools/probes/buffer_lds_oob.hip), so halo pixels outside the image are
@@ -85,11 +94,11 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
         const bool ok = px < NPIX && ww < TW + KW - 1 && ti < p.Tin && hi_ >= 0 && hi_ < p.Hin && wi >= 0 && wi < p.Win;
         hoff[i] = ok ? (int)((((int64_t)ti * p.Hin + hi_) * p.Win + wi) * p.xs * 2) + c * 16 : -1;
     }
-    int woff[2];          // (weights of one layer are far below 2 GiB)
+    int woff[WPW];          // (weights of one layer are far below 2 GiB)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = (i * 8 + wave) * 64 + lane;
-        const int tig = q >> 8, n = (q & 255) >> 1, physc = q & 1;
+    for (int i = 0; i < WPW; ++i) {
+        const int q = (i * 8 + wave) * 64 + lane;                   // 16-byte slot inside the group: tap, row, physical chunk
+        const int tig = q / (NB * 2), n = (q % (NB * 2)) >> 1, physc = q & 1;
         const int c = physc ^ ((n >> 3) & 1);
         const int64_t row = min(n0 + n, p.Cout - 1);
         woff[i] = (int)((row * p.K + tig * p.Cin + c * 8) * 2);
@@ -105,39 +114,31 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
         char* dst = conv_dyn_smem + HALO_BYTES + buf * WG_BYTES;
         const int koff = (g * KW * p.Cin + ck0) * 2;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WPW; ++i)
             if (i * 8 + wave < WINSTR)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDS_AS void*)(dst + (i * 8 + wave) * 1024), 16, woff[i], koff, 0, 0);
     };
 
     // ---- per-lane fragment addresses ----
-    // MFMA "B" operand (activations): lane (li, hi) = pixel li of the wave's 32-pixel tile mi, 8 channels of chunk hi
-    unsigned abase[2][KW];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int mt = wm * 2 + mi;                                   // 32-pixel tile index inside the patch (0..7)
-        const int row = TW == 32 ? mt : mt * ROWS_PER_MT + li / TW;
+    // MFMA "B" operand (activations): lane (li, hi) = pixel li of this wave's 32-pixel tile, 8 channels of chunk hi
+    unsigned abase[KW];
+    {
+        const int row = TW == 32 ? wave : wave * ROWS_PER_MT + li / TW;
         const int col = TW == 32 ? li : li % TW;
 #pragma unroll
         for (int dw = 0; dw < KW; ++dw) {
             const int cc = col + dw;
-            abase[mi][dw] = (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
+            abase[dw] = (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
         }
     }
-    unsigned wfrag[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = wn * 64 + ni * 32 + li;
-        wfrag[ni] = (unsigned)(n * PXB + ((hi ^ ((n >> 3) & 1)) << 4));
-    }
+    // MFMA "A" operand (weights): row n = ni*32 + li of the tap's [NB x 16] tile; further column tiles are +32 rows = +1024 bytes
+    const unsigned wfrag = (unsigned)(li * PXB + ((hi ^ ((li >> 3) & 1)) << 4));
 
-    f32x16 acc[2][2];   // [ni][mi]
+    f32x16 acc[NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)conv_dyn_smem;
     const int nchunk = p.Cin / CK;
@@ -148,14 +149,16 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
 #pragma unroll 1
     for (int ci = 0; ci < nchunk; ++ci) {
 #pragma unroll 1
-        for (int g = 0; g < NG; ++g, ++s) {       // (kept rolled: unrolled, hipcc hoists 54 fragment addresses and spills)
+        for (int g = 0; g < NG; ++g, ++s) {       // (kept rolled: unrolled, hipcc hoists every fragment address and spills)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my share of weight group s (and of the halo at g == 0)
             if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
             if (g == 0 && ci > 0) {
                 // every wave is done with the previous chunk's halo: overwrite it (the co-resident workgroup computes meanwhile)
                 if (!(M4D_ABL(p) & 8)) issue_halo(ci * CK);
                 if (s + 1 < total) issue_w((s + 1) & 1, (NG == 1 ? ci + 1 : ci) * CK, NG == 1 ? 0 : 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2) : "memory");      // the halo instructions are older than the weight ones
+                // the halo instructions are older than the weight ones: leave only the latter in flight (WPW or WPW - 1 of them, by wave)
+                if (WINSTR % 8 == 0 || wave < WINSTR % 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW - 1) : "memory");
                 if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
             } else if (s + 1 < total) {
                 const int g1 = g + 1 == NG ? 0 : g + 1;
@@ -163,65 +166,75 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
             }
             const int fdt = g / KH, dh = g % KH;
             const unsigned hb = lds_base + (unsigned)((fdt * HH + dh) * PITCH * PXB);
-            const unsigned wb = lds_base + HALO_BYTES + (s & 1) * WG_BYTES;
+            const unsigned wb = lds_base + HALO_BYTES + (s & 1) * WG_BYTES + wfrag;
+            // one pixel fragment feeds NT MFMAs; the fragments of tap dw+1 are requested before the MFMAs of tap dw (counted
+            // lgkmcnt): the LDS latency is exposed once per step, not once per tap
+            bf16x8 fa[2], fw[2][NT];
+#define HL_LD(buf, dw)                                                                                          \
+            do {                                                                                                \
+                const unsigned a_ = hb + abase[dw];                                                             \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fa[buf]) : "v"(a_));                                  \
+                _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) {                                             \
+                    const unsigned w_ = wb + (dw) * WTAP + ni * 1024;                                           \
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[buf][ni]) : "v"(w_));                          \
+                }                                                                                               \
+            } while (0)
+            if (!(M4D_ABL(p) & 2)) HL_LD(0, 0);
 #pragma unroll
             for (int dw = 0; dw < KW; ++dw) {
-                bf16x8 fa[2], fw[2];
                 if (!(M4D_ABL(p) & 2)) {
-                    const unsigned w0_ = wb + dw * WTAP + wfrag[0], w1_ = wb + dw * WTAP + wfrag[1];
-                    const unsigned a0_ = hb + abase[0][dw], a1_ = hb + abase[1][dw];
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[0]) : "v"(w0_));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[1]) : "v"(w1_));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(a0_));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[1]) : "v"(a1_));
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (dw == 0) { HL_LD(1, 1); }
+                    else if (dw == 1) { HL_LD(0, 2); }
+                    if (dw < KW - 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + 1) : "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-                        if (!(M4D_ABL(p) & 1)) mma32(fw[ni], fa[mi], acc[ni][mi]);
+                for (int ni = 0; ni < NT; ++ni)
+                    if (!(M4D_ABL(p) & 1)) mma32(fw[dw & 1][ni], fa[dw & 1], acc[ni]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#undef HL_LD
         }
     }
 
-    // ---- epilogue through LDS: each wave parks 32 pixels x 64 channels (+bias, rounded to T) at a time in its own 4 KiB block of
-    // the (now free) buffers, pixel-major with an XOR swizzle, and writes them back out as 128-byte row segments ----
+    // ---- epilogue through LDS: each wave parks its 32 pixels x NB channels (+bias, rounded to T) in its own block of the (now free)
+    // buffers, pixel-major with an XOR swizzle of the 16-byte chunks, and writes them back out as contiguous row segments ----
     const T* bias = (const T*)p.bias;
     const T* resid = (const T*)p.resid;
     __syncthreads();                                       // all fragment reads of the last step are done
     if (M4D_ABL(p) & 32) return;                           // ablation: no epilogue
-    char* blk = conv_dyn_smem + wave * 4096;               // [32 pixels][64 channels] bf16, 128-byte rows, 16-byte chunk c at c ^ (px & 7)
+    char* blk = conv_dyn_smem + wave * (32 * EROW);        // [32 pixels][NB channels] bf16; chunk c of pixel px at c ^ (px & ESW)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int rq = 0; rq < 4; ++rq) {
+            const int nl = ni * 32 + rq * 8 + hi * 4;              // channel inside the workgroup's NB
+            const int nb = n0 + nl;
+            f32x4 v;
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int nl = ni * 32 + rq * 8 + hi * 4;              // channel inside the wave's 64
-                const int nb = n0 + wn * 64 + nl;
-                f32x4 v;
+            for (int e = 0; e < 4; ++e) v[e] = acc[ni][rq * 4 + e];
+            if (bias && nb < p.Cout) v += load4(bias + nb);
+            bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][rq * 4 + e];
-                if (bias && nb < p.Cout) v += load4(bias + nb);
-                bf16x4 o;
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+            const int ch = nl >> 3;
+            *reinterpret_cast<bf16x4*>(blk + li * EROW + ((ch ^ (li & ESW)) << 4) + (nl & 7) * 2) = o;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave reads back only its own block
+    {
+        constexpr int CPP = NT * 4;                        // 16-byte chunks per pixel
+        const int row0 = TW == 32 ? wave : wave * ROWS_PER_MT;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-                *reinterpret_cast<bf16x4*>(blk + li * 128 + (((nl >> 3) ^ (li & 7)) << 4) + (nl & 7) * 2) = o;
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave reads back only its own block
-        // read back: one instruction = 8 pixels x 128 bytes; lane -> (pixel j*8 + lane/8, chunk lane%8)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pl = j * 8 + (lane >> 3), ch = lane & 7;
-            const int mt = wm * 2 + mi;
-            const int row = TW == 32 ? mt : mt * ROWS_PER_MT + pl / TW;
+        for (int j = 0; j < (32 * CPP + 63) / 64; ++j) {
+            const int q = j * 64 + lane;
+            const int pl = q / CPP, ch = q % CPP;
+            if (pl >= 32) continue;
+            const int row = TW == 32 ? row0 : row0 + pl / TW;
             const int col = TW == 32 ? pl : pl % TW;
             const int ho = h0 + row, wo = w0 + col;
-            const int nb = n0 + wn * 64 + ch * 8;
-            uint4 raw = *reinterpret_cast<const uint4*>(blk + pl * 128 + ((ch ^ (pl & 7)) << 4));
+            const int nb = n0 + ch * 8;
+            uint4 raw = *reinterpret_cast<const uint4*>(blk + pl * EROW + ((ch ^ (pl & ESW)) << 4));
             if (ho >= p.Ho || wo >= p.Wo || nb >= p.Cout) continue;
             const int64_t m = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
             if (resid) {
@@ -235,7 +248,6 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
             }
             *reinterpret_cast<uint4*>((T*)p.out + m * p.ldo + nb) = raw;          // (Cout % 8 == 0 on this path)
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
     }
 #endif
 }
