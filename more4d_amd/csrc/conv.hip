@@ -31,6 +31,7 @@ struct ConvArgs {
     int64_t M, K;
     int tiles_m, tiles_n;
     int abl;               // timing ablations (tool builds only)
+    int xplanar;           // input is planar-16: [Cin/16][Tin][Hin][Win][16] (conv_halo_kernel only)
 };
 
 constexpr int ROWB = 128, BM = 128, BN = 128;
@@ -375,16 +376,12 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
 
 #include "conv_halo.h"
 
-template <int KT, int KH, int TH, int TW, int NT>
+template <int KT, int KH, int TH, int TW, int NT, int MT>
 int launch_halo(ConvArgs& p, hipStream_t st) {
-    using namespace halo;
-    constexpr int HH = TH + KH - 1, PITCH = (TW + KW - 1 + 15) / 16 * 16, NPIX = KT * HH * PITCH;
-    constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + 7) / 8 * 8;
-    constexpr int MAIN = HINSTR * 1024 + 2 * KW * NT * 32 * PXB, EPI = 8 * 32 * NT * 64;       // halo + 2 weight groups | epilogue blocks
-    constexpr int LDS = MAIN > EPI ? MAIN : EPI;
+    constexpr int LDS = halo::Cfg<KT, KH, TH, TW, NT, MT>::LDS_BYTES;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             m4d_set_error("conv_cl: cannot enable %d bytes of LDS", LDS);
             return -3;
         }
@@ -392,14 +389,14 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
     }
     p.tiles_m = p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
     p.tiles_n = (p.Cout + NT * 32 - 1) / (NT * 32);
-    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), LDS, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT, MT>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512 / MT), LDS, st, p);
     return 0;
 }
 
 // output channels per workgroup = NT x 32: 96 / 192 / 384 -> 1 / 2 / 4 tiles of 96, everything else tiles of 128
 template <int KT, int KH, int TH, int TW>
 int launch_halo_nt(ConvArgs& p, hipStream_t st) {
-    return ((p.Cout + 31) / 32) % 3 == 0 ? launch_halo<KT, KH, TH, TW, 3>(p, st) : launch_halo<KT, KH, TH, TW, 4>(p, st);
+    return ((p.Cout + 31) / 32) % 3 == 0 ? launch_halo<KT, KH, TH, TW, 3, 2>(p, st) : launch_halo<KT, KH, TH, TW, 4, 2>(p, st);
 }
 
 }  // namespace
@@ -427,9 +424,10 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
     p.M = (int64_t)To * Ho * Wo;
     p.K = (int64_t)kt * kh * kw * Cin;
-    p.abl = 0;
+    p.abl = 0; p.xplanar = 0;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0); p.abl = conv_abl; }
+    { M4D_ENV_ONCE(conv_planar, "M4D_CONV_PLANAR", 0); p.xplanar = conv_planar; }     // timing experiment: same bytes read as planar-16
 #endif
     // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
     const int64_t xbytes = (int64_t)Tin * Hin * Win * x_pixel_stride * 2;

@@ -32,29 +32,41 @@ namespace halo {
 constexpr int CK = 16;                 // input channels per chunk = one MFMA K step
 constexpr int PXB = CK * 2;            // bytes per halo pixel / per weight row of one tap
 constexpr int KW = 3;
+
+// LDS geometry of one instantiation (shared by the kernel and its launcher)
+template <int KT, int KH, int TH, int TW, int NT, int MT>
+struct Cfg {
+    static constexpr int NWAVE = 8 / MT;                                  // every wave owns MT 32-pixel tiles x NT 32-channel tiles
+    static constexpr int NB = NT * 32;                                    // output channels per workgroup
+    static constexpr int WTAP = NB * PXB;                                 // bytes of one tap of the weight tile
+    static constexpr int HH = TH + KH - 1;
+    static constexpr int PITCH = (TW + KW - 1 + 7) / 8 * 8;               // (a multiple of 8 pixels = 256 B keeps the bank pattern of a row)
+    static constexpr int NPIX = KT * HH * PITCH;
+    static constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + NWAVE - 1) / NWAVE * NWAVE;    // 1 KiB wave-instructions per halo, a multiple of the waves
+    static constexpr int HALO_BYTES = HINSTR * 1024;
+    static constexpr int WG_BYTES = KW * WTAP;                            // one (dt, dh) group of 3 taps
+    static constexpr int NWB = HALO_BYTES + 3 * WG_BYTES <= 80 * 1024 ? 3 : 2;      // weight ring (two workgroups share the CU's 160 KiB)
+    static constexpr int EROW = NT * 64;                                  // bytes of one pixel's NB channels in the epilogue staging block
+    static constexpr int MAIN_BYTES = HALO_BYTES + NWB * WG_BYTES, EPI_BYTES = NWAVE * 32 * EROW;
+    static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+};
 }  // namespace halo
 
-template <int KT, int KH, int TH, int TW, int NT>
-__global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      // two workgroups per CU (<= 128 VGPRs)
+template <int KT, int KH, int TH, int TW, int NT, int MT>
+__global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p) {      // two workgroups per CU: 128 (MT = 1) / 256 (MT = 2) VGPRs
 #if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins exist only in the device pass; the host pass needs just the stub)
     using namespace halo;
     typedef bf16_t T;
-    constexpr int NB = NT * 32;                                    // output channels per workgroup
-    constexpr int WTAP = NB * PXB;                                 // bytes of one tap of the weight tile
-    constexpr int HH = TH + KH - 1;
-    constexpr int PITCH = (TW + KW - 1 + 15) / 16 * 16;
-    constexpr int NPIX = KT * HH * PITCH;
-    constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + 7) / 8 * 8;    // 1 KiB wave-instructions per halo, a multiple of the 8 waves
-    constexpr int HPW = HINSTR / 8;
-    constexpr int HALO_BYTES = HINSTR * 1024;
-    constexpr int WG_BYTES = KW * WTAP;                            // one (dt, dh) group of 3 taps
-    constexpr int WINSTR = WG_BYTES / 1024;                        // 9 / 12 / 18
-    constexpr int WPW = (WINSTR + 7) / 8;                          // weight DMA instructions per wave (upper bound)
+    using C = Cfg<KT, KH, TH, TW, NT, MT>;
+    constexpr int NWAVE = C::NWAVE, NB = C::NB, WTAP = C::WTAP, HH = C::HH, PITCH = C::PITCH, NPIX = C::NPIX, HINSTR = C::HINSTR;
+    constexpr int HALO_BYTES = C::HALO_BYTES, WG_BYTES = C::WG_BYTES, NWB = C::NWB, EROW = C::EROW;
+    constexpr int HPW = HINSTR / NWAVE;
+    constexpr int WINSTR = WG_BYTES / 1024;                        // 9 / 12
+    constexpr int WPW = (WINSTR + NWAVE - 1) / NWAVE;              // weight DMA instructions per wave (upper bound)
     constexpr int NG = KT * KH;
     static_assert(NG >= 2, "the halo reload assumes a weight group follows it");
     constexpr int ROWS_PER_MT = 32 / TW > 0 ? 32 / TW : 1;         // image rows covered by one 32-pixel MFMA tile (TW = 32: 1, TW = 16: 2)
     constexpr int ESW = NT % 2 == 0 ? 7 : 3;                       // epilogue swizzle mask: the XOR must stay inside the pixel's NT*4 chunks
-    constexpr int EROW = NT * 64;                                  // bytes of one pixel's NB channels in the epilogue staging block
     static_assert(TH * TW == 256 && (TW == 32 || TW == 16), "256 output pixels per workgroup");
     static_assert(NT == 3 || NT == 4, "two workgroups per CU: 128 VGPRs, <= 80 KiB of LDS (launch_halo sizes it for the epilogue blocks too)");
 
@@ -82,22 +94,23 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.x), (short)0, (int)((int64_t)p.Tin * p.Hin * p.Win * p.xs * 2), 0x00027000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
+    const int plane_bytes = p.Tin * p.Hin * p.Win * 32;     // planar-16 input: [Cin/16][Tin][Hin][Win][16]
     int hoff[HPW];
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
-        const int q = (i * 8 + wave) * 64 + lane;
+        const int q = (i * NWAVE + wave) * 64 + lane;
         const int px = q >> 1, physc = q & 1;
         const int fdt = px / (HH * PITCH), r = px % (HH * PITCH);
         const int hh = r / PITCH, ww = r % PITCH;
         const int c = physc ^ ((ww >> 3) & 1);
         const int ti = to + fdt, hi_ = h0 - 1 + hh, wi = w0 - 1 + ww;
         const bool ok = px < NPIX && ww < TW + KW - 1 && ti < p.Tin && hi_ >= 0 && hi_ < p.Hin && wi >= 0 && wi < p.Win;
-        hoff[i] = ok ? (int)((((int64_t)ti * p.Hin + hi_) * p.Win + wi) * p.xs * 2) + c * 16 : -1;
+        hoff[i] = ok ? (int)((((int64_t)ti * p.Hin + hi_) * p.Win + wi) * (p.xplanar ? 32 : p.xs * 2)) + c * 16 : -1;
     }
     int woff[WPW];          // (weights of one layer are far below 2 GiB)
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int q = (i * 8 + wave) * 64 + lane;                   // 16-byte slot inside the group: tap, row, physical chunk
+        const int q = (i * NWAVE + wave) * 64 + lane;                   // 16-byte slot inside the group: tap, row, physical chunk
         const int tig = q / (NB * 2), n = (q % (NB * 2)) >> 1, physc = q & 1;
         const int c = physc ^ ((n >> 3) & 1);
         const int64_t row = min(n0 + n, p.Cout - 1);
@@ -105,9 +118,10 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
     }
     auto issue_halo = [&](int ck0) {
         char* dst = conv_dyn_smem;
+        const int soff = p.xplanar ? (ck0 >> 4) * plane_bytes : ck0 * 2;
 #pragma unroll
         for (int i = 0; i < HPW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * 8 + wave) * 1024), 16, hoff[i], ck0 * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * NWAVE + wave) * 1024), 16, hoff[i], soff, 0, 0);
     };
     auto issue_w = [&](int buf, int ck0, int g) {
         if (M4D_ABL(p) & 4) return;
@@ -115,65 +129,92 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
         const int koff = (g * KW * p.Cin + ck0) * 2;
 #pragma unroll
         for (int i = 0; i < WPW; ++i)
-            if (i * 8 + wave < WINSTR)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDS_AS void*)(dst + (i * 8 + wave) * 1024), 16, woff[i], koff, 0, 0);
+            if (i * NWAVE + wave < WINSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (LDS_AS void*)(dst + (i * NWAVE + wave) * 1024), 16, woff[i], koff, 0, 0);
     };
 
     // ---- per-lane fragment addresses ----
     // MFMA "B" operand (activations): lane (li, hi) = pixel li of this wave's 32-pixel tile, 8 channels of chunk hi
-    unsigned abase[KW];
-    {
-        const int row = TW == 32 ? wave : wave * ROWS_PER_MT + li / TW;
+    unsigned abase[MT][KW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int mt = wave * MT + mi;
+        const int row = TW == 32 ? mt : mt * ROWS_PER_MT + li / TW;
         const int col = TW == 32 ? li : li % TW;
 #pragma unroll
         for (int dw = 0; dw < KW; ++dw) {
             const int cc = col + dw;
-            abase[dw] = (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
+            abase[mi][dw] = (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
         }
     }
     // MFMA "A" operand (weights): row n = ni*32 + li of the tap's [NB x 16] tile; further column tiles are +32 rows = +1024 bytes
     const unsigned wfrag = (unsigned)(li * PXB + ((hi ^ ((li >> 3) & 1)) << 4));
 
-    f32x16 acc[NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)conv_dyn_smem;
     const int nchunk = p.Cin / CK;
     const int total = nchunk * NG;
-    issue_w(0, 0, 0);
+    // weight groups stream through a ring of NWB buffers, requested NWB-1 steps ahead (one step = MT*NT*3 MFMAs per wave is shorter
+    // than an L2 round trip); jc/jg/jb = chunk, group and buffer of the next group to request
+    int jc = 0, jg = 0, jb = 0;
+    auto next_w = [&]() {
+        if (jc < nchunk) issue_w(jb, jc * CK, jg);
+        jb = jb + 1 == NWB ? 0 : jb + 1;
+        if (++jg == NG) { jg = 0; ++jc; }
+    };
+    const bool wfull = WINSTR % NWAVE == 0 || wave < WINSTR % NWAVE;       // this wave issues WPW (else WPW - 1) pieces per group
+    // wait until at most `n` of my weight groups are still in flight (everything older - halo pieces included - has landed)
+#define HL_WAIT_W(n)                                                                                             \
+    do {                                                                                                         \
+        if (wfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * WPW) : "memory");                              \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * (WPW - 1)) : "memory");                              \
+    } while (0)
+    next_w();
     issue_halo(0);
-    int s = 0;
+#pragma unroll
+    for (int d = 1; d < NWB - 1; ++d) next_w();
+    int s = 0, rb = 0;
 #pragma unroll 1
     for (int ci = 0; ci < nchunk; ++ci) {
 #pragma unroll 1
         for (int g = 0; g < NG; ++g, ++s) {       // (kept rolled: unrolled, hipcc hoists every fragment address and spills)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my share of weight group s (and of the halo at g == 0)
+            // my share of weight group s (and of the first halo): group s+1 may stay in flight (NWB = 3)
+            if (NWB == 2 || s + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else HL_WAIT_W(1);
             if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
             if (g == 0 && ci > 0) {
                 // every wave is done with the previous chunk's halo: overwrite it (the co-resident workgroup computes meanwhile)
                 if (!(M4D_ABL(p) & 8)) issue_halo(ci * CK);
-                if (s + 1 < total) issue_w((s + 1) & 1, (NG == 1 ? ci + 1 : ci) * CK, NG == 1 ? 0 : 1);
-                // the halo instructions are older than the weight ones: leave only the latter in flight (WPW or WPW - 1 of them, by wave)
-                if (WINSTR % 8 == 0 || wave < WINSTR % 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW - 1) : "memory");
+                const bool more = jc < nchunk;
+                next_w();
+                // the halo pieces are older than that weight group: leave only it in flight
+                if (more) HL_WAIT_W(1);
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
-            } else if (s + 1 < total) {
-                const int g1 = g + 1 == NG ? 0 : g + 1;
-                issue_w((s + 1) & 1, (g + 1 == NG ? ci + 1 : ci) * CK, g1);
+            } else {
+                next_w();
             }
             const int fdt = g / KH, dh = g % KH;
             const unsigned hb = lds_base + (unsigned)((fdt * HH + dh) * PITCH * PXB);
-            const unsigned wb = lds_base + HALO_BYTES + (s & 1) * WG_BYTES + wfrag;
-            // one pixel fragment feeds NT MFMAs; the fragments of tap dw+1 are requested before the MFMAs of tap dw (counted
-            // lgkmcnt): the LDS latency is exposed once per step, not once per tap
-            bf16x8 fa[2], fw[2][NT];
+            const unsigned wb = lds_base + HALO_BYTES + rb * WG_BYTES + wfrag;
+            rb = rb + 1 == NWB ? 0 : rb + 1;
+            // MT pixel fragments + NT weight fragments feed MT x NT MFMAs (LDS reads per MFMA: 1.33 at 1 x 3, 0.83 at 2 x 3, 0.75 at
+            // 2 x 4 - at one read per MFMA the LDS array is as busy as the MFMA pipe); the fragments of tap dw+1 are requested before
+            // the MFMAs of tap dw (counted lgkmcnt): the LDS latency is exposed once per step, not once per tap
+            bf16x8 fa[2][MT], fw[2][NT];
 #define HL_LD(buf, dw)                                                                                          \
             do {                                                                                                \
-                const unsigned a_ = hb + abase[dw];                                                             \
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fa[buf]) : "v"(a_));                                  \
+                _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                             \
+                    const unsigned a_ = hb + abase[mi][dw];                                                     \
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[buf][mi]) : "v"(a_));                          \
+                }                                                                                               \
                 _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) {                                             \
                     const unsigned w_ = wb + (dw) * WTAP + ni * 1024;                                           \
                     asm volatile("ds_read_b128 %0, %1" : "=v"(fw[buf][ni]) : "v"(w_));                          \
@@ -185,13 +226,15 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
                 if (!(M4D_ABL(p) & 2)) {
                     if (dw == 0) { HL_LD(1, 1); }
                     else if (dw == 1) { HL_LD(0, 2); }
-                    if (dw < KW - 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + 1) : "memory");
+                    if (dw < KW - 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + MT) : "memory");
                     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ni = 0; ni < NT; ++ni)
-                    if (!(M4D_ABL(p) & 1)) mma32(fw[dw & 1][ni], fa[dw & 1], acc[ni]);
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        if (!(M4D_ABL(p) & 1)) mma32(fw[dw & 1][ni], fa[dw & 1][mi], acc[mi][ni]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef HL_LD
@@ -206,25 +249,27 @@ __global__ __launch_bounds__(512, 4) void conv_halo_kernel(ConvArgs p) {      //
     if (M4D_ABL(p) & 32) return;                           // ablation: no epilogue
     char* blk = conv_dyn_smem + wave * (32 * EROW);        // [32 pixels][NB channels] bf16; chunk c of pixel px at c ^ (px & ESW)
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni)
+    for (int mi = 0; mi < MT; ++mi) {                      // (a wave's LDS operations execute in order: round mi+1 may overwrite the block)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int nl = ni * 32 + rq * 8 + hi * 4;              // channel inside the workgroup's NB
-            const int nb = n0 + nl;
-            f32x4 v;
+        for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[ni][rq * 4 + e];
-            if (bias && nb < p.Cout) v += load4(bias + nb);
-            bf16x4 o;
+            for (int rq = 0; rq < 4; ++rq) {
+                const int nl = ni * 32 + rq * 8 + hi * 4;              // channel inside the workgroup's NB
+                const int nb = n0 + nl;
+                f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-            const int ch = nl >> 3;
-            *reinterpret_cast<bf16x4*>(blk + li * EROW + ((ch ^ (li & ESW)) << 4) + (nl & 7) * 2) = o;
-        }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave reads back only its own block
-    {
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][rq * 4 + e];
+                if (bias && nb < p.Cout) v += load4(bias + nb);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                const int ch = nl >> 3;
+                *reinterpret_cast<bf16x4*>(blk + li * EROW + ((ch ^ (li & ESW)) << 4) + (nl & 7) * 2) = o;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave reads back only its own block
         constexpr int CPP = NT * 4;                        // 16-byte chunks per pixel
-        const int row0 = TW == 32 ? wave : wave * ROWS_PER_MT;
+        const int mt = wave * MT + mi;
+        const int row0 = TW == 32 ? mt : mt * ROWS_PER_MT;
 #pragma unroll
         for (int j = 0; j < (32 * CPP + 63) / 64; ++j) {
             const int q = j * 64 + lane;
