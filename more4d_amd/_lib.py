@@ -6,9 +6,9 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmore4d_hip.so")
-if os.environ.get("M4D_LIB") == "abl":      # tools/abl*.sh only: the -DM4D_ABLATIONS build (wrong results by design)
-    LIB_PATH = os.path.join(_HERE, "lib", "libmore4d_hip_abl.so")
-ABLATION_BUILD = LIB_PATH.endswith("_abl.so")
+if os.environ.get("M4D_LIB"):      # tools only: "abl" = the -DM4D_ABLATIONS build (wrong results by design), else a side build to A/B
+    LIB_PATH = os.path.join(_HERE, "lib", "libmore4d_hip_%s.so" % os.environ["M4D_LIB"])
+ABLATION_BUILD = bool(os.environ.get("M4D_LIB"))      # anything but the shipping library: bench.py refuses it
 
 M4D_F32, M4D_BF16 = 0, 1
 EPI_STORE, EPI_GELU_TANH, EPI_GELU_ERF, EPI_SILU, EPI_RESID_GATE, EPI_STORE_F32 = range(6)

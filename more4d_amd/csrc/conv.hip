@@ -393,9 +393,12 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
     return 0;
 }
 
-// output channels per workgroup = NT x 32: 96 / 192 / 384 -> 1 / 2 / 4 tiles of 96, everything else tiles of 128
+// output channels per workgroup = NT x 32: 96 / 192 / 384 -> 1 / 2 / 4 tiles of 96, <= 32 / <= 64 (the 3-channel heads) one tile of
+// 32 / 64, everything else tiles of 128
 template <int KT, int KH, int TH, int TW>
 int launch_halo_nt(ConvArgs& p, hipStream_t st) {
+    if (p.Cout <= 32) return launch_halo<KT, KH, TH, TW, 1, 2>(p, st);
+    if (p.Cout <= 64) return launch_halo<KT, KH, TH, TW, 2, 2>(p, st);
     return ((p.Cout + 31) / 32) % 3 == 0 ? launch_halo<KT, KH, TH, TW, 3, 2>(p, st) : launch_halo<KT, KH, TH, TW, 4, 2>(p, st);
 }
 
@@ -432,11 +435,12 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
     const int64_t xbytes = (int64_t)Tin * Hin * Win * x_pixel_stride * 2;
     M4D_ENV_ONCE(conv_variant, "M4D_CONV_VARIANT", 3);     // 3 LDS-halo kernel where it applies (default) | 2 DMA-gather implicit GEMM | 1 register-staged
-    const bool v2_shape = conv_variant >= 2 && dt == M4D_BF16 && st == 1 && sh == 1 && sw == 1 && !ups && !tsplit && kt <= 8 &&
-                          kh <= 8 && kw <= 8 && p.M >= 1024;
-    const bool halo_shape = conv_variant == 3 && v2_shape && kw == 3 && kh == 3 && (kt == 3 || kt == 1) && pad_t == 0 && pad_h == 1 &&
-                            pad_w == 1 && Ho == Hin && Wo == Win && To == Tin - kt + 1 && Cin % 16 == 0 && Cout >= 32 && Cout % 8 == 0 &&
-                            out_ld % 8 == 0 && (!resid || resid_ld % 8 == 0);
+    const bool v2_base = conv_variant >= 2 && dt == M4D_BF16 && st == 1 && sh == 1 && sw == 1 && kt <= 8 && kh <= 8 && kw <= 8 && p.M >= 1024;
+    const bool v2_shape = v2_base && !ups && !tsplit;
+    // the halo kernel also reads through the up-sampled / time-split views (its DMA addresses are per halo pixel anyway)
+    const bool halo_shape = conv_variant == 3 && v2_base && kw == 3 && kh == 3 && (kt == 3 || kt == 1) && pad_t == 0 && pad_h == 1 &&
+                            pad_w == 1 && Ho == (Hin << ups) && Wo == (Win << ups) && To == (Tin << tsplit) - kt + 1 && Cin % 16 == 0 &&
+                            (!tsplit || kt == 1);
     if (v2_shape && xbytes >= (1ll << 30) && kt == 1 && pad_t == 0 && To == Tin) {
         // 2-D convolution over many frames (the adaptors: 49 x 480 x 832 x 128): frames are independent, so launch groups of
         // frames whose input fits the kernel's 31-bit offsets

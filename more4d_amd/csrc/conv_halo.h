@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
     constexpr int ROWS_PER_MT = 32 / TW > 0 ? 32 / TW : 1;         // image rows covered by one 32-pixel MFMA tile (TW = 32: 1, TW = 16: 2)
     constexpr int ESW = NT % 2 == 0 ? 7 : 3;                       // epilogue swizzle mask: the XOR must stay inside the pixel's NT*4 chunks
     static_assert(TH * TW == 256 && (TW == 32 || TW == 16), "256 output pixels per workgroup");
-    static_assert(NT == 3 || NT == 4, "two workgroups per CU: 128 VGPRs, <= 80 KiB of LDS (launch_halo sizes it for the epilogue blocks too)");
+    static_assert(NT >= 1 && NT <= 4, "two workgroups per CU: <= 80 KiB of LDS (launch_halo sizes it for the epilogue blocks too)");
 
     const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
     const int nwg = p.tiles_m * p.tiles_n;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
     // for an offset past the end of the buffer (probed: tools/probes/buffer_lds_oob.hip), so halo pixels outside the image are
     // just offset -1: no zero page, no select, no 64-bit per-lane addresses ----
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.x), (short)0, (int)((int64_t)p.Tin * p.Hin * p.Win * p.xs * 2), 0x00027000);
+        const_cast<void*>(p.x), (short)0, (int)((int64_t)p.Tin * p.Hin * p.Win * p.xs * 2), 0x00027000);      // (physical extent)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
     const int plane_bytes = p.Tin * p.Hin * p.Win * 32;     // planar-16 input: [Cin/16][Tin][Hin][Win][16]
     int hoff[HPW];
@@ -103,9 +103,13 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
         const int fdt = px / (HH * PITCH), r = px % (HH * PITCH);
         const int hh = r / PITCH, ww = r % PITCH;
         const int c = physc ^ ((ww >> 3) & 1);
+        // logical coordinates: frame ti of Tin << tsplit (frame f = channels (f & 1) * Cin + [0, Cin) of physical frame f >> 1,
+        // wan_vae.py:138-141), pixel (hi_, wi) of the nearest-exact 2x up-sampled map when ups (:61-67)
         const int ti = to + fdt, hi_ = h0 - 1 + hh, wi = w0 - 1 + ww;
-        const bool ok = px < NPIX && ww < TW + KW - 1 && ti < p.Tin && hi_ >= 0 && hi_ < p.Hin && wi >= 0 && wi < p.Win;
-        hoff[i] = ok ? (int)((((int64_t)ti * p.Hin + hi_) * p.Win + wi) * (p.xplanar ? 32 : p.xs * 2)) + c * 16 : -1;
+        const bool ok = px < NPIX && ww < TW + KW - 1 && ti < (p.Tin << p.tsplit) && hi_ >= 0 && hi_ < (p.Hin << p.ups) && wi >= 0 &&
+                        wi < (p.Win << p.ups);
+        const int64_t pix = ((int64_t)(ti >> p.tsplit) * p.Hin + (hi_ >> p.ups)) * p.Win + (wi >> p.ups);
+        hoff[i] = ok ? (int)(pix * (p.xplanar ? 32 : p.xs * 2)) + (p.tsplit ? (ti & 1) * p.Cin * 2 : 0) + c * 16 : -1;
     }
     int woff[WPW];          // (weights of one layer are far below 2 GiB)
 #pragma unroll
@@ -282,16 +286,26 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
             uint4 raw = *reinterpret_cast<const uint4*>(blk + pl * EROW + ((ch ^ (pl & ESW)) << 4));
             if (ho >= p.Ho || wo >= p.Wo || nb >= p.Cout) continue;
             const int64_t m = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
+            const bool wide = nb + 8 <= p.Cout && ((p.ldo | (resid ? p.ldr : 0)) & 7) == 0;      // else 4-channel halves (Cout % 4 == 0)
             if (resid) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(resid + m * p.ldr + nb);
+                bf16_t rr[8] = {};
+                if (wide) *reinterpret_cast<uint4*>(rr) = *reinterpret_cast<const uint4*>(resid + m * p.ldr + nb);
+                else {
+                    *reinterpret_cast<uint2*>(rr) = *reinterpret_cast<const uint2*>(resid + m * p.ldr + nb);
+                    if (nb + 8 <= p.Cout) *reinterpret_cast<uint2*>(rr + 4) = *reinterpret_cast<const uint2*>(resid + m * p.ldr + nb + 4);
+                }
                 const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw);
-                const bf16_t* b = reinterpret_cast<const bf16_t*>(&rr);
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)b[e]);        // conv output is T, then x + h (:224)
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)rr[e]);        // conv output is T, then x + h (:224)
                 raw = *reinterpret_cast<const uint4*>(&o);
             }
-            *reinterpret_cast<uint4*>((T*)p.out + m * p.ldo + nb) = raw;          // (Cout % 8 == 0 on this path)
+            T* dst = (T*)p.out + m * p.ldo + nb;
+            if (wide) *reinterpret_cast<uint4*>(dst) = raw;
+            else {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(raw.x, raw.y);
+                if (nb + 8 <= p.Cout) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(raw.z, raw.w);
+            }
         }
     }
 #endif

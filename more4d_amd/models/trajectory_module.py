@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .wan_vae import CIN_PAD, _round
 
 
 def zero_module(module):
@@ -62,7 +63,7 @@ class _AdaptorBase(nn.Module):
         if hit is None or hit[0] != key:
             w = conv.weight.detach()
             co, ci, kh, kw = w.shape
-            cip, cop = (ci + 7) // 8 * 8, (co + 3) // 4 * 4
+            cip, cop = _round(ci, CIN_PAD), _round(co, 4)
             wp = torch.zeros((cop, kh, kw, cip), device=w.device, dtype=T)
             wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
             bp = torch.zeros(cop, device=w.device, dtype=T)
@@ -140,8 +141,8 @@ class VAEEncoderadaptor(_AdaptorBase):
         C, F, H, W = x.shape
         T, dev = self.dtype, self.device
         xb = x.to(device=dev, dtype=T).contiguous()
-        h = ops.ncthw_to_cl(xb, T, Cp=8).view(F * H * W, 8)
-        h, _ = self._conv(h, self.conv_in, F, H, W, 8)
+        h = ops.ncthw_to_cl(xb, T, Cp=CIN_PAD).view(F * H * W, CIN_PAD)
+        h, _ = self._conv(h, self.conv_in, F, H, W, CIN_PAD)
         for blk in self.down[0].block:
             h = self._resnet(h, blk, F, H, W)
         h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
@@ -188,8 +189,8 @@ class VAEDecoderadaptor(_AdaptorBase):
         C, F, H, W = z.shape
         T, dev = self.dtype, self.device
         zb = z.to(device=dev, dtype=T).contiguous()
-        h = ops.ncthw_to_cl(zb, T, Cp=8).view(F * H * W, 8)
-        h, _ = self._conv(h, self.conv_in, F, H, W, 8)
+        h = ops.ncthw_to_cl(zb, T, Cp=CIN_PAD).view(F * H * W, CIN_PAD)
+        h, _ = self._conv(h, self.conv_in, F, H, W, CIN_PAD)
         for blk in self.up[0].block:
             h = self._resnet(h, blk, F, H, W)
         h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)

@@ -152,6 +152,9 @@ class AutoencoderKLWan_(nn.Module):
 
 # --------------------------------------------------------------------------------------------- runner
 
+CIN_PAD = 16     # input channels of every conv are padded to one MFMA K step (the 3-channel video / 3-channel adaptor inputs)
+
+
 def _round(n, m):
     return (n + m - 1) // m * m
 
@@ -198,7 +201,7 @@ class _Runner:
         self.vae, self.dev, self.T = vae, device, dtype
         self.stages = {}
         self.flags = {}
-        self.cin_pad = 8
+        self.cin_pad = CIN_PAD
 
     # ---- parameter views in kernel layout (cached on the owning AutoencoderKLWan)
     def packed(self, conv):

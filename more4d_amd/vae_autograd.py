@@ -23,7 +23,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import ops
-from .models.wan_vae import _Act, _Runner, _Stage, _round
+from .models.wan_vae import CIN_PAD, _Act, _Runner, _Stage, _round
 
 
 # ------------------------------------------------------------------------------------------------ conv gradients
@@ -561,8 +561,8 @@ class AdaptorFn(Function):
             n = f1 - f0
             xb = x[:, f0:f1].to(dev, T).contiguous()
             tp = _AdaptorTape(mod, grads, n, H, W)
-            x0 = _Act(ops.ncthw_to_cl(xb, T, Cp=8).view(n * H * W, 8), n, H, W, 8)
-            h = tp.conv(x0, mod.conv_in, 8)
+            x0 = _Act(ops.ncthw_to_cl(xb, T, Cp=CIN_PAD).view(n * H * W, CIN_PAD), n, H, W, CIN_PAD)
+            h = tp.conv(x0, mod.conv_in, CIN_PAD)
             for blk in blocks:
                 h = tp.resnet(h, blk)
             h = tp.conv(tp.gn_swish(h, mod.norm_out), mod.conv_out, mod.ch)

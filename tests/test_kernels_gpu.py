@@ -365,7 +365,10 @@ def test_attention_phased_kernel_segments_and_rescale():
 
 
 @pytest.mark.parametrize("cin,cout,k,pad", [(96, 96, (3, 3, 3), (0, 1, 1)), (192, 384, (3, 3, 3), (0, 1, 1)),
-                                            (384, 384, (1, 1, 1), (0, 0, 0)), (128, 128, (1, 3, 3), (0, 1, 1))])
+                                            (384, 384, (1, 1, 1), (0, 0, 0)), (128, 128, (1, 3, 3), (0, 1, 1)),
+                                            (96, 4, (3, 3, 3), (0, 1, 1)), (16, 96, (3, 3, 3), (0, 1, 1)),      # the VAE's head / conv1
+                                            (128, 4, (1, 3, 3), (0, 1, 1)), (16, 128, (1, 3, 3), (0, 1, 1)),   # the adaptors' conv_out / conv_in
+                                            (48, 64, (3, 3, 3), (0, 1, 1)), (32, 20, (1, 3, 3), (0, 1, 1))])
 def test_conv_cl_production_kernel(cin, cout, k, pad):
     """conv_cl256_kernel (bf16, unit stride, M >= 1024: DMA gather with a zero page for the padding taps) against fp32 torch
     on bf16-rounded operands: borders in H and W, the causal 2-frame tail in T, K not a multiple of 64, Cout not of 128."""
@@ -385,6 +388,28 @@ def test_conv_cl_production_kernel(cin, cout, k, pad):
     out2 = o.conv_cl(x.to(DEV), wp.to(DEV), b.to(DEV), Tin=Tin, Hin=H, Win=W, Cin=cin, k=k, pad=pad, out_thw=(To, H, W),
                      resid=res.to(DEV))
     assert rel_err(out2.float().cpu(), ref.bfloat16().float() + res.float()) < BF16_TOL
+
+
+@pytest.mark.parametrize("tsplit", [False, True])
+@pytest.mark.parametrize("cin,cout", [(192, 96), (384, 192), (32, 40)])
+def test_conv_cl_production_kernel_upsampled(cin, cout, tsplit):
+    """The Resample up-sampling conv (wan_vae.py:61-67, 81-90, 138-141) on conv_halo_kernel: the conv reads a nearest-exact 2x view
+    of x (ups) and, after the time_conv of upsample3d, frame f from channels (f & 1) * Cin of physical frame f >> 1 (tsplit)."""
+    import torch.nn.functional as F
+    o = ops()
+    T, H, W = 3, 12, 20
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T, H, W, cin * (2 if tsplit else 1), generator=g).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (cin * 9) ** -0.5).bfloat16()
+    b = torch.randn(cout, generator=g).bfloat16()
+    frames = x.float().view(T, H, W, 2, cin).permute(0, 3, 1, 2, 4).reshape(2 * T, H, W, cin) if tsplit else x.float()
+    up = F.interpolate(frames.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest-exact")
+    ref = F.conv2d(up, w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = o.conv_cl(x.to(DEV), wp.to(DEV), b.to(DEV), Tin=T, Hin=H, Win=W, Cin=cin, k=(1, 3, 3), pad=(0, 1, 1),
+                    out_thw=(T * (2 if tsplit else 1), 2 * H, 2 * W), ups=True, tsplit=tsplit,
+                    x_pixel_stride=cin * (2 if tsplit else 1))
+    assert rel_err(out.float().cpu(), ref) < BF16_TOL
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

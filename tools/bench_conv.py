@@ -31,13 +31,18 @@ def main():
         b = torch.zeros(co, device=dev, dtype=torch.bfloat16)
         kw = dict(Tin=Tin, Hin=H, Win=W, Cin=ci, k=(kt, 3, 3), pad=(0, 1, 1), out_thw=(t, H, W))
         out = ops.conv_cl(x, w, b, **kw)
-        torch.cuda.synchronize()
-        n = 5
-        t0 = time.perf_counter()
-        for _ in range(n):
+        # steady state: the first ~15 launches after an idle gap ride a clock transient (tools/bench_conv_cold.py), so warm up
+        # with 40 launches and report the median of 30 launches timed one by one
+        for _ in range(40):
             ops.conv_cl(x, w, b, out=out, **kw)
+        n = 30
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            ops.conv_cl(x, w, b, out=out, **kw)
+            ev[i + 1].record()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        dt = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))[n // 2] * 1e-3
         fl = 2.0 * t * H * W * co * kt * 9 * ci
         print(f"{name:36s} {dt*1e6:9.1f} us  {fl/dt/1e12:7.1f} TF/s  ({fl/dt/1e12/25:.1f} % of 2.5 PF)", flush=True)
 
