@@ -140,6 +140,7 @@ class _TrainRunner(_Runner):
 
     def __init__(self, vae, device, dtype, grads, snap=None):
         super().__init__(vae, device, dtype)
+        self.ring = 1                  # (no streaming inside a recomputed chunk: every chunk starts from its own snapshot)
         self.tape = []
         self.grads = grads
         self.video_grad = None       # gradient of the encoder's input chunk (channels-last), set by video_into's backward
@@ -191,7 +192,8 @@ class _TrainRunner(_Runner):
         kt, kh, kw = k
         st = self.stage(key, kt - 1, t, h, w, cip)
         fill(st.chunk(t))
-        y = ops.conv_cl(st.buf, wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=k, pad=(0, kh // 2, kw // 2),
+        xin = st.window(t)
+        y = ops.conv_cl(xin, wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=k, pad=(0, kh // 2, kw // 2),
                         out_thw=(t, h, w), resid=None if resid is None else resid.data, out=out)
         ya = _Act(y, t, h, w, cop)                         # (no roll: the tails of the NEXT chunk come from its own snapshot)
         self.last_act = ya
@@ -203,7 +205,7 @@ class _TrainRunner(_Runner):
             dy = dy.contiguous()
             if resid is not None:
                 _acc(resid, dy.clone())
-            self._conv_grads(conv, st.buf, cip, st.n_tail + t, h, w, cip, dy, k, (kh // 2, kw // 2), wgt, cop)
+            self._conv_grads(conv, xin, cip, st.n_tail + t, h, w, cip, dy, k, (kh // 2, kw // 2), wgt, cop)
             fill.bwd(conv_dgrad(dy, wgt, cop, cip, k, t, h, w))
         self.tape.append(bwd)
         return ya
@@ -318,7 +320,7 @@ class _TrainRunner(_Runner):
             st = self.stage(key + ".time_conv", 1, x.t, ho, wo, cop)
             mid = self.conv_plain(x, conv, stride_hw=2, out=st.chunk(x.t))
             to = x.t // 2
-            y = ops.conv_cl(st.buf, wgt, b, Tin=1 + x.t, Hin=ho, Win=wo, Cin=cop, k=(3, 1, 1), stride=(2, 1, 1), out_thw=(to, ho, wo))
+            y = ops.conv_cl(st.window(x.t), wgt, b, Tin=1 + x.t, Hin=ho, Win=wo, Cin=cop, k=(3, 1, 1), stride=(2, 1, 1), out_thw=(to, ho, wo))
             ya = _Act(y, to, ho, wo, cop)
 
             def bwd():
