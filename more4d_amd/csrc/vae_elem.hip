@@ -95,94 +95,135 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(RmsClArgs p) {
 
 // ------------------------------------------------------------------ GroupNorm (+swish), channels-last, two deterministic passes
 struct GnArgs {
-    const void* x; void* out; float* partial; const float* weight; const float* bias;
+    const void* x; void* out; float* partial; float* stat; const float* weight; const float* bias;
     int64_t HW;
     int F, C, G, nblk, ppb, silu; float eps;
 };
 
-// pass 1: partial[f][blk][g] = (sum, sumsq) over this block's pixels; thread t owns channel vector t % NV (4 channels)
-template <typename T>
+// A thread owns VEC = 16 bytes of channels of a pixel (8 bf16 / 4 float; 4 when C % 8 != 0) = VEC/4 sub-vectors of 4 channels, each
+// inside one group (channels per group % 4 == 0).  16-byte accesses, 8 of them in flight per thread.
+template <typename T, int VEC> struct GnVec;
+template <typename T> struct GnVec<T, 4> {
+    f32x4 h[1];
+    M4D_DEV void load(const T* p) { h[0] = load4(p); }
+    M4D_DEV void store(T* p) const { store4(p, h[0]); }
+};
+template <> struct GnVec<bf16_t, 8> {
+    f32x4 h[2];
+    M4D_DEV void load(const bf16_t* p) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e >> 2][e & 3] = (float)v[e];
+    }
+    M4D_DEV void store(bf16_t* p) const {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)h[e >> 2][e & 3];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+
+// pass 1: partial[f][blk][g] = (sum, sumsq) over this block's pixels
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(GnArgs p) {
-    __shared__ float red[256][2];
-    const int NV = p.C >> 2, slots = 256 / NV;
+    constexpr int NH = VEC / 4;
+    __shared__ float red[256 * NH][2];
+    const int NV = p.C / VEC, slots = 256 / NV;
     const int t = threadIdx.x, v = t % NV, slot = t / NV;
     const int f = blockIdx.y, blk = blockIdx.x;
     const int64_t p0 = (int64_t)blk * p.ppb, p1 = min(p0 + p.ppb, p.HW);
-    const T* xf = (const T*)p.x + (int64_t)f * p.HW * p.C;
-    float s = 0.f, q = 0.f;
-    // (8 independent loads in flight per thread: one 8-byte load at a time left the kernel latency-bound at 1.7 TB/s)
+    const T* xf = (const T*)p.x + (int64_t)f * p.HW * p.C + v * VEC;
+    float s[NH] = {}, q[NH] = {};
+    auto add = [&](const GnVec<T, VEC>& u) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[h] += u.h[h][e]; q[h] += u.h[h][e] * u.h[h][e]; }
+    };
     if (slot < slots) {
         int64_t px = p0 + slot;
         for (; px + 7 * slots < p1; px += 8 * slots) {
-            f32x4 u[8];
+            GnVec<T, VEC> u[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = load4(xf + (px + j * slots) * p.C + v * 4);
+            for (int j = 0; j < 8; ++j) u[j].load(xf + (px + j * slots) * p.C);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s += u[j][e]; q += u[j][e] * u[j][e]; }
+            for (int j = 0; j < 8; ++j) add(u[j]);
         }
-        for (; px < p1; px += slots) {
-            const f32x4 u = load4(xf + px * p.C + v * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { s += u[e]; q += u[e] * u[e]; }
-        }
+        for (; px < p1; px += slots) { GnVec<T, VEC> u; u.load(xf + px * p.C); add(u); }
     }
-    red[t][0] = s; red[t][1] = q;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { red[t * NH + h][0] = s[h]; red[t * NH + h][1] = q[h]; }
     __syncthreads();
-    const int cpg = p.C / p.G, vpg = cpg >> 2;      // channel vectors per group
+    const int vpg = p.C / p.G / 4;                  // 4-channel sub-vectors per group; sub-vector i of slot sl = red[(sl * NV) * NH + i]
     if (t < p.G) {
         float ss = 0.f, qq = 0.f;
         for (int j = 0; j < vpg; ++j)
-            for (int sl = 0; sl < slots; ++sl) { ss += red[sl * NV + t * vpg + j][0]; qq += red[sl * NV + t * vpg + j][1]; }
+            for (int sl = 0; sl < slots; ++sl) { ss += red[sl * NV * NH + t * vpg + j][0]; qq += red[sl * NV * NH + t * vpg + j][1]; }
         float* dst = p.partial + (((int64_t)f * p.nblk + blk) * p.G + t) * 2;
         dst[0] = ss; dst[1] = qq;
     }
 }
 
-// pass 2: reduce the partials of this frame (fixed order), normalise + affine (+ x*sigmoid(x))
-template <typename T>
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnArgs p) {
-    __shared__ float mean[64], rstd[64];
-    const int t = threadIdx.x, f = blockIdx.y, blk = blockIdx.x;
-    const int cpg = p.C / p.G;
+// pass 2 (one small workgroup per frame): stat[f][g] = (mean, rstd) from the partials in a fixed order (the apply kernel's workgroups
+// each used to re-reduce all nblk partials with one dependent load after the other: ~0.4 ms per workgroup at 195 partials)
+__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(GnArgs p, int cpg) {
+    __shared__ float red[256][2];
+    const int f = blockIdx.x, t = threadIdx.x, g = t % p.G, lane = t / p.G, nl = 256 / p.G;
+    float ss = 0.f, qq = 0.f;
+    const float* src = p.partial + ((int64_t)f * p.nblk * p.G + g) * 2;
+    if (lane < nl)
+        for (int b = lane; b < p.nblk; b += nl) { ss += src[(int64_t)b * p.G * 2]; qq += src[(int64_t)b * p.G * 2 + 1]; }
+    red[t][0] = ss; red[t][1] = qq;
+    __syncthreads();
     if (t < p.G) {
-        float ss = 0.f, qq = 0.f;
-        const float* src = p.partial + ((int64_t)f * p.nblk * p.G + t) * 2;
-        for (int b = 0; b < p.nblk; ++b) { ss += src[(int64_t)b * p.G * 2]; qq += src[(int64_t)b * p.G * 2 + 1]; }
+        ss = 0.f; qq = 0.f;
+        for (int l = 0; l < nl; ++l) { ss += red[l * p.G + t][0]; qq += red[l * p.G + t][1]; }
         const float n = (float)p.HW * cpg;
         const float m = ss / n;
-        mean[t] = m;
-        rstd[t] = rsqrtf(fmaxf(qq / n - m * m, 0.f) + p.eps);
+        p.stat[((int64_t)f * p.G + t) * 2] = m;
+        p.stat[((int64_t)f * p.G + t) * 2 + 1] = rsqrtf(fmaxf(qq / n - m * m, 0.f) + p.eps);
     }
-    __syncthreads();
-    const int NV = p.C >> 2, slots = 256 / NV;
+}
+
+// pass 3: normalise + affine (+ x*sigmoid(x))
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnArgs p) {
+    constexpr int NH = VEC / 4;
+    const int t = threadIdx.x, f = blockIdx.y, blk = blockIdx.x;
+    const int cpg = p.C / p.G;
+    const int NV = p.C / VEC, slots = 256 / NV;
     const int v = t % NV, slot = t / NV;
     if (slot >= slots) return;
-    const int g = (v * 4) / cpg;
-    const float m = mean[g], r = rstd[g];
-    const f32x4 w = load4(p.weight + v * 4), bb = load4(p.bias + v * 4);
-    const int64_t p0 = (int64_t)blk * p.ppb, p1 = min(p0 + p.ppb, p.HW);
-    const T* xf = (const T*)p.x + (int64_t)f * p.HW * p.C;
-    T* of = (T*)p.out + (int64_t)f * p.HW * p.C;
-    auto apply = [&](f32x4 u) {
+    float m[NH], r[NH];
+    f32x4 w[NH], bb[NH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float y = (u[e] - m) * r * w[e] + bb[e];
-            if (p.silu) { y = round_through<T>(y); y = y / (1.f + __expf(-y)); }
-            u[e] = y;
-        }
-        return u;
+    for (int h = 0; h < NH; ++h) {
+        const int c0 = v * VEC + h * 4, g = c0 / cpg;
+        m[h] = p.stat[((int64_t)f * p.G + g) * 2]; r[h] = p.stat[((int64_t)f * p.G + g) * 2 + 1];
+        w[h] = load4(p.weight + c0); bb[h] = load4(p.bias + c0);
+    }
+    const int64_t p0 = (int64_t)blk * p.ppb, p1 = min(p0 + p.ppb, p.HW);
+    const T* xf = (const T*)p.x + (int64_t)f * p.HW * p.C + v * VEC;
+    T* of = (T*)p.out + (int64_t)f * p.HW * p.C + v * VEC;
+    auto apply = [&](GnVec<T, VEC>& u) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = (u.h[h][e] - m[h]) * r[h] * w[h][e] + bb[h][e];
+                if (p.silu) { y = round_through<T>(y); y = y / (1.f + __expf(-y)); }
+                u.h[h][e] = y;
+            }
     };
     int64_t px = p0 + slot;
     for (; px + 7 * slots < p1; px += 8 * slots) {       // 8 loads in flight per thread (x and out may be the same buffer: load all first)
-        f32x4 u[8];
+        GnVec<T, VEC> u[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = load4(xf + (px + j * slots) * p.C + v * 4);
+        for (int j = 0; j < 8; ++j) u[j].load(xf + (px + j * slots) * p.C);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) store4(of + (px + j * slots) * p.C + v * 4, apply(u[j]));
+        for (int j = 0; j < 8; ++j) { apply(u[j]); u[j].store(of + (px + j * slots) * p.C); }
     }
-    for (; px < p1; px += slots) store4(of + px * p.C + v * 4, apply(load4(xf + px * p.C + v * 4)));
+    for (; px < p1; px += slots) { GnVec<T, VEC> u; u.load(xf + px * p.C); apply(u); u.store(of + px * p.C); }
 }
 
 // ------------------------------------------------------------------ row softmax (VAE mid attention scores)
@@ -273,6 +314,8 @@ extern "C" int m4d_rmsnorm_silu_cl(m4d_dtype dt, const void* x, int64_t x_ld, co
     return 0;
 }
 
+constexpr int GN_PPB = 512;        // pixels per workgroup of the stats / apply passes
+
 extern "C" int m4d_groupnorm_cl(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats,
                                 const float* weight, const float* bias, int F, int64_t HW, int C, int G, float eps, int silu,
                                 m4d_stream stream) {
@@ -280,25 +323,31 @@ extern "C" int m4d_groupnorm_cl(m4d_dtype dt, const void* x, void* out, float* p
     M4D_CHECK_ARG(x && out && partial && weight && bias && F > 0 && HW > 0, "groupnorm_cl: null/empty");
     M4D_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "groupnorm_cl: C=%d unsupported (C/4 must divide 256)", C);
     M4D_CHECK_ARG(G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0, "groupnorm_cl: channels per group must be a multiple of 4");
-    const int ppb = 2048;
-    const int nblk = (int)((HW + ppb - 1) / ppb);
-    M4D_CHECK_ARG(partial_floats >= (int64_t)F * nblk * G * 2, "groupnorm_cl: workspace too small (need %lld floats)", (long long)F * nblk * G * 2);
-    GnArgs p{x, out, partial, weight, bias, HW, F, C, G, nblk, ppb, silu, eps};
+    const int nblk = (int)((HW + GN_PPB - 1) / GN_PPB);
+    M4D_CHECK_ARG(partial_floats >= m4d_groupnorm_cl_workspace(F, HW, G), "groupnorm_cl: workspace too small (need %lld floats)",
+                  (long long)m4d_groupnorm_cl_workspace(F, HW, G));
+    GnArgs p{x, out, partial, partial + (int64_t)F * nblk * G * 2, weight, bias, HW, F, C, G, nblk, GN_PPB, silu, eps};
     dim3 grid(nblk, F), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dt == M4D_BF16) {
-        hipLaunchKernelGGL(groupnorm_stats_kernel<bf16_t>, grid, block, 0, st, p);
-        hipLaunchKernelGGL(groupnorm_apply_kernel<bf16_t>, grid, block, 0, st, p);
+    if (dt == M4D_BF16 && C % 8 == 0) {
+        hipLaunchKernelGGL((groupnorm_stats_kernel<bf16_t, 8>), grid, block, 0, st, p);
+        hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(F), block, 0, st, p, C / G);
+        hipLaunchKernelGGL((groupnorm_apply_kernel<bf16_t, 8>), grid, block, 0, st, p);
+    } else if (dt == M4D_BF16) {
+        hipLaunchKernelGGL((groupnorm_stats_kernel<bf16_t, 4>), grid, block, 0, st, p);
+        hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(F), block, 0, st, p, C / G);
+        hipLaunchKernelGGL((groupnorm_apply_kernel<bf16_t, 4>), grid, block, 0, st, p);
     } else {
-        hipLaunchKernelGGL(groupnorm_stats_kernel<float>, grid, block, 0, st, p);
-        hipLaunchKernelGGL(groupnorm_apply_kernel<float>, grid, block, 0, st, p);
+        hipLaunchKernelGGL((groupnorm_stats_kernel<float, 4>), grid, block, 0, st, p);
+        hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(F), block, 0, st, p, C / G);
+        hipLaunchKernelGGL((groupnorm_apply_kernel<float, 4>), grid, block, 0, st, p);
     }
     M4D_CHECK_LAUNCH("groupnorm_cl");
     return 0;
 }
 
-extern "C" int64_t m4d_groupnorm_cl_workspace(int F, int64_t HW, int G) {
-    return (int64_t)F * ((HW + 2047) / 2048) * G * 2;
+extern "C" int64_t m4d_groupnorm_cl_workspace(int F, int64_t HW, int G) {      // per-workgroup partial sums + the per-frame (mean, rstd)
+    return (int64_t)F * ((HW + GN_PPB - 1) / GN_PPB) * G * 2 + (int64_t)F * G * 2;
 }
 
 extern "C" int m4d_softmax_rows(m4d_dtype in_dt, const void* x, int64_t ldx, m4d_dtype out_dt, void* out, int64_t ldo,

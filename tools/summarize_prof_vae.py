@@ -17,15 +17,18 @@ for line in open(os.path.join(src, "trace.log")):
     if line.startswith("{"):
         open(f"profiles/{tag}_vae_bench_under_rocprof.json", "w").write(line)
 
-KEYS = ("conv_halo_kernel<3, 3, 8, 32>", "conv_halo_kernel<3, 3, 16, 16>", "conv_halo_kernel<1, 3, 8, 32>", "conv_halo_kernel<1, 3, 16, 16>",
-        "conv_cl256_kernel", "conv_cl_kernel", "rmsnorm_silu_cl_kernel", "groupnorm_apply_kernel", "groupnorm_stats_kernel")
+import re
+
+FIXED = ("conv_cl256_kernel", "conv_cl_kernel", "rmsnorm_silu_cl_kernel", "groupnorm_apply_kernel", "groupnorm_stats_kernel")
+KEYS = []
 
 
 def short(n):
-    for k in KEYS:
-        if k in n:
-            return k
-    return None
+    m_ = re.search(r"conv_halo_kernel<[^>]*>", n)           # every instantiation (KT, KH, TH, TW, NT, MT) on its own row
+    k = m_.group(0) if m_ else next((k for k in FIXED if k in n), None)
+    if k and k not in KEYS:
+        KEYS.append(k)
+    return k
 
 
 def agg(d):
@@ -47,7 +50,7 @@ f, nf = agg("pmc_fetch")
 w, nw = agg("pmc_write")
 lines = [f"# {tag}: VAE PMC summary (tools/bench_vae.py 17 480 832, one rocprofv3 pass per counter group)", "",
          "| kernel | launches | MFMA busy / SIMD-cycles | FETCH_SIZE MiB/launch (x2-corrected) | WRITE_SIZE MiB/launch |", "|---|---|---|---|---|"]
-for k in KEYS:
+for k in sorted(KEYS, key=lambda k_: (not k_.startswith("conv_halo"), k_)):
     if k not in m:
         continue
     gui = m[k]["GRBM_GUI_ACTIVE"] / 8.0
