@@ -399,6 +399,11 @@ template <int KT, int KH, int TH, int TW>
 int launch_halo_nt(ConvArgs& p, hipStream_t st) {
     if (p.Cout <= 32) return launch_halo<KT, KH, TH, TW, 1, 2>(p, st);
     if (p.Cout <= 64) return launch_halo<KT, KH, TH, TW, 2, 2>(p, st);
+    // small maps (60 x 104 x 1 frame x 384 channels = 112 workgroups of 96 channels on 512 slots): narrower channel tiles, 3x the
+    // workgroups; the extra halo copies come out of L2 (the whole input is 5 MB)
+    const int64_t patches = (int64_t)p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
+    M4D_ENV_ONCE(small, "M4D_CONV_SMALL", 1);
+    if (small && p.Cout % 32 == 0 && patches * ((p.Cout + 95) / 96) <= 256) return launch_halo<KT, KH, TH, TW, 1, 2>(p, st);
     return ((p.Cout + 31) / 32) % 3 == 0 ? launch_halo<KT, KH, TH, TW, 3, 2>(p, st) : launch_halo<KT, KH, TH, TW, 4, 2>(p, st);
 }
 

@@ -370,11 +370,22 @@ def test_attention_phased_kernel_segments_and_rescale():
                                             (128, 4, (1, 3, 3), (0, 1, 1)), (16, 128, (1, 3, 3), (0, 1, 1)),   # the adaptors' conv_out / conv_in
                                             (48, 64, (3, 3, 3), (0, 1, 1)), (32, 20, (1, 3, 3), (0, 1, 1))])
 def test_conv_cl_production_kernel(cin, cout, k, pad):
+    _conv_cl_production_case(cin, cout, k, pad, 4, 20, 24)
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,thw", [(96, 96, (3, 3, 3), (0, 1, 1), (4, 128, 160)),      # 8 x 32 patches, 3 column tiles per wave
+                                                (128, 128, (1, 3, 3), (0, 1, 1), (4, 128, 160)),   # 4 column tiles (the adaptors)
+                                                (48, 192, (3, 3, 3), (0, 1, 1), (3, 120, 104))])   # 16 x 16 patches (narrow maps)
+def test_conv_cl_production_kernel_large_maps(cin, cout, k, pad, thw):
+    """Maps with more than 256 patches: the 96 / 128-channel tiles of conv_halo_kernel (smaller maps take 32-channel tiles)."""
+    _conv_cl_production_case(cin, cout, k, pad, *thw)
+
+
+def _conv_cl_production_case(cin, cout, k, pad, To, H, W):
     """conv_cl256_kernel (bf16, unit stride, M >= 1024: DMA gather with a zero page for the padding taps) against fp32 torch
     on bf16-rounded operands: borders in H and W, the causal 2-frame tail in T, K not a multiple of 64, Cout not of 128."""
     import torch.nn.functional as F
     o = ops()
-    To, H, W = 4, 20, 24
     Tin = To + k[0] - 1
     g = torch.Generator().manual_seed(0)
     x = torch.randn(Tin, H, W, cin, generator=g).bfloat16()
