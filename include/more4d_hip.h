@@ -170,10 +170,22 @@ int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void*
                 int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h, int pad_w, int To,
                 int Ho, int Wo, int ups, int tsplit, m4d_stream stream);
 
+/* The same convolution for the stride-1 3x3(x3) layers (kh = kw = 3, pad (0,1,1), To = Tin - kt + 1, bf16) with x in PLANAR-16
+ * layout: [Cin/16][rows][16], `x_plane_stride` elements between channel planes, row = (t*Hin + h)*Win + w.  That is the layout
+ * m4d_rmsnorm_silu_cl_planar writes into a causal conv's [tail + chunk] staging buffer (wan_vae.py:199-224: norm -> SiLU -> conv):
+ * a halo pixel's 16-channel piece sits next to its row neighbours', so the kernel's halo DMA uses every byte of the lines it
+ * fetches (channels-last: 32 bytes of each Cin*2-byte pixel per pass).  Input extent < 2 GiB. */
+int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                       int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
+                       m4d_stream stream);
+
 /* RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:43-58) fused with the following SiLU
  * (:199-201, :319, :424).  x/out: T [P, C] with row strides; gamma float [C]. */
 int m4d_rmsnorm_silu_cl(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_ld,
                         int64_t P, int C, int silu, m4d_stream stream);
+/* ... with the result in planar-16 layout: out[(c / 16) * out_plane_stride + row * 16 + c % 16], rows [0, P) (bf16, C % 16 == 0). */
+int m4d_rmsnorm_silu_cl_planar(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_plane_stride,
+                               int64_t P, int C, int silu, m4d_stream stream);
 
 /* GroupNorm(G groups, eps) + affine (+ x*sigmoid(x)) per frame on [F, HW, C] (trajectory_module.py:54-60): two
  * deterministic passes; `partial` is a float workspace of m4d_groupnorm_cl_workspace(F, HW, G) elements. */

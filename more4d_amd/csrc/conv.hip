@@ -31,7 +31,7 @@ struct ConvArgs {
     int64_t M, K;
     int tiles_m, tiles_n;
     int abl;               // timing ablations (tool builds only)
-    int xplanar;           // input is planar-16: [Cin/16][Tin][Hin][Win][16] (conv_halo_kernel only)
+    int64_t xplane;        // != 0: input is planar-16, [Cin/16][rows][16] with xplane elements between planes (conv_halo_kernel only)
 };
 
 constexpr int ROWB = 128, BM = 128, BN = 128;
@@ -432,10 +432,10 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
     p.M = (int64_t)To * Ho * Wo;
     p.K = (int64_t)kt * kh * kw * Cin;
-    p.abl = 0; p.xplanar = 0;
+    p.abl = 0; p.xplane = 0;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0); p.abl = conv_abl; }
-    { M4D_ENV_ONCE(conv_planar, "M4D_CONV_PLANAR", 0); p.xplanar = conv_planar; }     // timing experiment: same bytes read as planar-16
+    { M4D_ENV_ONCE(conv_planar, "M4D_CONV_PLANAR", 0); if (conv_planar) p.xplane = (int64_t)Tin * Hin * Win * 16; }     // timing experiment: same bytes read as planar-16
 #endif
     // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
     const int64_t xbytes = (int64_t)Tin * Hin * Win * x_pixel_stride * 2;
@@ -493,5 +493,37 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     if (dt == M4D_BF16) hipLaunchKernelGGL(conv_cl_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv_cl_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
     M4D_CHECK_LAUNCH("conv_cl");
+    return 0;
+}
+
+/* m4d_conv_cl for the 3x3(x3), stride-1, pad-(0,1,1) case with the input in planar-16 layout (what m4d_rmsnorm_silu_cl_planar writes
+ * into a causal conv's staging buffer): a halo pixel's 16-channel piece is 32 contiguous bytes next to its row neighbours' instead
+ * of 32 bytes out of a Cin*2-byte pixel, so the halo DMA fetches whole lines it uses (fabric traffic / 4 at Cin = 96). */
+extern "C" int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                                  int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
+                                  m4d_stream stream) {
+    M4D_CHECK_ARG(dt == M4D_BF16, "conv_cl_planar: bf16 only");
+    M4D_CHECK_ARG(x && w && out && Tin > 0 && Hin > 0 && Win > 0 && Cout > 0 && To > 0, "conv_cl_planar: null/empty");
+    M4D_CHECK_ARG((kt == 3 || kt == 1) && To == Tin - kt + 1, "conv_cl_planar: kt=%d To=%d Tin=%d", kt, To, Tin);
+    M4D_CHECK_ARG(Cin % 16 == 0 && Cout % 4 == 0, "conv_cl_planar: Cin %% 16, Cout %% 4");
+    M4D_CHECK_ARG(x_plane_stride >= (int64_t)Tin * Hin * Win * 16 && x_plane_stride % 8 == 0, "conv_cl_planar: plane stride too small");
+    M4D_CHECK_ARG((int64_t)(Cin / 16) * x_plane_stride * 2 < (1ll << 31), "conv_cl_planar: input extent must stay below 2 GiB");
+    M4D_CHECK_ARG(out_ld % 4 == 0 && out_ld >= Cout && (!resid || (resid_ld % 4 == 0 && resid_ld >= Cout)), "conv_cl_planar: bad out/resid stride");
+    M4D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0, "conv_cl_planar: pointers must be 16-byte aligned");
+    ConvArgs p;
+    p.x = x; p.w = w; p.bias = bias; p.resid = resid; p.out = out;
+    p.xs = Cin; p.ldo = out_ld; p.ldr = resid_ld;
+    p.Tin = Tin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout;
+    p.kt = kt; p.kh = 3; p.kw = 3; p.st = p.sh = p.sw = 1; p.pad_t = 0; p.pad_h = p.pad_w = 1;
+    p.To = To; p.Ho = Hin; p.Wo = Win; p.ups = 0; p.tsplit = 0;
+    p.M = (int64_t)To * Hin * Win;
+    p.K = (int64_t)kt * 9 * Cin;
+    p.abl = 0; p.xplane = x_plane_stride;
+    const bool wide = (Win % 32 == 0) || Win >= 256;
+    int rc;
+    if (kt == 3) rc = wide ? launch_halo_nt<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<3, 3, 16, 16>(p, (hipStream_t)stream);
+    else rc = wide ? launch_halo_nt<1, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<1, 3, 16, 16>(p, (hipStream_t)stream);
+    if (rc) return rc;
+    M4D_CHECK_LAUNCH("conv_cl_planar");
     return 0;
 }

@@ -92,9 +92,11 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
     // for an offset past the end of the buffer (probed: tools/probes/buffer_lds_oob.hip), so halo pixels outside the image are
     // just offset -1: no zero page, no select, no 64-bit per-lane addresses ----
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.x), (short)0, (int)((int64_t)p.Tin * p.Hin * p.Win * p.xs * 2), 0x00027000);      // (physical extent)
+        const_cast<void*>(p.x), (short)0,
+        (int)(p.xplane ? (int64_t)(p.Cin / 16 - 1) * p.xplane * 2 + (int64_t)p.Tin * p.Hin * p.Win * 32 : (int64_t)p.Tin * p.Hin * p.Win * p.xs * 2),
+        0x00027000);                                       // (physical extent, < 2 GiB)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
-    const int plane_bytes = p.Tin * p.Hin * p.Win * 32;     // planar-16 input: [Cin/16][Tin][Hin][Win][16]
+    const int plane_bytes = (int)(p.xplane * 2);            // planar-16 input: [Cin/16][rows >= Tin*Hin*Win][16], p.xplane elements between planes
     int hoff[HPW];
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
         const bool ok = px < NPIX && ww < TW + KW - 1 && ti < (p.Tin << p.tsplit) && hi_ >= 0 && hi_ < (p.Hin << p.ups) && wi >= 0 &&
                         wi < (p.Win << p.ups);
         const int64_t pix = ((int64_t)(ti >> p.tsplit) * p.Hin + (hi_ >> p.ups)) * p.Win + (wi >> p.ups);
-        hoff[i] = ok ? (int)(pix * (p.xplanar ? 32 : p.xs * 2)) + (p.tsplit ? (ti & 1) * p.Cin * 2 : 0) + c * 16 : -1;
+        hoff[i] = ok ? (int)(pix * (p.xplane ? 32 : p.xs * 2)) + (p.tsplit ? (ti & 1) * p.Cin * 2 : 0) + c * 16 : -1;
     }
     int woff[WPW];          // (weights of one layer are far below 2 GiB)
 #pragma unroll
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
     }
     auto issue_halo = [&](int ck0) {
         char* dst = conv_dyn_smem;
-        const int soff = p.xplanar ? (ck0 >> 4) * plane_bytes : ck0 * 2;
+        const int soff = p.xplane ? (ck0 >> 4) * plane_bytes : ck0 * 2;
 #pragma unroll
         for (int i = 0; i < HPW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * NWAVE + wave) * 1024), 16, hoff[i], soff, 0, 0);

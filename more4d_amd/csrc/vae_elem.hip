@@ -46,6 +46,7 @@ struct RmsClArgs {
     const void* x; void* out; const float* gamma;
     int64_t P, x_ld, out_ld;
     int C, silu;
+    int64_t out_plane;      // != 0: planar-16 output [C/16][rows][16] with `out_plane` elements between planes (bf16; conv_halo_kernel's input)
 };
 
 template <typename T, int SW, int VPL>
@@ -88,7 +89,10 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(RmsClArgs p) {
                     y[e + j] = u;
                 }
             }
-            stv<T, EPV>(orow + cv * EPV, y);
+            // planar-16: this lane's 8 channels are half (cv & 1) of pixel `pix` in plane cv >> 1; the 4 pixels of a wave make one
+            // 128-byte line per plane
+            if (p.out_plane) stv<T, EPV>((T*)p.out + (int64_t)(cv >> 1) * p.out_plane + pix * 16 + (cv & 1) * 8, y);
+            else stv<T, EPV>(orow + cv * EPV, y);
         }
     }
 }
@@ -292,6 +296,9 @@ __global__ __launch_bounds__(256) void cl_to_ncthw_kernel(LayoutArgs p) {
 
 }  // namespace
 
+static int rmsnorm_silu_launch(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_ld, int64_t out_plane,
+                               int64_t P, int C, int silu, m4d_stream stream);
+
 extern "C" int m4d_rmsnorm_silu_cl(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_ld,
                                    int64_t P, int C, int silu, m4d_stream stream) {
     M4D_CHECK_ARG(x && gamma && out && P > 0, "rmsnorm_silu_cl: null/empty");
@@ -299,7 +306,22 @@ extern "C" int m4d_rmsnorm_silu_cl(m4d_dtype dt, const void* x, int64_t x_ld, co
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "rmsnorm_silu_cl: bad dtype");
     M4D_CHECK_ARG(C % epv == 0 && C / epv <= 128, "rmsnorm_silu_cl: C=%d must be a multiple of %d and <= %d", C, epv, 128 * epv);
     M4D_CHECK_ARG(x_ld % epv == 0 && out_ld % epv == 0 && x_ld >= C && out_ld >= C, "rmsnorm_silu_cl: bad row strides");
-    RmsClArgs p{x, out, gamma, P, x_ld, out_ld, C, silu};
+    return rmsnorm_silu_launch(dt, x, x_ld, gamma, out, out_ld, 0, P, C, silu, stream);
+}
+
+extern "C" int m4d_rmsnorm_silu_cl_planar(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_plane_stride,
+                                          int64_t P, int C, int silu, m4d_stream stream) {
+    M4D_CHECK_ARG(x && gamma && out && P > 0, "rmsnorm_silu_cl_planar: null/empty");
+    M4D_CHECK_ARG(dt == M4D_BF16 && C % 16 == 0 && C <= 1024 && x_ld % 8 == 0 && x_ld >= C, "rmsnorm_silu_cl_planar: bf16, C a multiple of 16");
+    M4D_CHECK_ARG(out_plane_stride >= P * 16 && out_plane_stride % 8 == 0, "rmsnorm_silu_cl_planar: plane stride %lld too small for %lld rows",
+                  (long long)out_plane_stride, (long long)P);
+    return rmsnorm_silu_launch(dt, x, x_ld, gamma, out, C, out_plane_stride, P, C, silu, stream);
+}
+
+static int rmsnorm_silu_launch(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_ld, int64_t out_plane,
+                               int64_t P, int C, int silu, m4d_stream stream) {
+    const int epv = dt == M4D_BF16 ? 8 : 4;
+    RmsClArgs p{x, out, gamma, P, x_ld, out_ld, C, silu, out_plane};
     const int nvec = C / epv;
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256);

@@ -177,45 +177,61 @@ class _Stage:
 
     With ring > 1 the buffer holds `ring` chunks: the next chunk is written right behind the current one, whose last n_tail frames
     then ARE the tail in place; only when the end of the buffer is reached are they copied back to the front (one small copy per
-    `ring` chunks instead of one per chunk: 1 233 copy kernels = 19 ms of a 49x480x832 round trip at ring = 1)."""
+    `ring` chunks instead of one per chunk: 1 233 copy kernels = 19 ms of a 49x480x832 round trip at ring = 1).
 
-    def __init__(self, n_tail, t, h, w, c, dtype, device, ring=1):
+    planar: the buffer is [C/16, frames, h*w, 16] (ops.Planar16) instead of [frames, h*w, C]: what the RMS-norm kernel writes for the
+    LDS-halo conv kernel, whose halo DMA then uses every byte of the lines it fetches."""
+
+    def __init__(self, n_tail, t, h, w, c, dtype, device, ring=1, planar=False):
         self.n_tail, self.h, self.w, self.c = n_tail, h, w, c
-        self.cap, self.ring, self.pos = t, ring, 0
-        self.buf = torch.zeros((n_tail + ring * t, h * w, c), device=device, dtype=dtype)
+        self.cap, self.ring, self.pos, self.planar = t, ring, 0, planar
+        self.buf = self._alloc(n_tail + ring * t, dtype, device)
+
+    def _alloc(self, frames, dtype, device):
+        shape = (self.c // 16, frames, self.h * self.w, 16) if self.planar else (frames, self.h * self.w, self.c)
+        return torch.zeros(shape, device=device, dtype=dtype)
+
+    def _frames(self, a, n):
+        return self.buf.narrow(1 if self.planar else 0, a, n)
 
     def chunk(self, t):
-        if t > self.cap or self.pos + self.n_tail + t > self.buf.shape[0]:
+        """Where the next chunk of t frames goes: a [t*h*w, C] view, or an ops.Planar16 of a planar stage."""
+        total = self.buf.shape[1 if self.planar else 0]
+        if t > self.cap or self.pos + self.n_tail + t > total:
             tail = self.tail()
             if t > self.cap:   # grow, keeping the tail
-                nb = torch.zeros((self.n_tail + self.ring * t, self.h * self.w, self.c), device=self.buf.device, dtype=self.buf.dtype)
-                nb[:self.n_tail] = tail
-                self.buf, self.cap = nb, t
+                old = tail.clone()
+                self.cap = t
+                self.buf = self._alloc(self.n_tail + self.ring * t, self.buf.dtype, self.buf.device)
+                self._frames(0, self.n_tail).copy_(old)
             else:              # wrap around
-                self.buf[:self.n_tail].copy_(tail.clone() if self.pos < self.n_tail else tail)
+                self._frames(0, self.n_tail).copy_(tail.clone() if self.pos < self.n_tail else tail)
             self.pos = 0
-        a = self.pos + self.n_tail
-        return self.buf[a:a + t].view(t * self.h * self.w, self.c)
+        v = self._frames(self.pos + self.n_tail, t)
+        return ops.Planar16(v) if self.planar else v.view(t * self.h * self.w, self.c)
 
     def window(self, t):
         """[tail + chunk of t frames]: the conv's input."""
-        return self.buf[self.pos:self.pos + self.n_tail + t]
+        v = self._frames(self.pos, self.n_tail + t)
+        return ops.Planar16(v) if self.planar else v
 
     def tail(self):
-        return self.buf[self.pos:self.pos + self.n_tail]
+        return self._frames(self.pos, self.n_tail)
 
     def roll(self, t):
         """tail <- last n_tail frames of (tail + chunk of t frames)."""
         if self.ring > 1:
             self.pos += t
             return
-        src = self.buf[t:t + self.n_tail]
-        self.buf[:self.n_tail].copy_(src.clone() if t < self.n_tail else src)
+        src = self._frames(t, self.n_tail)
+        self._frames(0, self.n_tail).copy_(src.clone() if t < self.n_tail else src)
 
 
 class _Runner:
     """Executes the encoder / decoder module trees with the HIP kernels.  One instance per encode()/decode() call
     (fresh streaming state = the reference's clear_cache(), wan_vae.py:717-724)."""
+
+    PLANAR, PLANAR_MIN_PIXELS, PLANAR_DTYPES = True, 1024, (torch.bfloat16,)     # (class attributes so that tests can force either path)
 
     def __init__(self, vae, device, dtype):
         self.vae, self.dev, self.T = vae, device, dtype
@@ -223,6 +239,7 @@ class _Runner:
         self.flags = {}
         self.cin_pad = CIN_PAD
         self.ring = 4                  # chunks per staging buffer (_Stage)
+        self.planar = self.PLANAR      # norm -> 3x3x3 conv staging buffers in planar-16 layout (bf16, maps of >= 1024 pixels)
 
     # ---- parameter views in kernel layout (cached on the owning AutoencoderKLWan)
     def packed(self, conv):
@@ -254,10 +271,10 @@ class _Runner:
             cache[id(norm)] = hit
         return hit[1]
 
-    def stage(self, key, n_tail, t, h, w, c):
+    def stage(self, key, n_tail, t, h, w, c, planar=False):
         st = self.stages.get(key)
         if st is None:
-            st = _Stage(n_tail, t, h, w, c, self.T, self.dev, ring=self.ring)
+            st = _Stage(n_tail, t, h, w, c, self.T, self.dev, ring=self.ring, planar=planar)
             self.stages[key] = st
         return st
 
@@ -280,10 +297,17 @@ class _Runner:
     def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None):
         """k=3 causal conv with a 2-frame tail.  `fill(dst)` writes the chunk [t*h*w, Cin] into the staging buffer."""
         wgt, b, (kt, kh, kw), cip, cop = self.packed(conv)
-        st = self.stage(key, kt - 1, t, h, w, cip)
+        # planar-16 staging where the producer can write it (RMS-norm) and the LDS-halo kernel reads it (the decision is per stage:
+        # it must not depend on the chunk length)
+        planar = (self.planar and getattr(fill, "planar_ok", False) and self.T in self.PLANAR_DTYPES and (kt, kh, kw) == (3, 3, 3)
+                  and cip % 16 == 0 and h * w >= self.PLANAR_MIN_PIXELS)
+        st = self.stage(key, kt - 1, t, h, w, cip, planar=planar)
         fill(st.chunk(t))
-        y = ops.conv_cl(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=(kt, kh, kw), pad=(0, kh // 2, kw // 2),
-                        out_thw=(t, h, w), resid=_data(resid), out=out)
+        if st.planar:
+            y = ops.conv_cl_planar(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, kt=kt, resid=_data(resid), out=out)
+        else:
+            y = ops.conv_cl(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=(kt, kh, kw), pad=(0, kh // 2, kw // 2),
+                            out_thw=(t, h, w), resid=_data(resid), out=out)
         st.roll(t)
         return _Act(y, t, h, w, cop)
 
@@ -291,7 +315,13 @@ class _Runner:
     # how to take the gradient of that chunk back to where it came from)
     def norm_into(self, x: _Act, norm, silu=True):
         g = self.gamma(norm)
-        return lambda dst: ops.rmsnorm_silu_cl(x.data, g, silu=silu, out=dst)
+
+        def fill(dst):
+            if isinstance(dst, ops.Planar16):
+                return ops.rmsnorm_silu_cl_planar(x.data, g, dst, silu=silu)
+            return ops.rmsnorm_silu_cl(x.data, g, silu=silu, out=dst)
+        fill.planar_ok = True
+        return fill
 
     def copy_into(self, x: _Act):
         return lambda dst: dst.copy_(x.data)
@@ -307,14 +337,16 @@ class _Runner:
     def snapshot(self):
         """The streaming state in front of the next chunk: every conv's tail frames and the first-chunk flags (what the
         reference's `_clone_cache`, wan_vae.py:604-613, captures for the checkpointed twins)."""
-        return ({k: (st.n_tail, st.h, st.w, st.c, st.tail().clone()) for k, st in self.stages.items()}, dict(self.flags))
+        return ({k: (st.n_tail, st.h, st.w, st.c, st.planar, st.tail().clone()) for k, st in self.stages.items()}, dict(self.flags))
 
     def restore(self, snap):
         tails, flags = snap
         self.stages = {}
-        for k, (n_tail, h, w, c, tail) in tails.items():
-            st = _Stage(n_tail, 1, h, w, c, self.T, self.dev, ring=self.ring)
-            st.buf[:n_tail].copy_(tail)
+        for k, (n_tail, h, w, c, planar, tail) in tails.items():
+            st = _Stage(n_tail, 1, h, w, c, self.T, self.dev, ring=self.ring, planar=planar and self.planar)
+            if planar and not st.planar:         # a channels-last runner (training recompute) restoring a planar snapshot
+                tail = tail.permute(1, 2, 0, 3).reshape(n_tail, h * w, c)
+            st.tail().copy_(tail)
             self.stages[k] = st
         self.flags = dict(flags)
 

@@ -376,6 +376,65 @@ def conv_cl(x, w, bias, *, Tin, Hin, Win, Cin, k, stride=(1, 1, 1), pad=(0, 0, 0
     return out
 
 
+class Planar16:
+    """A bf16 activation in planar-16 layout: `t` is a [C/16, frames, h*w, 16] view (dims 1.. contiguous) whose dim-0 stride is the
+    plane stride — what rmsnorm_silu_cl_planar writes and conv_cl_planar reads (a causal conv's staging buffer)."""
+
+    def __init__(self, t):
+        if t.dim() != 4 or t.shape[3] != 16 or t.stride(3) != 1 or t.stride(2) != 16 or t.stride(1) != t.shape[2] * 16:
+            raise ValueError(f"Planar16: bad view {tuple(t.shape)} / {t.stride()}")
+        self.t = t
+
+    @property
+    def plane_stride(self):
+        return self.t.stride(0)
+
+    @property
+    def rows(self):
+        return self.t.shape[1] * self.t.shape[2]
+
+    @property
+    def channels(self):
+        return self.t.shape[0] * 16
+
+
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None):
+    """3x3(x3) stride-1 conv (pad (0,1,1), valid in T) of a Planar16 input; w / bias / resid / out as conv_cl."""
+    _dev(x.t, w, bias, resid, out)
+    Cin, Cout = x.channels, w.shape[0]
+    if x.t.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.rows != Tin * Hin * Win or w.shape[1] != kt * 9 * Cin:
+        raise ValueError("conv_cl_planar: bf16, rows == Tin*Hin*Win, w [Cout, kt*9*Cin]")
+    To = Tin - kt + 1
+    M = To * Hin * Win
+    if out is None:
+        out = torch.empty((M, Cout), device=w.device, dtype=w.dtype)
+    om, ldo = _rows2d(out)
+    if om != M or out.shape[-1] != Cout:
+        raise ValueError(f"conv_cl_planar: out {tuple(out.shape)} vs M={M} Cout={Cout}")
+    ldr = 0
+    if resid is not None:
+        rm, ldr = _rows2d(resid)
+        if rm != M or resid.shape[-1] != Cout:
+            raise ValueError("conv_cl_planar: resid shape mismatch")
+    check(_lib.load().m4d_conv_cl_planar(dt_code(w.dtype), _ptr(x.t), x.plane_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
+                                         Tin, Hin, Win, Cin, Cout, kt, To, _stream()), "m4d_conv_cl_planar")
+    return out
+
+
+def rmsnorm_silu_cl_planar(x, gamma, out, *, silu=True):
+    """rmsnorm_silu_cl with the result written into the Planar16 view `out` (rows == x's rows)."""
+    _dev(x, gamma, out.t)
+    P, ldx = _rows2d(x)
+    C = x.shape[-1]
+    if x.dtype != torch.bfloat16 or out.t.dtype != torch.bfloat16 or out.rows != P or out.channels != C:
+        raise ValueError("rmsnorm_silu_cl_planar: bf16, matching rows / channels")
+    if gamma.dtype != torch.float32 or gamma.numel() != C:
+        raise TypeError("rmsnorm_silu_cl_planar: gamma must be float32 [C]")
+    check(_lib.load().m4d_rmsnorm_silu_cl_planar(dt_code(x.dtype), _ptr(x), ldx, _ptr(gamma), _ptr(out.t), out.plane_stride, P, C, int(silu),
+                                                 _stream()), "m4d_rmsnorm_silu_cl_planar")
+    return out
+
+
 def rmsnorm_silu_cl(x, gamma, *, silu=True, out=None):
     """x [P, C] (row-strided) -> RMS_norm(x) (* SiLU) in x.dtype."""
     _dev(x, gamma, out)

@@ -141,6 +141,7 @@ class _TrainRunner(_Runner):
     def __init__(self, vae, device, dtype, grads, snap=None):
         super().__init__(vae, device, dtype)
         self.ring = 1                  # (no streaming inside a recomputed chunk: every chunk starts from its own snapshot)
+        self.planar = False            # (the weight-gradient kernels read the staging buffers channels-last)
         self.tape = []
         self.grads = grads
         self.video_grad = None       # gradient of the encoder's input chunk (channels-last), set by video_into's backward

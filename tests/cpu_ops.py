@@ -265,6 +265,27 @@ def rmsnorm_silu_cl(x, gamma, *, silu=True, out=None):
     return out
 
 
+def _planar_to_cl(x):
+    """Planar16 view [C/16, frames, hw, 16] -> channels-last [frames*hw, C]."""
+    c16, fr, hw, _ = x.t.shape
+    return x.t.permute(1, 2, 0, 3).reshape(fr * hw, c16 * 16)
+
+
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None):
+    return conv_cl(_planar_to_cl(x).contiguous(), w, bias, Tin=Tin, Hin=Hin, Win=Win, Cin=x.channels, k=(kt, 3, 3), pad=(0, 1, 1),
+                   out_thw=(Tin - kt + 1, Hin, Win), resid=resid, out=out)
+
+
+def rmsnorm_silu_cl_planar(x, gamma, out, *, silu=True):
+    y = rmsnorm_silu_cl(x, gamma, silu=silu)
+    c16, fr, hw, _ = out.t.shape
+    out.t.copy_(y.view(fr, hw, c16, 16).permute(2, 0, 1, 3))
+    return out
+
+
+NAMES += ["conv_cl_planar", "rmsnorm_silu_cl_planar"]
+
+
 def groupnorm_cl(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, out=None):
     C = x.shape[-1]
     y = torch.nn.functional.group_norm(x.float().view(F, HW, C).permute(0, 2, 1), groups, weight, bias, eps)

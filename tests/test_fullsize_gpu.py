@@ -169,6 +169,16 @@ def test_vae_full_size_causality():
         dec_part = vae.decode(full[:, :, :3].contiguous()).sample
     assert dec_full.shape == (1, 3, 17, 480, 832) and torch.equal(dec_part, dec_full[:, :, :9])
     assert bool(torch.isfinite(dec_full.float()).all()) and float(dec_full.float().abs().max()) <= 1.0
+    # the planar-16 staging layout (default for these maps) is only a layout: channels-last staging gives the same bits
+    from more4d_amd.models import wan_vae
+    was = wan_vae._Runner.PLANAR
+    wan_vae._Runner.PLANAR = False
+    try:
+        with torch.no_grad():
+            assert torch.equal(vae.encode(x)[0].mode(), full)
+            assert torch.equal(vae.decode(full).sample, dec_full)
+    finally:
+        wan_vae._Runner.PLANAR = was
 
 
 def test_attention_backward_full_length_sampled():

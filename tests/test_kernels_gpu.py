@@ -401,6 +401,31 @@ def _conv_cl_production_case(cin, cout, k, pad, To, H, W):
     assert rel_err(out2.float().cpu(), ref.bfloat16().float() + res.float()) < BF16_TOL
 
 
+@pytest.mark.parametrize("cin,cout,kt,thw", [(96, 96, 3, (4, 128, 160)), (96, 4, 3, (2, 40, 64)), (384, 384, 3, (2, 60, 104)),
+                                             (128, 128, 1, (3, 64, 96))])
+def test_planar16_norm_and_conv_equal_channels_last(cin, cout, kt, thw):
+    """m4d_rmsnorm_silu_cl_planar + m4d_conv_cl_planar (the norm -> conv staging path of the VAE) against the channels-last pair:
+    the same arithmetic on another layout, so bit-identical; the planar buffer is a window of a larger ring with a plane stride."""
+    o = ops()
+    To, H, W = thw
+    Tin = To + kt - 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(Tin * H * W, cin, generator=g).bfloat16().to(DEV)
+    gamma = (1 + 0.1 * torch.randn(cin, generator=g)).to(DEV)
+    w = (torch.randn(cout, kt * 9 * cin, generator=g) * (kt * 9 * cin) ** -0.5).bfloat16().to(DEV)
+    b = torch.randn(cout, generator=g).bfloat16().to(DEV)
+    res = torch.randn(To * H * W, cout, generator=g).bfloat16().to(DEV)
+    xn = o.rmsnorm_silu_cl(x, gamma, silu=True)
+    ref = o.conv_cl(xn, w, b, Tin=Tin, Hin=H, Win=W, Cin=cin, k=(kt, 3, 3), pad=(0, 1, 1), out_thw=(To, H, W), resid=res)
+    ring = torch.full((cin // 16, Tin + 5, H * W, 16), float("nan"), dtype=torch.bfloat16, device=DEV)
+    win = o.Planar16(ring[:, 3:3 + Tin])
+    o.rmsnorm_silu_cl_planar(x, gamma, win, silu=True)
+    assert torch.equal(win.t.permute(1, 2, 0, 3).reshape(Tin * H * W, cin), xn)
+    assert torch.isnan(ring[:, :3].float()).all() and torch.isnan(ring[:, 3 + Tin:].float()).all()
+    out = o.conv_cl_planar(win, w, b, Tin=Tin, Hin=H, Win=W, kt=kt, resid=res)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("tsplit", [False, True])
 @pytest.mark.parametrize("cin,cout", [(192, 96), (384, 192), (32, 40)])
 def test_conv_cl_production_kernel_upsampled(cin, cout, tsplit):

@@ -35,6 +35,41 @@ def test_vae_roundtrip_host_logic(monkeypatch):
         assert rel_err(dec, z["dec"]) < 1e-4
 
 
+def test_vae_planar_staging_host_logic(monkeypatch):
+    """The planar-16 staging buffers (RMS-norm writes [C/16, frames, h*w, 16], the LDS-halo conv reads it; 4-chunk ring with wrap-around
+    and growth, tails handed over in place) forced on at the fixture's tiny maps: same round trip as the reference."""
+    from more4d_amd.models import wan_vae
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    cpu_ops.install(monkeypatch)
+    monkeypatch.setattr(wan_vae._Runner, "PLANAR_MIN_PIXELS", 0)
+    monkeypatch.setattr(wan_vae._Runner, "PLANAR_DTYPES", (torch.float32, torch.bfloat16))
+    planar_stages = []
+    orig = wan_vae._Stage.__init__
+
+    def spy(self, *a, **kw):
+        orig(self, *a, **kw)
+        planar_stages.append(self.planar)
+    monkeypatch.setattr(wan_vae._Stage, "__init__", spy)
+    z = load_npz("vae_roundtrip.npz")
+    vae = AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(load_keys("vae_keys.json"), 2024))
+    with torch.no_grad():
+        assert rel_err(vae._encode(z["x"]), z["enc"]) < 1e-4
+        assert rel_err(vae.decode(z["enc"][:, :16]).sample, z["dec"]) < 1e-4
+    assert sum(planar_stages) > 20 and not all(planar_stages)      # residual-block convs planar, conv1 / time_conv stages not
+    # the ring itself: tails stay in place, wrap-around copies them to the front, growth keeps them
+    st = wan_vae._Stage(2, 2, 2, 2, 32, torch.float32, "cpu", ring=2, planar=True)
+    frames = []
+    for i, t in enumerate([1, 2, 2, 1, 4, 2]):
+        c = torch.arange(t * 4 * 32, dtype=torch.float32).view(t, 4, 32) + 1000 * i
+        st.chunk(t).t.copy_(c.view(t, 4, 2, 16).permute(2, 0, 1, 3))
+        frames += list(c)
+        win = st.window(t).t.permute(1, 2, 0, 3).reshape(2 + t, 4, 32)
+        want = torch.stack(([torch.zeros(4, 32)] * 2 + frames)[-(2 + t):])
+        assert torch.equal(win, want), i
+        st.roll(t)
+
+
 def test_adaptors_host_logic(monkeypatch):
     from more4d_amd.models.trajectory_module import VAEDecoderadaptor, VAEEncoderadaptor
     cpu_ops.install(monkeypatch)
