@@ -178,6 +178,13 @@ int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void*
 int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
                        int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
                        m4d_stream stream);
+/* ... with the NEXT layer's RMS_norm (+SiLU) fused into the epilogue (a ResidualBlock's conv -> norm -> SiLU -> conv, wan_vae.py:199-224):
+ * norm_out (planar-16, rows [0, To*Hin*Win)) = rmsnorm_silu(conv result (+resid)) with `norm_gamma` float [Cout]; `out` may be NULL
+ * when nobody reads the un-normalised result.  Cout in {32, 64, 96, 128} (one workgroup owns all channels of a pixel); results are
+ * bit-identical to m4d_conv_cl_planar followed by m4d_rmsnorm_silu_cl_planar. */
+int m4d_conv_cl_planar_norm(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                            int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
+                            const float* norm_gamma, void* norm_out, int64_t norm_out_plane_stride, int silu, m4d_stream stream);
 
 /* RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:43-58) fused with the following SiLU
  * (:199-201, :319, :424).  x/out: T [P, C] with row strides; gamma float [C]. */

@@ -105,6 +105,8 @@ SIGNATURES = {
     "m4d_rmsnorm_silu_cl_planar": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "m4d_conv_cl_planar": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
                            [c_int] * 7 + [c_void_p]),
+    "m4d_conv_cl_planar_norm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
+                                [c_int] * 7 + [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "m4d_groupnorm_cl_workspace": (c_int64, [c_int, c_int64, c_int]),
     "m4d_groupnorm_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int,
                                  c_int, c_float, c_int, c_void_p]),

@@ -32,6 +32,7 @@ struct ConvArgs {
     int tiles_m, tiles_n;
     int abl;               // timing ablations (tool builds only)
     int64_t xplane;        // != 0: input is planar-16, [Cin/16][rows][16] with xplane elements between planes (conv_halo_kernel only)
+    const float* post_gamma; void* post_out; int64_t post_plane; int post_silu;      // fused RMS_norm(+SiLU) of the next layer (conv_halo.h)
 };
 
 constexpr int ROWB = 128, BM = 128, BN = 128;
@@ -397,6 +398,15 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
 // 32 / 64, everything else tiles of 128
 template <int KT, int KH, int TH, int TW>
 int launch_halo_nt(ConvArgs& p, hipStream_t st) {
+    if (p.post_out) {        // fused next-layer norm: one workgroup must own all channels of a pixel
+        switch (p.Cout) {
+            case 32: return launch_halo<KT, KH, TH, TW, 1, 2>(p, st);
+            case 64: return launch_halo<KT, KH, TH, TW, 2, 2>(p, st);
+            case 96: return launch_halo<KT, KH, TH, TW, 3, 2>(p, st);
+            case 128: return launch_halo<KT, KH, TH, TW, 4, 2>(p, st);
+            default: m4d_set_error("conv_cl_planar_norm: Cout must be 32, 64, 96 or 128 (got %d)", p.Cout); return -1;
+        }
+    }
     if (p.Cout <= 32) return launch_halo<KT, KH, TH, TW, 1, 2>(p, st);
     if (p.Cout <= 64) return launch_halo<KT, KH, TH, TW, 2, 2>(p, st);
     // small maps (60 x 104 x 1 frame x 384 channels = 112 workgroups of 96 channels on 512 slots): narrower channel tiles, 3x the
@@ -432,7 +442,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
     p.M = (int64_t)To * Ho * Wo;
     p.K = (int64_t)kt * kh * kw * Cin;
-    p.abl = 0; p.xplane = 0;
+    p.abl = 0; p.xplane = 0; p.post_gamma = nullptr; p.post_out = nullptr; p.post_plane = 0; p.post_silu = 0;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0); p.abl = conv_abl; }
     { M4D_ENV_ONCE(conv_planar, "M4D_CONV_PLANAR", 0); if (conv_planar) p.xplane = (int64_t)Tin * Hin * Win * 16; }     // timing experiment: same bytes read as planar-16
@@ -499,16 +509,22 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
 /* m4d_conv_cl for the 3x3(x3), stride-1, pad-(0,1,1) case with the input in planar-16 layout (what m4d_rmsnorm_silu_cl_planar writes
  * into a causal conv's staging buffer): a halo pixel's 16-channel piece is 32 contiguous bytes next to its row neighbours' instead
  * of 32 bytes out of a Cin*2-byte pixel, so the halo DMA fetches whole lines it uses (fabric traffic / 4 at Cin = 96). */
-extern "C" int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
-                                  int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
-                                  m4d_stream stream) {
+static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                               int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
+                               const float* norm_gamma, void* norm_out, int64_t norm_plane, int norm_silu, m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16, "conv_cl_planar: bf16 only");
-    M4D_CHECK_ARG(x && w && out && Tin > 0 && Hin > 0 && Win > 0 && Cout > 0 && To > 0, "conv_cl_planar: null/empty");
+    M4D_CHECK_ARG(x && w && (out || norm_out) && Tin > 0 && Hin > 0 && Win > 0 && Cout > 0 && To > 0, "conv_cl_planar: null/empty");
+    if (norm_out) {
+        M4D_CHECK_ARG(norm_gamma && norm_plane >= (int64_t)To * Hin * Win * 16 && norm_plane % 8 == 0 && ((uintptr_t)norm_out % 16) == 0,
+                      "conv_cl_planar_norm: gamma / plane stride / alignment of the normalised output");
+        M4D_CHECK_ARG(Cout % 32 == 0 && Cout <= 128 && (!out || out_ld % 8 == 0) && (!resid || resid_ld % 8 == 0),
+                      "conv_cl_planar_norm: Cout in {32, 64, 96, 128}, row strides %% 8");
+    }
     M4D_CHECK_ARG((kt == 3 || kt == 1) && To == Tin - kt + 1, "conv_cl_planar: kt=%d To=%d Tin=%d", kt, To, Tin);
     M4D_CHECK_ARG(Cin % 16 == 0 && Cout % 4 == 0, "conv_cl_planar: Cin %% 16, Cout %% 4");
     M4D_CHECK_ARG(x_plane_stride >= (int64_t)Tin * Hin * Win * 16 && x_plane_stride % 8 == 0, "conv_cl_planar: plane stride too small");
     M4D_CHECK_ARG((int64_t)(Cin / 16) * x_plane_stride * 2 < (1ll << 31), "conv_cl_planar: input extent must stay below 2 GiB");
-    M4D_CHECK_ARG(out_ld % 4 == 0 && out_ld >= Cout && (!resid || (resid_ld % 4 == 0 && resid_ld >= Cout)), "conv_cl_planar: bad out/resid stride");
+    M4D_CHECK_ARG((!out || (out_ld % 4 == 0 && out_ld >= Cout)) && (!resid || (resid_ld % 4 == 0 && resid_ld >= Cout)), "conv_cl_planar: bad out/resid stride");
     M4D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0, "conv_cl_planar: pointers must be 16-byte aligned");
     ConvArgs p;
     p.x = x; p.w = w; p.bias = bias; p.resid = resid; p.out = out;
@@ -519,6 +535,7 @@ extern "C" int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_s
     p.M = (int64_t)To * Hin * Win;
     p.K = (int64_t)kt * 9 * Cin;
     p.abl = 0; p.xplane = x_plane_stride;
+    p.post_gamma = norm_gamma; p.post_out = norm_out; p.post_plane = norm_plane; p.post_silu = norm_silu;
     const bool wide = (Win % 32 == 0) || Win >= 256;
     int rc;
     if (kt == 3) rc = wide ? launch_halo_nt<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<3, 3, 16, 16>(p, (hipStream_t)stream);
@@ -526,4 +543,21 @@ extern "C" int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_s
     if (rc) return rc;
     M4D_CHECK_LAUNCH("conv_cl_planar");
     return 0;
+}
+
+extern "C" int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                                  int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
+                                  m4d_stream stream) {
+    M4D_CHECK_ARG(out, "conv_cl_planar: null output");
+    return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, nullptr, nullptr, 0, 0,
+                               stream);
+}
+
+extern "C" int m4d_conv_cl_planar_norm(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                                       int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt,
+                                       int To, const float* norm_gamma, void* norm_out, int64_t norm_out_plane_stride, int silu,
+                                       m4d_stream stream) {
+    M4D_CHECK_ARG(norm_out, "conv_cl_planar_norm: null normalised output");
+    return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, norm_gamma, norm_out,
+                               norm_out_plane_stride, silu, stream);
 }

@@ -276,6 +276,62 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
         constexpr int CPP = NT * 4;                        // 16-byte chunks per pixel
         const int mt = wave * MT + mi;
         const int row0 = TW == 32 ? mt : mt * ROWS_PER_MT;
+        if (p.post_out) {
+            // fused RMS_norm (+SiLU) of the NEXT layer (wan_vae.py:199-201: norm -> SiLU -> conv): the workgroup owns all Cout = NB
+            // channels of its pixels, so the normalised result goes straight into the next conv's planar-16 staging buffer and the raw
+            // output is written only if somebody else reads it (p.out).  16 lanes per pixel and the reduction order of
+            // rmsnorm_silu_cl_kernel<T, 16, 1>: bit-identical to the separate kernel.
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = j * 64 + lane;
+                const int pl = q >> 4, ch = q & 15;
+                const bool act = ch < CPP;
+                const int row = TW == 32 ? row0 : row0 + pl / TW;
+                const int col = TW == 32 ? pl : pl % TW;
+                const int ho = h0 + row, wo = w0 + col;
+                const bool inside = ho < p.Ho && wo < p.Wo;
+                const int64_t m = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                uint4 raw = make_uint4(0, 0, 0, 0);
+                if (act) {
+                    raw = *reinterpret_cast<const uint4*>(blk + pl * EROW + ((ch ^ (pl & ESW)) << 4));
+                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw);
+                    if (resid && inside) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(resid + m * p.ldr + ch * 8);
+                        const bf16_t* b = reinterpret_cast<const bf16_t*>(&rr);
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)b[e]);
+                        raw = *reinterpret_cast<const uint4*>(&o);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+                }
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                const float sc = sqrtf((float)p.Cout) / fmaxf(sqrtf(ss), 1e-12f);
+                if (!act || !inside) continue;
+                if (p.out) *reinterpret_cast<uint4*>((T*)p.out + m * p.ldo + ch * 8) = raw;
+                bf16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; e += 4) {
+                    const f32x4 g = load4(p.post_gamma + ch * 8 + e);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float u = v[e + k] * sc * g[k];
+                        if (p.post_silu) u = silu_f(round_through<T>(u));
+                        y[e + k] = (bf16_t)u;
+                    }
+                }
+                *reinterpret_cast<bf16x8*>((T*)p.post_out + (int64_t)(ch >> 1) * p.post_plane + m * 16 + (ch & 1) * 8) = y;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < (32 * CPP + 63) / 64; ++j) {
             const int q = j * 64 + lane;

@@ -161,11 +161,12 @@ def _round(n, m):
 
 class _Act:
     """A channels-last activation: `data` is a [t*h*w, C] row-strided 2-D view (`g`: its gradient in the training runner)."""
-    __slots__ = ("data", "t", "h", "w", "c", "g")
+    __slots__ = ("data", "t", "h", "w", "c", "g", "prefilled")
 
     def __init__(self, data, t, h, w, c):
         self.data, self.t, self.h, self.w, self.c = data, t, h, w, c
         self.g = None
+        self.prefilled = False      # data is None: RMS_norm+SiLU of it already sits in the consumer's staging buffer (conv_causal: then=)
 
 
 def _data(a):
@@ -188,8 +189,11 @@ class _Stage:
         self.buf = self._alloc(n_tail + ring * t, dtype, device)
 
     def _alloc(self, frames, dtype, device):
+        """Only the tail is read before it is written (every chunk is filled in full, padding channels included)."""
         shape = (self.c // 16, frames, self.h * self.w, 16) if self.planar else (frames, self.h * self.w, self.c)
-        return torch.zeros(shape, device=device, dtype=dtype)
+        buf = torch.empty(shape, device=device, dtype=dtype)
+        buf.narrow(1 if self.planar else 0, 0, self.n_tail).zero_()
+        return buf
 
     def _frames(self, a, n):
         return self.buf.narrow(1 if self.planar else 0, a, n)
@@ -231,7 +235,7 @@ class _Runner:
     """Executes the encoder / decoder module trees with the HIP kernels.  One instance per encode()/decode() call
     (fresh streaming state = the reference's clear_cache(), wan_vae.py:717-724)."""
 
-    PLANAR, PLANAR_MIN_PIXELS, PLANAR_DTYPES = True, 1024, (torch.bfloat16,)     # (class attributes so that tests can force either path)
+    PLANAR, PLANAR_MIN_PIXELS, PLANAR_DTYPES, FUSE_NORM = True, 1024, (torch.bfloat16,), True     # (class attributes: tests force either path)
 
     def __init__(self, vae, device, dtype):
         self.vae, self.dev, self.T = vae, device, dtype
@@ -240,6 +244,7 @@ class _Runner:
         self.cin_pad = CIN_PAD
         self.ring = 4                  # chunks per staging buffer (_Stage)
         self.planar = self.PLANAR      # norm -> 3x3x3 conv staging buffers in planar-16 layout (bf16, maps of >= 1024 pixels)
+        self.fuse_norm = self.FUSE_NORM   # conv1 -> norm -> conv2 of a ResidualBlock: the norm in conv1's epilogue (<= 128 channels)
 
     # ---- parameter views in kernel layout (cached on the owning AutoencoderKLWan)
     def packed(self, conv):
@@ -294,22 +299,39 @@ class _Runner:
                         x_pixel_stride=x_pixel_stride)
         return _Act(y, t, ho, wo, cop)
 
-    def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None):
-        """k=3 causal conv with a 2-frame tail.  `fill(dst)` writes the chunk [t*h*w, Cin] into the staging buffer."""
+    def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None, then=None):
+        """k=3 causal conv with a 2-frame tail.  `fill(dst)` writes the chunk [t*h*w, Cin] into the staging buffer.
+        then = (norm, next_key, next_conv): the caller will feed RMS_norm+SiLU of this conv's output (and nothing else of it) into
+        `next_conv` (a ResidualBlock's conv1 -> norm -> SiLU -> conv2); where the kernel can, that norm runs in this conv's epilogue
+        straight into next_conv's staging buffer and the returned activation has `.data is None` and `.prefilled = True`."""
         wgt, b, (kt, kh, kw), cip, cop = self.packed(conv)
         # planar-16 staging where the producer can write it (RMS-norm) and the LDS-halo kernel reads it (the decision is per stage:
         # it must not depend on the chunk length)
-        planar = (self.planar and getattr(fill, "planar_ok", False) and self.T in self.PLANAR_DTYPES and (kt, kh, kw) == (3, 3, 3)
-                  and cip % 16 == 0 and h * w >= self.PLANAR_MIN_PIXELS)
+        planar = self._planar_stage(fill, (kt, kh, kw), cip, h, w)
         st = self.stage(key, kt - 1, t, h, w, cip, planar=planar)
         fill(st.chunk(t))
+        fused = False
         if st.planar:
-            y = ops.conv_cl_planar(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, kt=kt, resid=_data(resid), out=out)
+            norm = None
+            if then is not None and self.fuse_norm and conv.weight.shape[0] in (32, 64, 96, 128) and out is None:
+                nxt_norm, nxt_key, nxt_conv = then
+                _, _, k2, cip2, _ = self.packed(nxt_conv)
+                if cip2 == cop and self._planar_stage(self.norm_into(None, nxt_norm), k2, cip2, h, w):
+                    st2 = self.stage(nxt_key, k2[0] - 1, t, h, w, cip2, planar=True)
+                    norm, fused = (self.gamma(nxt_norm), st2.chunk(t), True), True
+            y = ops.conv_cl_planar(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, kt=kt, resid=_data(resid), out=out, norm=norm,
+                                   keep_raw=not fused)
         else:
             y = ops.conv_cl(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=(kt, kh, kw), pad=(0, kh // 2, kw // 2),
                             out_thw=(t, h, w), resid=_data(resid), out=out)
         st.roll(t)
-        return _Act(y, t, h, w, cop)
+        a = _Act(y, t, h, w, cop)
+        a.prefilled = fused
+        return a
+
+    def _planar_stage(self, fill, k, cip, h, w):
+        return (self.planar and getattr(fill, "planar_ok", False) and self.T in self.PLANAR_DTYPES and tuple(k) == (3, 3, 3)
+                and cip % 16 == 0 and h * w >= self.PLANAR_MIN_PIXELS)
 
     # fill callbacks: write a chunk into a conv's staging buffer (the training runner returns objects that also know
     # how to take the gradient of that chunk back to where it came from)
@@ -317,6 +339,8 @@ class _Runner:
         g = self.gamma(norm)
 
         def fill(dst):
+            if getattr(x, "prefilled", False):       # the producing conv's epilogue already wrote RMS_norm+SiLU(x) here (conv_causal: then=)
+                return dst
             if isinstance(dst, ops.Planar16):
                 return ops.rmsnorm_silu_cl_planar(x.data, g, dst, silu=silu)
             return ops.rmsnorm_silu_cl(x.data, g, silu=silu, out=dst)
@@ -353,7 +377,7 @@ class _Runner:
     # ---- blocks
     def residual_block(self, x: _Act, blk, key, out=None):
         r = blk.residual
-        y1 = self.conv_causal(key + ".residual.2", r[2], x.t, x.h, x.w, self.norm_into(x, r[0]))
+        y1 = self.conv_causal(key + ".residual.2", r[2], x.t, x.h, x.w, self.norm_into(x, r[0]), then=(r[3], key + ".residual.6", r[6]))
         h = x if isinstance(blk.shortcut, nn.Identity) else self.conv_plain(x, blk.shortcut)
         return self.conv_causal(key + ".residual.6", r[6], x.t, x.h, x.w, self.norm_into(y1, r[3]), resid=h, out=out)
 

@@ -398,26 +398,42 @@ class Planar16:
         return self.t.shape[0] * 16
 
 
-def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None):
-    """3x3(x3) stride-1 conv (pad (0,1,1), valid in T) of a Planar16 input; w / bias / resid / out as conv_cl."""
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True):
+    """3x3(x3) stride-1 conv (pad (0,1,1), valid in T) of a Planar16 input; w / bias / resid / out as conv_cl.
+    norm = (gamma float32 [Cout], dst Planar16, silu): the next layer's RMS_norm(+SiLU) fused into the epilogue, written to `dst`
+    (rows == To*Hin*Win); with keep_raw=False the un-normalised result is not stored and None is returned."""
     _dev(x.t, w, bias, resid, out)
     Cin, Cout = x.channels, w.shape[0]
     if x.t.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.rows != Tin * Hin * Win or w.shape[1] != kt * 9 * Cin:
         raise ValueError("conv_cl_planar: bf16, rows == Tin*Hin*Win, w [Cout, kt*9*Cin]")
     To = Tin - kt + 1
     M = To * Hin * Win
-    if out is None:
-        out = torch.empty((M, Cout), device=w.device, dtype=w.dtype)
-    om, ldo = _rows2d(out)
-    if om != M or out.shape[-1] != Cout:
-        raise ValueError(f"conv_cl_planar: out {tuple(out.shape)} vs M={M} Cout={Cout}")
+    ldo = 0
+    if norm is None or keep_raw:
+        if out is None:
+            out = torch.empty((M, Cout), device=w.device, dtype=w.dtype)
+        om, ldo = _rows2d(out)
+        if om != M or out.shape[-1] != Cout:
+            raise ValueError(f"conv_cl_planar: out {tuple(out.shape)} vs M={M} Cout={Cout}")
+    elif out is not None:
+        raise ValueError("conv_cl_planar: keep_raw=False with an output buffer")
     ldr = 0
     if resid is not None:
         rm, ldr = _rows2d(resid)
         if rm != M or resid.shape[-1] != Cout:
             raise ValueError("conv_cl_planar: resid shape mismatch")
-    check(_lib.load().m4d_conv_cl_planar(dt_code(w.dtype), _ptr(x.t), x.plane_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
-                                         Tin, Hin, Win, Cin, Cout, kt, To, _stream()), "m4d_conv_cl_planar")
+    lib = _lib.load()
+    if norm is None:
+        check(lib.m4d_conv_cl_planar(dt_code(w.dtype), _ptr(x.t), x.plane_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
+                                     Tin, Hin, Win, Cin, Cout, kt, To, _stream()), "m4d_conv_cl_planar")
+        return out
+    gamma, dst, silu = norm
+    _dev(gamma, dst.t)
+    if gamma.dtype != torch.float32 or gamma.numel() != Cout or dst.rows != M or dst.channels != Cout or dst.t.dtype != w.dtype:
+        raise ValueError("conv_cl_planar: norm = (gamma float32 [Cout], Planar16 of To*Hin*Win rows x Cout channels, silu)")
+    check(lib.m4d_conv_cl_planar_norm(dt_code(w.dtype), _ptr(x.t), x.plane_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
+                                      Tin, Hin, Win, Cin, Cout, kt, To, _ptr(gamma), _ptr(dst.t), dst.plane_stride, int(silu), _stream()),
+          "m4d_conv_cl_planar_norm")
     return out
 
 

@@ -271,9 +271,14 @@ def _planar_to_cl(x):
     return x.t.permute(1, 2, 0, 3).reshape(fr * hw, c16 * 16)
 
 
-def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None):
-    return conv_cl(_planar_to_cl(x).contiguous(), w, bias, Tin=Tin, Hin=Hin, Win=Win, Cin=x.channels, k=(kt, 3, 3), pad=(0, 1, 1),
-                   out_thw=(Tin - kt + 1, Hin, Win), resid=resid, out=out)
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True):
+    y = conv_cl(_planar_to_cl(x).contiguous(), w, bias, Tin=Tin, Hin=Hin, Win=Win, Cin=x.channels, k=(kt, 3, 3), pad=(0, 1, 1),
+                out_thw=(Tin - kt + 1, Hin, Win), resid=resid, out=out if (norm is None or keep_raw) else None)
+    if norm is None:
+        return y
+    gamma, dst, silu = norm
+    rmsnorm_silu_cl_planar(y, gamma, dst, silu=silu)
+    return y if keep_raw else None
 
 
 def rmsnorm_silu_cl_planar(x, gamma, out, *, silu=True):

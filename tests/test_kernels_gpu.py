@@ -402,7 +402,7 @@ def _conv_cl_production_case(cin, cout, k, pad, To, H, W):
 
 
 @pytest.mark.parametrize("cin,cout,kt,thw", [(96, 96, 3, (4, 128, 160)), (96, 4, 3, (2, 40, 64)), (384, 384, 3, (2, 60, 104)),
-                                             (128, 128, 1, (3, 64, 96))])
+                                             (128, 128, 1, (3, 64, 96)), (192, 96, 3, (2, 30, 52)), (32, 64, 3, (1, 33, 47))])
 def test_planar16_norm_and_conv_equal_channels_last(cin, cout, kt, thw):
     """m4d_rmsnorm_silu_cl_planar + m4d_conv_cl_planar (the norm -> conv staging path of the VAE) against the channels-last pair:
     the same arithmetic on another layout, so bit-identical; the planar buffer is a window of a larger ring with a plane stride."""
@@ -424,6 +424,17 @@ def test_planar16_norm_and_conv_equal_channels_last(cin, cout, kt, thw):
     assert torch.isnan(ring[:, :3].float()).all() and torch.isnan(ring[:, 3 + Tin:].float()).all()
     out = o.conv_cl_planar(win, w, b, Tin=Tin, Hin=H, Win=W, kt=kt, resid=res)
     assert torch.equal(out, ref)
+    if cout in (32, 64, 96, 128):
+        # the next layer's RMS_norm+SiLU in the conv epilogue == the separate kernel on the conv's result, bit for bit
+        gamma2 = (1 + 0.1 * torch.randn(cout, generator=g)).to(DEV)
+        want = o.rmsnorm_silu_cl(ref, gamma2, silu=True)
+        for keep in (True, False):
+            ring2 = torch.full((cout // 16, To + 4, H * W, 16), float("nan"), dtype=torch.bfloat16, device=DEV)
+            dst = o.Planar16(ring2[:, 2:2 + To])
+            raw = o.conv_cl_planar(win, w, b, Tin=Tin, Hin=H, Win=W, kt=kt, resid=res, norm=(gamma2, dst, True), keep_raw=keep)
+            assert (raw is None) == (not keep) and (raw is None or torch.equal(raw, ref))
+            assert torch.equal(dst.t.permute(1, 2, 0, 3).reshape(To * H * W, cout), want)
+            assert torch.isnan(ring2[:, :2].float()).all() and torch.isnan(ring2[:, 2 + To:].float()).all()
 
 
 @pytest.mark.parametrize("tsplit", [False, True])
