@@ -894,9 +894,8 @@ class WanTransformer4DModel(nn.Module):
 
     def _guidance_tables(self, feats, hw, latent_T):
         """OmniMAE patch features -> SiLU'd, adapter-convolved, resized [B, h*w, 768] table (reference
-        :1149-1156).  The 3x3 adapter convs + bilinear resize run once per forward on a 14x14 map; they are
-        built with the VAE conv kernels in a later round — until then guidance inference needs the caller to
-        pass features already adapted to (h, w)."""
+        :1149-1156).  Raw 14x14 OmniMAE patch features go through `_adapt_features` (the 3x3 adapter convs on the VAE conv
+        kernel + bilinear resize, once per forward); features already adapted to (h, w) are taken as they are."""
         patch, cls = feats
         T = self.dtype
         h, w = hw
