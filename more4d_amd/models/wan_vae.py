@@ -183,10 +183,23 @@ class _Stage:
     planar: the buffer is [C/16, frames, h*w, 16] (ops.Planar16) instead of [frames, h*w, C]: what the RMS-norm kernel writes for the
     LDS-halo conv kernel, whose halo DMA then uses every byte of the lines it fetches."""
 
+    PLANAR_MAX_BYTES = (1 << 31) - (1 << 20)      # m4d_conv_cl_planar addresses its input with 32-bit offsets
+
     def __init__(self, n_tail, t, h, w, c, dtype, device, ring=1, planar=False):
         self.n_tail, self.h, self.w, self.c = n_tail, h, w, c
         self.cap, self.ring, self.pos, self.planar = t, ring, 0, planar
-        self.buf = self._alloc(n_tail + ring * t, dtype, device)
+        self.buf = self._alloc(self._frames_for(t), dtype, device)
+
+    def _frames_for(self, t):
+        """Frames of a buffer for chunks of t frames: tail + ring chunks; a planar buffer must stay below 2 GiB, so large maps get
+        fewer chunks per buffer, and a stage that cannot even hold one chunk that way goes (back) to channels-last."""
+        if self.planar:
+            most = self.PLANAR_MAX_BYTES // ((self.c // 16) * self.h * self.w * 32)
+            r = min(self.ring, (most - self.n_tail) // t)
+            if r >= 1:
+                return self.n_tail + r * t
+            self.planar = False
+        return self.n_tail + self.ring * t
 
     def _alloc(self, frames, dtype, device):
         """Only the tail is read before it is written (every chunk is filled in full, padding channels included)."""
@@ -204,9 +217,11 @@ class _Stage:
         if t > self.cap or self.pos + self.n_tail + t > total:
             tail = self.tail()
             if t > self.cap:   # grow, keeping the tail
-                old = tail.clone()
+                old, was_planar = tail.clone(), self.planar
                 self.cap = t
-                self.buf = self._alloc(self.n_tail + self.ring * t, self.buf.dtype, self.buf.device)
+                self.buf = self._alloc(self._frames_for(t), self.buf.dtype, self.buf.device)
+                if was_planar and not self.planar:
+                    old = old.permute(1, 2, 0, 3).reshape(self.n_tail, self.h * self.w, self.c)
                 self._frames(0, self.n_tail).copy_(old)
             else:              # wrap around
                 self._frames(0, self.n_tail).copy_(tail.clone() if self.pos < self.n_tail else tail)
@@ -317,8 +332,9 @@ class _Runner:
                 nxt_norm, nxt_key, nxt_conv = then
                 _, _, k2, cip2, _ = self.packed(nxt_conv)
                 if cip2 == cop and self._planar_stage(self.norm_into(None, nxt_norm), k2, cip2, h, w):
-                    st2 = self.stage(nxt_key, k2[0] - 1, t, h, w, cip2, planar=True)
-                    norm, fused = (self.gamma(nxt_norm), st2.chunk(t), True), True
+                    dst2 = self.stage(nxt_key, k2[0] - 1, t, h, w, cip2, planar=True).chunk(t)
+                    if isinstance(dst2, ops.Planar16):
+                        norm, fused = (self.gamma(nxt_norm), dst2, True), True
             y = ops.conv_cl_planar(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, kt=kt, resid=_data(resid), out=out, norm=norm,
                                    keep_raw=not fused)
         else:

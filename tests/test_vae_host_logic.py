@@ -68,6 +68,20 @@ def test_vae_planar_staging_host_logic(monkeypatch):
         want = torch.stack(([torch.zeros(4, 32)] * 2 + frames)[-(2 + t):])
         assert torch.equal(win, want), i
         st.roll(t)
+    # a planar buffer must stay below the 2 GiB the conv kernel can address: fewer chunks per buffer, then channels-last
+    monkeypatch.setattr(wan_vae._Stage, "PLANAR_MAX_BYTES", 2 * (2 + 2 * 3) * 4 * 32)      # room for tail + 2 chunks of 3 frames
+    st = wan_vae._Stage(2, 3, 2, 2, 32, torch.float32, "cpu", ring=4, planar=True)
+    assert st.planar and st.buf.shape == (2, 2 + 2 * 3, 4, 16)
+    tail = torch.arange(2 * 4 * 32, dtype=torch.float32).view(2, 4, 32)
+    st.tail().copy_(tail.view(2, 4, 2, 16).permute(2, 0, 1, 3))
+    v = st.chunk(8)                                                                        # grows past the limit: channels-last from now on
+    assert not st.planar and not isinstance(v, ops_mod().Planar16) and v.shape == (8 * 4, 32)
+    assert torch.equal(st.tail(), tail)
+
+
+def ops_mod():
+    import more4d_amd.ops as o
+    return o
 
 
 def test_adaptors_host_logic(monkeypatch):
