@@ -199,6 +199,12 @@ int m4d_rmsnorm_silu_cl_planar(m4d_dtype dt, const void* x, int64_t x_ld, const 
 int64_t m4d_groupnorm_cl_workspace(int F, int64_t HW, int G);
 int m4d_groupnorm_cl(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight,
                      const float* bias, int F, int64_t HW, int C, int G, float eps, int silu, m4d_stream stream);
+/* ... with the result in planar-16 layout for m4d_conv_cl_planar (the adaptors' norm -> swish -> conv, trajectory_module.py:54-71): the F
+ * frames go into groups of `frames_per_group`, group g = [C/16][frames_per_group*HW][16] at out + g*out_group_stride with
+ * out_plane_stride elements between channel planes (a group must stay below the 2 GiB the conv addresses).  bf16, C % 16 == 0. */
+int m4d_groupnorm_cl_planar(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight,
+                            const float* bias, int F, int64_t HW, int C, int G, float eps, int silu, int frames_per_group,
+                            int64_t out_plane_stride, int64_t out_group_stride, m4d_stream stream);
 
 /* out[r, c] = softmax_c(x[r, c] * scale) for c < C, 0 for C <= c < Cpad — the score matrix of the VAE's single-head
  * mid-block attention (wan_vae.py:256-260; head dim 384 > the flash kernel's 128). */

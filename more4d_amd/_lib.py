@@ -110,6 +110,8 @@ SIGNATURES = {
     "m4d_groupnorm_cl_workspace": (c_int64, [c_int, c_int64, c_int]),
     "m4d_groupnorm_cl": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int,
                                  c_int, c_float, c_int, c_void_p]),
+    "m4d_groupnorm_cl_planar": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                        c_int, c_float, c_int, c_int, c_int64, c_int64, c_void_p]),
     "m4d_softmax_rows": (c_int, [c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
                                  c_void_p]),
     "m4d_ncthw_to_cl": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,

@@ -102,6 +102,9 @@ struct GnArgs {
     const void* x; void* out; float* partial; float* stat; const float* weight; const float* bias;
     int64_t HW;
     int F, C, G, nblk, ppb, silu; float eps;
+    // planar-16 output (out_plane != 0): frames in groups of `fpg`, group g = [C/16][fpg*HW][16] with out_plane elements between planes
+    // and out_group between groups (each group stays below the 2 GiB m4d_conv_cl_planar addresses)
+    int64_t out_plane, out_group; int fpg;
 };
 
 // A thread owns VEC = 16 bytes of channels of a pixel (8 bf16 / 4 float; 4 when C % 8 != 0) = VEC/4 sub-vectors of 4 channels, each
@@ -208,7 +211,10 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnArgs p) {
     }
     const int64_t p0 = (int64_t)blk * p.ppb, p1 = min(p0 + p.ppb, p.HW);
     const T* xf = (const T*)p.x + (int64_t)f * p.HW * p.C + v * VEC;
-    T* of = (T*)p.out + (int64_t)f * p.HW * p.C + v * VEC;
+    // channels-last: pixel stride C; planar-16 (VEC = 8): this thread's 8 channels are half (v & 1) of plane v >> 1, pixel stride 16
+    const int64_t opx = p.out_plane ? 16 : p.C;
+    T* of = p.out_plane ? (T*)p.out + (int64_t)(f / p.fpg) * p.out_group + (int64_t)(v >> 1) * p.out_plane + (int64_t)(f % p.fpg) * p.HW * 16 + (v & 1) * 8
+                        : (T*)p.out + (int64_t)f * p.HW * p.C + v * VEC;
     auto apply = [&](GnVec<T, VEC>& u) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
@@ -225,9 +231,9 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnArgs p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) u[j].load(xf + (px + j * slots) * p.C);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { apply(u[j]); u[j].store(of + (px + j * slots) * p.C); }
+        for (int j = 0; j < 8; ++j) { apply(u[j]); u[j].store(of + (px + j * slots) * opx); }
     }
-    for (; px < p1; px += slots) { GnVec<T, VEC> u; u.load(xf + px * p.C); apply(u); u.store(of + px * p.C); }
+    for (; px < p1; px += slots) { GnVec<T, VEC> u; u.load(xf + px * p.C); apply(u); u.store(of + px * opx); }
 }
 
 // ------------------------------------------------------------------ row softmax (VAE mid attention scores)
@@ -338,9 +344,27 @@ static int rmsnorm_silu_launch(m4d_dtype dt, const void* x, int64_t x_ld, const 
 
 constexpr int GN_PPB = 512;        // pixels per workgroup of the stats / apply passes
 
+static int groupnorm_impl(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight, const float* bias,
+                          int F, int64_t HW, int C, int G, float eps, int silu, int fpg, int64_t out_plane, int64_t out_group, m4d_stream stream);
+
 extern "C" int m4d_groupnorm_cl(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats,
                                 const float* weight, const float* bias, int F, int64_t HW, int C, int G, float eps, int silu,
                                 m4d_stream stream) {
+    return groupnorm_impl(dt, x, out, partial, partial_floats, weight, bias, F, HW, C, G, eps, silu, 0, 0, 0, stream);
+}
+
+extern "C" int m4d_groupnorm_cl_planar(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight,
+                                       const float* bias, int F, int64_t HW, int C, int G, float eps, int silu, int frames_per_group,
+                                       int64_t out_plane_stride, int64_t out_group_stride, m4d_stream stream) {
+    M4D_CHECK_ARG(dt == M4D_BF16 && C % 16 == 0, "groupnorm_cl_planar: bf16, C %% 16");
+    M4D_CHECK_ARG(frames_per_group > 0 && out_plane_stride >= (int64_t)frames_per_group * HW * 16 && out_plane_stride % 8 == 0 &&
+                  out_group_stride >= (int64_t)(C / 16) * out_plane_stride, "groupnorm_cl_planar: bad group / plane strides");
+    return groupnorm_impl(dt, x, out, partial, partial_floats, weight, bias, F, HW, C, G, eps, silu, frames_per_group, out_plane_stride,
+                          out_group_stride, stream);
+}
+
+static int groupnorm_impl(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight, const float* bias,
+                          int F, int64_t HW, int C, int G, float eps, int silu, int fpg, int64_t out_plane, int64_t out_group, m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "groupnorm_cl: bad dtype");
     M4D_CHECK_ARG(x && out && partial && weight && bias && F > 0 && HW > 0, "groupnorm_cl: null/empty");
     M4D_CHECK_ARG(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "groupnorm_cl: C=%d unsupported (C/4 must divide 256)", C);
@@ -348,7 +372,7 @@ extern "C" int m4d_groupnorm_cl(m4d_dtype dt, const void* x, void* out, float* p
     const int nblk = (int)((HW + GN_PPB - 1) / GN_PPB);
     M4D_CHECK_ARG(partial_floats >= m4d_groupnorm_cl_workspace(F, HW, G), "groupnorm_cl: workspace too small (need %lld floats)",
                   (long long)m4d_groupnorm_cl_workspace(F, HW, G));
-    GnArgs p{x, out, partial, partial + (int64_t)F * nblk * G * 2, weight, bias, HW, F, C, G, nblk, GN_PPB, silu, eps};
+    GnArgs p{x, out, partial, partial + (int64_t)F * nblk * G * 2, weight, bias, HW, F, C, G, nblk, GN_PPB, silu, eps, out_plane, out_group, fpg > 0 ? fpg : 1};
     dim3 grid(nblk, F), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (dt == M4D_BF16 && C % 8 == 0) {

@@ -90,6 +90,28 @@ class _AdaptorBase(nn.Module):
         return ops.groupnorm_cl(x.view(F, HW, -1), self._f32(norm.weight), self._f32(norm.bias), F=F, HW=HW,
                                 groups=norm.num_groups, eps=norm.eps, silu=True).view(F * HW, -1)
 
+    PLANAR, PLANAR_MIN_PIXELS, PLANAR_MAX_BYTES, PLANAR_DTYPES = True, 1024, (1 << 31) - (1 << 20), (torch.bfloat16,)    # (tests force either path)
+
+    def _norm_conv(self, h, norm, conv, F, H, W, cin, resid=None):
+        """GroupNorm + swish + 3x3 conv (:54-71).  bf16 inference on real maps: the norm writes planar-16 frame groups (each below the
+        2 GiB the conv kernel addresses) and the LDS-halo conv reads them, so its halo DMA uses the lines it fetches."""
+        if self.PLANAR and self.dtype in self.PLANAR_DTYPES and cin % 16 == 0 and H * W >= self.PLANAR_MIN_PIXELS:
+            most = max(1, self.PLANAR_MAX_BYTES // ((cin // 16) * H * W * 32))
+            ng = -(-F // most)
+            groups = ops.groupnorm_cl_planar(h.view(F, H * W, -1), self._f32(norm.weight), self._f32(norm.bias), F=F, HW=H * W,
+                                             groups=norm.num_groups, eps=norm.eps, silu=True, frames_per_group=-(-F // ng))
+            w, b, cip, cop = self._packed(conv)
+            assert cip == cin
+            out = torch.empty((F * H * W, cop), device=h.device, dtype=h.dtype)
+            f0 = 0
+            for g in groups:
+                n = g.t.shape[1]
+                rows = slice(f0 * H * W, (f0 + n) * H * W)
+                ops.conv_cl_planar(g, w, b, Tin=n, Hin=H, Win=W, kt=1, resid=None if resid is None else resid[rows], out=out[rows])
+                f0 += n
+            return out, cop
+        return self._conv(self._gn_swish(h, norm, F, H * W), conv, F, H, W, cin, resid=resid)
+
     def _run(self, x):
         """Per-sample forward; under autograd (trainable adaptor or an input that needs its gradient, train_vae.py:438-455) every
         sample is one `vae_autograd.AdaptorFn` node whose backward recomputes groups of frames with the HIP kernels."""
@@ -100,8 +122,8 @@ class _AdaptorBase(nn.Module):
 
     def _resnet(self, h, blk, F, H, W):
         c = blk.in_channels
-        y, _ = self._conv(self._gn_swish(h, blk.norm1, F, H * W), blk.conv1, F, H, W, c)
-        y, _ = self._conv(self._gn_swish(y, blk.norm2, F, H * W), blk.conv2, F, H, W, c, resid=h)
+        y, _ = self._norm_conv(h, blk.norm1, blk.conv1, F, H, W, c)
+        y, _ = self._norm_conv(y, blk.norm2, blk.conv2, F, H, W, c, resid=h)
         return y
 
 
@@ -145,7 +167,7 @@ class VAEEncoderadaptor(_AdaptorBase):
         h, _ = self._conv(h, self.conv_in, F, H, W, CIN_PAD)
         for blk in self.down[0].block:
             h = self._resnet(h, blk, F, H, W)
-        h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
+        h, cop = self._norm_conv(h, self.norm_out, self.conv_out, F, H, W, self.ch)
         return ops.cl_to_ncthw(h, T, C=C, T=F, H=H, W=W, pixel_stride=cop, act=2, aux=xb)
 
     def forward(self, x):
@@ -193,7 +215,7 @@ class VAEDecoderadaptor(_AdaptorBase):
         h, _ = self._conv(h, self.conv_in, F, H, W, CIN_PAD)
         for blk in self.up[0].block:
             h = self._resnet(h, blk, F, H, W)
-        h, cop = self._conv(self._gn_swish(h, self.norm_out, F, H * W), self.conv_out, F, H, W, self.ch)
+        h, cop = self._norm_conv(h, self.norm_out, self.conv_out, F, H, W, self.ch)
         return ops.cl_to_ncthw(h, T, C=self.out_ch, T=F, H=H, W=W, pixel_stride=cop)
 
     def forward(self, z):

@@ -485,6 +485,23 @@ def groupnorm_cl(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, out=
     return out
 
 
+def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, frames_per_group):
+    """groupnorm_cl with the result as a list of Planar16 views, one per group of `frames_per_group` frames (the last may be shorter),
+    ready for conv_cl_planar (kt = 1)."""
+    _dev(x, weight, bias)
+    if not x.is_contiguous() or x.dtype != torch.bfloat16:
+        raise ValueError("groupnorm_cl_planar: contiguous bf16 x")
+    C = x.shape[-1]
+    ng = (F + frames_per_group - 1) // frames_per_group
+    buf = torch.empty((ng, C // 16, frames_per_group, HW, 16), device=x.device, dtype=x.dtype)
+    lib = _lib.load()
+    n = lib.m4d_groupnorm_cl_workspace(F, HW, groups)
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    check(lib.m4d_groupnorm_cl_planar(dt_code(x.dtype), _ptr(x), _ptr(buf), _ptr(ws), n, _ptr(weight), _ptr(bias), F, HW, C, groups, eps,
+                                      int(silu), frames_per_group, buf.stride(1), buf.stride(0), _stream()), "m4d_groupnorm_cl_planar")
+    return [Planar16(buf[g, :, :min(frames_per_group, F - g * frames_per_group)]) for g in range(ng)]
+
+
 def softmax_rows(x, out_dtype, *, C, Cpad, scale):
     """x [R, >=C] float32/bf16 -> softmax(x[:, :C]*scale) in out_dtype [R, Cpad] (pad columns zero)."""
     _dev(x)

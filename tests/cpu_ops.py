@@ -288,7 +288,18 @@ def rmsnorm_silu_cl_planar(x, gamma, out, *, silu=True):
     return out
 
 
-NAMES += ["conv_cl_planar", "rmsnorm_silu_cl_planar"]
+def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, frames_per_group):
+    import more4d_amd.ops as real
+    y = groupnorm_cl(x, weight, bias, F=F, HW=HW, groups=groups, eps=eps, silu=silu).view(F, HW, -1)
+    C = y.shape[-1]
+    out = []
+    for f0 in range(0, F, frames_per_group):
+        n = min(frames_per_group, F - f0)
+        out.append(real.Planar16(y[f0:f0 + n].reshape(n, HW, C // 16, 16).permute(2, 0, 1, 3).contiguous()))
+    return out
+
+
+NAMES += ["conv_cl_planar", "rmsnorm_silu_cl_planar", "groupnorm_cl_planar"]
 
 
 def groupnorm_cl(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, out=None):

@@ -136,3 +136,33 @@ def test_adaptors_fp32(which):
     with torch.no_grad():
         out = m(z["x"].to(DEV))
     assert rel_err(out.cpu(), z["out"]) < 1e-3
+
+
+@pytest.mark.parametrize("which", ["enc", "dec"])
+def test_adaptor_planar_groups_equal_channels_last_bf16(which):
+    """bf16 adaptors on a 40x64 map: GroupNorm writing planar-16 frame groups + m4d_conv_cl_planar (default at >= 1024 pixels; here with
+    the group size forced down to 2 and 1 frames so that several groups and a short last group occur) give the same bits as the
+    channels-last GroupNorm + m4d_conv_cl pair."""
+    from more4d_amd.models import trajectory_module
+    from more4d_amd.models.trajectory_module import VAEDecoderadaptor, VAEEncoderadaptor
+    z = load_npz(f"adaptor_{which}.npz")
+    m = (VAEEncoderadaptor if which == "enc" else VAEDecoderadaptor)().eval()
+    m.load_state_dict({k[3:]: v for k, v in z.items() if k.startswith("sd.")}, strict=True)
+    m = m.to(DEV, torch.bfloat16)
+    x = (torch.randn(1, 3, 5, 40, 64, generator=torch.Generator().manual_seed(3)) * 0.5).to(DEV, torch.bfloat16)
+    base = trajectory_module._AdaptorBase
+    saved = base.PLANAR, base.PLANAR_MAX_BYTES
+    try:
+        base.PLANAR = False
+        with torch.no_grad():
+            ref = m(x)
+        outs = []
+        for limit in ((1 << 31) - (1 << 20), 2 * 8 * 40 * 64 * 32, 1):      # one group of 5 | groups of 2, 2, 1 | 5 groups of 1
+            base.PLANAR, base.PLANAR_MAX_BYTES = True, limit
+            with torch.no_grad():
+                outs.append(m(x))
+    finally:
+        base.PLANAR, base.PLANAR_MAX_BYTES = saved
+    assert torch.isfinite(ref.float()).all()
+    for o in outs:
+        assert torch.equal(o, ref)

@@ -84,9 +84,15 @@ def ops_mod():
     return o
 
 
-def test_adaptors_host_logic(monkeypatch):
+@pytest.mark.parametrize("planar", [False, True])
+def test_adaptors_host_logic(monkeypatch, planar):
+    from more4d_amd.models import trajectory_module
     from more4d_amd.models.trajectory_module import VAEDecoderadaptor, VAEEncoderadaptor
     cpu_ops.install(monkeypatch)
+    if planar:        # GroupNorm -> planar-16 frame groups -> conv, forced on at the fixture's size with 2-frame groups
+        monkeypatch.setattr(trajectory_module._AdaptorBase, "PLANAR_MIN_PIXELS", 0)
+        monkeypatch.setattr(trajectory_module._AdaptorBase, "PLANAR_MAX_BYTES", 1)
+        monkeypatch.setattr(trajectory_module._AdaptorBase, "PLANAR_DTYPES", (torch.float32, torch.bfloat16))
     for cls, name in ((VAEEncoderadaptor, "adaptor_enc.npz"), (VAEDecoderadaptor, "adaptor_dec.npz")):
         z = load_npz(name)
         m = cls().eval()
