@@ -543,7 +543,7 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
     p.gate_stride = gate_stride; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : M;
     p.epilogue = epilogue; p.bias_on_m = bias_on_m;
     p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0;
-    p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr;
+    p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
     p.abl = 0;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(abl_env, "M4D_GEMM_ABL", 0); p.abl = abl_env; }
@@ -582,7 +582,18 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
             q.remap_n = 0; q.tile_base = full; q.ksplit = S; q.ws = (float*)ws;
             hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)(tail * S)), dim3(512), 2 * P_BUF, st, q);
             hipLaunchKernelGGL(gemm_tail_fixup_kernel<bf16_t>, dim3((unsigned)(tail * 16)), dim3(256), 0, st, q);
-        } else if (variant == 4) hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)nwg), dim3(512), 2 * P_BUF, st, p);
+        } else if (variant == 4) {
+            // M4D_GEMM_CHUNK=n: the tile grid in launches of n tiles (whole rounds of the 256 CUs): every launch boundary re-aligns the
+            // workgroups that share A / W panels, whose K loops otherwise drift apart and stop hitting each other's lines in L2
+            M4D_ENV_ONCE(chunk, "M4D_GEMM_CHUNK", 0);
+            if (chunk > 0 && nwg > chunk) {
+                for (int64_t t0 = 0; t0 < nwg; t0 += chunk) {
+                    GemmArgs q = p;
+                    q.remap_n = (int)std::min<int64_t>(chunk, nwg - t0); q.tile_off = (int)t0;
+                    hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)q.remap_n), dim3(512), 2 * P_BUF, st, q);
+                }
+            } else hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)nwg), dim3(512), 2 * P_BUF, st, p);
+        }
         else if (variant == 3) hipLaunchKernelGGL(gemm_bt256s_kernel, dim3((unsigned)nwg), dim3(512), 5 * SLOT3, st, p);
         else if (variant == 1) hipLaunchKernelGGL(gemm_bt256_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE2_BYTES, st, p);
         else hipLaunchKernelGGL(gemm_bt256pp_kernel, dim3((unsigned)nwg), dim3(512), 4 * SLOT_BYTES, st, p);
@@ -633,7 +644,7 @@ extern "C" int m4d_gemm_bt_batched(m4d_dtype dt, const void* A, int64_t lda, int
     p.lda = lda; p.ldw = ldw; p.ldc = N; p.M = M; p.N = N; p.K = K;
     p.gate_stride = 0; p.rows_per_sample = M; p.epilogue = M4D_EPI_STORE_F32; p.bias_on_m = 0;
     p.nb1 = nb1; p.a_bs1 = a_bs1; p.a_bs2 = a_bs2; p.w_bs1 = w_bs1; p.w_bs2 = w_bs2; p.abl = 0;
-    p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr;
+    p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(nb1 * nb2)), block(256);
     if (dt == M4D_BF16) hipLaunchKernelGGL(gemm_bt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);

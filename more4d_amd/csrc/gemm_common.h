@@ -20,6 +20,7 @@ struct GemmArgs {
     // split-K tail (m4d_gemm_bt_ws): the launch over the full tile rounds uses `remap_n` (< tiles_m*tiles_n) logical tiles; the tail
     // launch has ksplit > 0: block b computes K-slice b % ksplit of logical tile tile_base + b / ksplit into its float32 slab of `ws`
     int remap_n, tile_base, ksplit;
+    int tile_off;   // chunked launches (M4D_GEMM_CHUNK): this launch covers logical tiles [tile_off, tile_off + remap_n)
     float* ws;
     int abl;   // timing ablations (tools only; results wrong when != 0): 1 no DMA, 2 frags once, 4 no barriers, 8 no MFMA
 };
@@ -34,7 +35,7 @@ M4D_DEV void tile_coords(const GemmArgs& p, int& tm, int& tn, int bid) {
     else {
         const int nwg = p.remap_n > 0 ? p.remap_n : p.tiles_m * p.tiles_n;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx + p.tile_off;
     }
     constexpr int GM = 8;
     const int band = bid / (GM * p.tiles_n);
