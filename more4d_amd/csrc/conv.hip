@@ -456,11 +456,11 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     const bool halo_shape = conv_variant == 3 && v2_base && kw == 3 && kh == 3 && (kt == 3 || kt == 1) && pad_t == 0 && pad_h == 1 &&
                             pad_w == 1 && Ho == (Hin << ups) && Wo == (Win << ups) && To == (Tin << tsplit) - kt + 1 && Cin % 16 == 0 &&
                             (!tsplit || kt == 1);
-    if (v2_shape && xbytes >= (1ll << 30) && kt == 1 && pad_t == 0 && To == Tin) {
+    if (v2_shape && xbytes >= (1ll << 31) - (1ll << 20) && kt == 1 && pad_t == 0 && To == Tin) {
         // 2-D convolution over many frames (the adaptors: 49 x 480 x 832 x 128): frames are independent, so launch groups of
         // frames whose input fits the kernel's 31-bit offsets
         const int64_t frame_bytes = (int64_t)Hin * Win * x_pixel_stride * 2;
-        const int per = (int)std::max<int64_t>(1, ((1ll << 30) - 1) / frame_bytes);
+        const int per = (int)std::max<int64_t>(1, ((1ll << 31) - (1ll << 20) - 1) / frame_bytes);
         for (int f0 = 0; f0 < Tin; f0 += per) {
             const int nf = std::min(per, Tin - f0);
             const int rc = m4d_conv_cl(dt, (const char*)x + (int64_t)f0 * frame_bytes, x_pixel_stride, w, bias,
@@ -471,7 +471,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
         }
         return 0;
     }
-    if (halo_shape && xbytes < (1ll << 30)) {
+    if (halo_shape && xbytes < (1ll << 31) - (1ll << 20)) {        // (unsigned 32-bit byte offsets into a raw buffer descriptor)
         const bool wide = (Wo % 32 == 0) || Wo >= 256;        // 8 x 32 patches; narrow maps (104, 208 columns) use 16 x 16
         int rc;
         if (kt == 3) rc = wide ? launch_halo_nt<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<3, 3, 16, 16>(p, (hipStream_t)stream);

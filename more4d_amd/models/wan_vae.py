@@ -16,6 +16,8 @@ temporal convs of the Resample blocks on chunk 0 exactly where the reference doe
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -161,12 +163,12 @@ def _round(n, m):
 
 class _Act:
     """A channels-last activation: `data` is a [t*h*w, C] row-strided 2-D view (`g`: its gradient in the training runner)."""
-    __slots__ = ("data", "t", "h", "w", "c", "g", "prefilled")
+    __slots__ = ("data", "t", "h", "w", "c", "g", "prefilled_for")
 
     def __init__(self, data, t, h, w, c):
         self.data, self.t, self.h, self.w, self.c = data, t, h, w, c
         self.g = None
-        self.prefilled = False      # data is None: RMS_norm+SiLU of it already sits in the consumer's staging buffer (conv_causal: then=)
+        self.prefilled_for = None   # key of the conv stage whose buffer already holds RMS_norm+SiLU of this activation (conv_causal: then=)
 
 
 def _data(a):
@@ -314,18 +316,21 @@ class _Runner:
                         x_pixel_stride=x_pixel_stride)
         return _Act(y, t, ho, wo, cop)
 
-    def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None, then=None):
+    def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None, then=None, keep_raw=True):
         """k=3 causal conv with a 2-frame tail.  `fill(dst)` writes the chunk [t*h*w, Cin] into the staging buffer.
-        then = (norm, next_key, next_conv): the caller will feed RMS_norm+SiLU of this conv's output (and nothing else of it) into
-        `next_conv` (a ResidualBlock's conv1 -> norm -> SiLU -> conv2); where the kernel can, that norm runs in this conv's epilogue
-        straight into next_conv's staging buffer and the returned activation has `.data is None` and `.prefilled = True`."""
+        then = (norm, next_key, next_conv): the caller will feed RMS_norm+SiLU of this conv's output into `next_conv` (conv1 -> norm ->
+        SiLU -> conv2 of a ResidualBlock, a block's output -> the next block's / the head's norm); where the kernel can, that norm runs in
+        this conv's epilogue straight into next_conv's staging buffer and the returned activation carries `prefilled_for = next_key`
+        (with keep_raw=False its `.data` is None: nobody else reads the un-normalised result)."""
         wgt, b, (kt, kh, kw), cip, cop = self.packed(conv)
         # planar-16 staging where the producer can write it (RMS-norm) and the LDS-halo kernel reads it (the decision is per stage:
         # it must not depend on the chunk length)
         planar = self._planar_stage(fill, (kt, kh, kw), cip, h, w)
         st = self.stage(key, kt - 1, t, h, w, cip, planar=planar)
-        fill(st.chunk(t))
-        fused = False
+        src = getattr(fill, "src", None)
+        if src is None or src.prefilled_for != key:         # (else the producing conv's epilogue already wrote this chunk)
+            fill(st.chunk(t))
+        fused_for = None
         if st.planar:
             norm = None
             if then is not None and self.fuse_norm and conv.weight.shape[0] in (32, 64, 96, 128) and out is None:
@@ -334,15 +339,15 @@ class _Runner:
                 if cip2 == cop and self._planar_stage(self.norm_into(None, nxt_norm), k2, cip2, h, w):
                     dst2 = self.stage(nxt_key, k2[0] - 1, t, h, w, cip2, planar=True).chunk(t)
                     if isinstance(dst2, ops.Planar16):
-                        norm, fused = (self.gamma(nxt_norm), dst2, True), True
+                        norm, fused_for = (self.gamma(nxt_norm), dst2, True), nxt_key
             y = ops.conv_cl_planar(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, kt=kt, resid=_data(resid), out=out, norm=norm,
-                                   keep_raw=not fused)
+                                   keep_raw=keep_raw or fused_for is None)
         else:
             y = ops.conv_cl(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=(kt, kh, kw), pad=(0, kh // 2, kw // 2),
                             out_thw=(t, h, w), resid=_data(resid), out=out)
         st.roll(t)
         a = _Act(y, t, h, w, cop)
-        a.prefilled = fused
+        a.prefilled_for = fused_for
         return a
 
     def _planar_stage(self, fill, k, cip, h, w):
@@ -355,12 +360,11 @@ class _Runner:
         g = self.gamma(norm)
 
         def fill(dst):
-            if getattr(x, "prefilled", False):       # the producing conv's epilogue already wrote RMS_norm+SiLU(x) here (conv_causal: then=)
-                return dst
             if isinstance(dst, ops.Planar16):
                 return ops.rmsnorm_silu_cl_planar(x.data, g, dst, silu=silu)
             return ops.rmsnorm_silu_cl(x.data, g, silu=silu, out=dst)
         fill.planar_ok = True
+        fill.src = x
         return fill
 
     def copy_into(self, x: _Act):
@@ -391,11 +395,23 @@ class _Runner:
         self.flags = dict(flags)
 
     # ---- blocks
-    def residual_block(self, x: _Act, blk, key, out=None):
+    def residual_block(self, x: _Act, blk, key, out=None, then=None):
+        """then: the (norm, key, conv) that consumes this block's output next (conv_causal)."""
         r = blk.residual
-        y1 = self.conv_causal(key + ".residual.2", r[2], x.t, x.h, x.w, self.norm_into(x, r[0]), then=(r[3], key + ".residual.6", r[6]))
+        y1 = self.conv_causal(key + ".residual.2", r[2], x.t, x.h, x.w, self.norm_into(x, r[0]), then=(r[3], key + ".residual.6", r[6]),
+                              keep_raw=False)
         h = x if isinstance(blk.shortcut, nn.Identity) else self.conv_plain(x, blk.shortcut)
-        return self.conv_causal(key + ".residual.6", r[6], x.t, x.h, x.w, self.norm_into(y1, r[3]), resid=h, out=out)
+        return self.conv_causal(key + ".residual.6", r[6], x.t, x.h, x.w, self.norm_into(y1, r[3]), resid=h, out=out, then=then)
+
+    @staticmethod
+    def _next_norm(layers, i, prefix, tail=None):
+        """What consumes layer i's output through an RMS-norm: the next ResidualBlock's conv1, or `tail` (the head) after the last."""
+        if i + 1 < len(layers):
+            nxt = layers[i + 1]
+            if isinstance(nxt, ResidualBlock):
+                return nxt.residual[0], f"{prefix}.{i + 1}.residual.2", nxt.residual[2]
+            return None
+        return tail
 
     def attention_block(self, x: _Act, blk):
         """Single-head attention over h*w tokens per frame (wan_vae.py:244-266): scores materialised per frame
@@ -461,7 +477,8 @@ class _Runner:
         a = self.conv_causal("enc.conv1", enc.conv1, t, H, W, self.video_into(x_ncthw))
         for i, layer in enumerate(enc.downsamples):
             key = f"enc.down.{i}"
-            a = self.residual_block(a, layer, key) if isinstance(layer, ResidualBlock) else self.resample(a, layer, key)
+            a = self.residual_block(a, layer, key, then=self._next_norm(enc.downsamples, i, "enc.down")) \
+                if isinstance(layer, ResidualBlock) else self.resample(a, layer, key)
         a = self.residual_block(a, enc.middle[0], "enc.mid.0")
         a = self.attention_block(a, enc.middle[1])
         a = self.residual_block(a, enc.middle[2], "enc.mid.2")
@@ -475,9 +492,11 @@ class _Runner:
         a = self.residual_block(a, dec.middle[0], "dec.mid.0")
         a = self.attention_block(a, dec.middle[1])
         a = self.residual_block(a, dec.middle[2], "dec.mid.2")
+        head = (dec.head[0], "dec.head", dec.head[2])
         for i, layer in enumerate(dec.upsamples):
             key = f"dec.up.{i}"
-            a = self.residual_block(a, layer, key) if isinstance(layer, ResidualBlock) else self.resample(a, layer, key)
+            a = self.residual_block(a, layer, key, then=self._next_norm(dec.upsamples, i, "dec.up", head)) \
+                if isinstance(layer, ResidualBlock) else self.resample(a, layer, key)
         return self.conv_causal("dec.head", dec.head[2], a.t, a.h, a.w, self.norm_into(a, dec.head[0]))
 
 
@@ -564,6 +583,8 @@ class AutoencoderKLWan(nn.Module):
         return self.model.conv1.weight.device
 
     # ---- encode
+    CHUNK_LATENT = int(os.environ.get("M4D_VAE_CHUNK", "4"))      # latent frames per streaming chunk after the first frame
+
     def _encode_one(self, x):
         """x [3, T, H, W] -> [2z, T', h, w] (mu normalised | logvar), reference encode (:520-547)."""
         dev, T = self.device, self.dtype
@@ -571,16 +592,19 @@ class AutoencoderKLWan(nn.Module):
         x = x.to(dev)
         t = x.shape[1]
         run = _Runner(self, dev, T)
-        n_chunks = 1 + (t - 1) // 4
-        lat_t = n_chunks
+        lat_t = 1 + (t - 1) // 4
         h, w = x.shape[2] // 8, x.shape[3] // 8
         enc_out = torch.empty((lat_t, h * w, z2), device=dev, dtype=T)
         pos = 0
-        for i in range(n_chunks):
-            chunk = x[:, :1] if i == 0 else x[:, 1 + 4 * (i - 1):1 + 4 * i]
+        # the reference streams 1 + 4 + 4 + ... frames (:520-547); every conv is causal over the cached tail, so the chunk length
+        # only changes how much work one launch carries: CHUNK_LATENT latent frames' worth per chunk after the first frame
+        bounds = [0, 1] + list(range(1 + 4 * self.CHUNK_LATENT, 1 + 4 * (lat_t - 1), 4 * self.CHUNK_LATENT)) + [1 + 4 * (lat_t - 1)]
+        for f0, f1 in zip(bounds[:-1], bounds[1:]):
+            if f1 <= f0:
+                continue
             def view(tt, pos=pos):
                 return enc_out[pos:pos + tt].view(tt * h * w, z2)
-            pos += run.encoder(chunk, view)
+            pos += run.encoder(x[:, f0:f1], view)
         a = _Act(enc_out.view(lat_t * h * w, z2), lat_t, h, w, z2)
         y = run.conv_plain(a, self.model.conv1)
         ch_scale, ch_shift = self._latent_affine(dev)
@@ -625,8 +649,11 @@ class AutoencoderKLWan(nn.Module):
         zin = ops.ncthw_to_cl(z.to(dev), T, ch_scale=self.std.to(dev), ch_shift=self.mean.to(dev))      # z/(1/std)+mean
         a = run.conv_plain(_Act(zin.view(lt * h * w, zc), lt, h, w, zc), self.model.conv2)
         frames = []
-        for i in range(lt):
-            o = run.decoder(_Act(a.data[i * h * w:(i + 1) * h * w], 1, h, w, zc))
+        bounds = [0, 1] + list(range(1 + self.CHUNK_LATENT, lt, self.CHUNK_LATENT)) + [lt]      # reference: one latent frame per chunk (:678-703)
+        for i0, i1 in zip(bounds[:-1], bounds[1:]):
+            if i1 <= i0:
+                continue
+            o = run.decoder(_Act(a.data[i0 * h * w:i1 * h * w], i1 - i0, h, w, zc))
             frames.append(ops.cl_to_ncthw(o.data, T, C=3, T=o.t, H=o.h, W=o.w, pixel_stride=o.data.stride(0), act=1))
         return torch.cat(frames, dim=1)
 

@@ -188,7 +188,7 @@ class _TrainRunner(_Runner):
         if conv.bias is not None and conv.bias.requires_grad:
             self.grads.add(conv.bias, ops.colsum(dy)[0][:conv.bias.numel()])
 
-    def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None, then=None):      # (then: inference-only epilogue fusion)
+    def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None, then=None, keep_raw=True):      # (then / keep_raw: inference-only epilogue fusion)
         wgt, b, k, cip, cop = self.packed(conv)
         kt, kh, kw = k
         st = self.stage(key, kt - 1, t, h, w, cip)
