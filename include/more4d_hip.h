@@ -205,6 +205,18 @@ int m4d_groupnorm_cl(m4d_dtype dt, const void* x, void* out, float* partial, int
 int m4d_groupnorm_cl_planar(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight,
                             const float* bias, int F, int64_t HW, int C, int G, float eps, int silu, int frames_per_group,
                             int64_t out_plane_stride, int64_t out_group_stride, m4d_stream stream);
+/* The adaptors' conv -> GroupNorm(32) -> swish -> conv chain without the statistics pass: m4d_conv_cl_planar_gnstats is
+ * m4d_conv_cl_planar (Cout = 128) that also writes, per output patch, the (sum, sum of squares) of its stored result for the 32 groups
+ * of 4 channels: gn_partial float [To][blocks][32][2], blocks = m4d_conv_cl_planar_gnstats_blocks(Hin, Win); a frame-group call
+ * passes gn_partial + first_frame * blocks * 64.  m4d_groupnorm_cl_planar_apply then reduces the `partial_blocks` rows of every
+ * frame in a fixed order into stat float [F][G][2] = (mean, rstd) and applies norm + affine (+ swish) like m4d_groupnorm_cl_planar. */
+int m4d_conv_cl_planar_gnstats_blocks(int Hin, int Win);
+int m4d_conv_cl_planar_gnstats(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                               int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
+                               float* gn_partial, m4d_stream stream);
+int m4d_groupnorm_cl_planar_apply(m4d_dtype dt, const void* x, void* out, const float* partial, int partial_blocks, float* stat,
+                                  const float* weight, const float* bias, int F, int64_t HW, int C, int G, float eps, int silu,
+                                  int frames_per_group, int64_t out_plane_stride, int64_t out_group_stride, m4d_stream stream);
 
 /* out[r, c] = softmax_c(x[r, c] * scale) for c < C, 0 for C <= c < Cpad — the score matrix of the VAE's single-head
  * mid-block attention (wan_vae.py:256-260; head dim 384 > the flash kernel's 128). */

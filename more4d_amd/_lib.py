@@ -105,6 +105,11 @@ SIGNATURES = {
     "m4d_rmsnorm_silu_cl_planar": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "m4d_conv_cl_planar": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
                            [c_int] * 7 + [c_void_p]),
+    "m4d_conv_cl_planar_gnstats_blocks": (c_int, [c_int, c_int]),
+    "m4d_conv_cl_planar_gnstats": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
+                                   [c_int] * 7 + [c_void_p, c_void_p]),
+    "m4d_groupnorm_cl_planar_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                              c_int, c_float, c_int, c_int, c_int64, c_int64, c_void_p]),
     "m4d_conv_cl_planar_norm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
                                 [c_int] * 7 + [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "m4d_groupnorm_cl_workspace": (c_int64, [c_int, c_int64, c_int]),

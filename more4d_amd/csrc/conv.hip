@@ -33,6 +33,7 @@ struct ConvArgs {
     int abl;               // timing ablations (tool builds only)
     int64_t xplane;        // != 0: input is planar-16, [Cin/16][rows][16] with xplane elements between planes (conv_halo_kernel only)
     const float* post_gamma; void* post_out; int64_t post_plane; int post_silu;      // fused RMS_norm(+SiLU) of the next layer (conv_halo.h)
+    float* gn_partial;     // per-patch GroupNorm(32 x 4 channels) statistics of the result, [To][patches][32][2] (Cout = 128)
 };
 
 constexpr int ROWB = 128, BM = 128, BN = 128;
@@ -398,6 +399,7 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
 // 32 / 64, everything else tiles of 128
 template <int KT, int KH, int TH, int TW>
 int launch_halo_nt(ConvArgs& p, hipStream_t st) {
+    if (p.gn_partial) return launch_halo<KT, KH, TH, TW, 4, 2>(p, st);       // (Cout = 128: one 128-channel tile per patch)
     if (p.post_out) {        // fused next-layer norm: one workgroup must own all channels of a pixel
         switch (p.Cout) {
             case 32: return launch_halo<KT, KH, TH, TW, 1, 2>(p, st);
@@ -442,7 +444,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
     p.M = (int64_t)To * Ho * Wo;
     p.K = (int64_t)kt * kh * kw * Cin;
-    p.abl = 0; p.xplane = 0; p.post_gamma = nullptr; p.post_out = nullptr; p.post_plane = 0; p.post_silu = 0;
+    p.abl = 0; p.xplane = 0; p.post_gamma = nullptr; p.post_out = nullptr; p.post_plane = 0; p.post_silu = 0; p.gn_partial = nullptr;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0); p.abl = conv_abl; }
     { M4D_ENV_ONCE(conv_planar, "M4D_CONV_PLANAR", 0); if (conv_planar) p.xplane = (int64_t)Tin * Hin * Win * 16; }     // timing experiment: same bytes read as planar-16
@@ -511,8 +513,10 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
  * of 32 bytes out of a Cin*2-byte pixel, so the halo DMA fetches whole lines it uses (fabric traffic / 4 at Cin = 96). */
 static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
                                int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
-                               const float* norm_gamma, void* norm_out, int64_t norm_plane, int norm_silu, m4d_stream stream) {
+                               const float* norm_gamma, void* norm_out, int64_t norm_plane, int norm_silu, float* gn_partial, m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16, "conv_cl_planar: bf16 only");
+    M4D_CHECK_ARG(!gn_partial || (Cout == 128 && out && !norm_out && out_ld % 8 == 0 && (!resid || resid_ld % 8 == 0)),
+                  "conv_cl_planar_gnstats: Cout = 128 (GroupNorm of 32 groups x 4 channels), row strides %% 8");
     M4D_CHECK_ARG(x && w && (out || norm_out) && Tin > 0 && Hin > 0 && Win > 0 && Cout > 0 && To > 0, "conv_cl_planar: null/empty");
     if (norm_out) {
         M4D_CHECK_ARG(norm_gamma && norm_plane >= (int64_t)To * Hin * Win * 16 && norm_plane % 8 == 0 && ((uintptr_t)norm_out % 16) == 0,
@@ -535,7 +539,7 @@ static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stri
     p.M = (int64_t)To * Hin * Win;
     p.K = (int64_t)kt * 9 * Cin;
     p.abl = 0; p.xplane = x_plane_stride;
-    p.post_gamma = norm_gamma; p.post_out = norm_out; p.post_plane = norm_plane; p.post_silu = norm_silu;
+    p.post_gamma = norm_gamma; p.post_out = norm_out; p.post_plane = norm_plane; p.post_silu = norm_silu; p.gn_partial = gn_partial;
     const bool wide = (Win % 32 == 0) || Win >= 256;
     int rc;
     if (kt == 3) rc = wide ? launch_halo_nt<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<3, 3, 16, 16>(p, (hipStream_t)stream);
@@ -550,7 +554,20 @@ extern "C" int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_s
                                   m4d_stream stream) {
     M4D_CHECK_ARG(out, "conv_cl_planar: null output");
     return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, nullptr, nullptr, 0, 0,
-                               stream);
+                               nullptr, stream);
+}
+
+extern "C" int m4d_conv_cl_planar_gnstats_blocks(int Hin, int Win) {
+    const bool wide = (Win % 32 == 0) || Win >= 256;
+    return wide ? ((Hin + 7) / 8) * ((Win + 31) / 32) : ((Hin + 15) / 16) * ((Win + 15) / 16);
+}
+
+extern "C" int m4d_conv_cl_planar_gnstats(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
+                                          int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt,
+                                          int To, float* gn_partial, m4d_stream stream) {
+    M4D_CHECK_ARG(out && gn_partial, "conv_cl_planar_gnstats: null output / statistics");
+    return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, nullptr, nullptr, 0, 0,
+                               gn_partial, stream);
 }
 
 extern "C" int m4d_conv_cl_planar_norm(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
@@ -559,5 +576,5 @@ extern "C" int m4d_conv_cl_planar_norm(m4d_dtype dt, const void* x, int64_t x_pl
                                        m4d_stream stream) {
     M4D_CHECK_ARG(norm_out, "conv_cl_planar_norm: null normalised output");
     return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, norm_gamma, norm_out,
-                               norm_out_plane_stride, silu, stream);
+                               norm_out_plane_stride, silu, nullptr, stream);
 }

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
     __syncthreads();                                       // all fragment reads of the last step are done
     if (M4D_ABL(p) & 32) return;                           // ablation: no epilogue
     char* blk = conv_dyn_smem + wave * (32 * EROW);        // [32 pixels][NB channels] bf16; chunk c of pixel px at c ^ (px & ESW)
+    float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};       // GroupNorm statistics of the result (p.gn_partial): this lane's two 4-channel groups
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {                      // (a wave's LDS operations execute in order: round mi+1 may overwrite the block)
 #pragma unroll
@@ -358,11 +359,42 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
                 for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)rr[e]);        // conv output is T, then x + h (:224)
                 raw = *reinterpret_cast<const uint4*>(&o);
             }
+            if constexpr (NT == 4) {
+                if (p.gn_partial) {          // (16 chunks per pixel: ch = lane & 15 for every j, i.e. the same two groups)
+                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float v = (float)a[e]; gsum[e >> 2] += v; gsq[e >> 2] += v * v; }
+                }
+            }
             T* dst = (T*)p.out + m * p.ldo + nb;
             if (wide) *reinterpret_cast<uint4*>(dst) = raw;
             else {
                 *reinterpret_cast<uint2*>(dst) = make_uint2(raw.x, raw.y);
                 if (nb + 8 <= p.Cout) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(raw.z, raw.w);
+            }
+        }
+    }
+    if constexpr (NT == 4) {
+        // the next layer's GroupNorm(32 groups of 4 channels) statistics (trajectory_module.py:54-60): per-workgroup (sum, sum of squares)
+        // of the stored values, one row per patch in the order [frame][patch][group]; a finalize kernel adds them in that fixed order
+        if (p.gn_partial) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int o = 16; o < 64; o <<= 1) { gsum[h] += __shfl_xor(gsum[h], o, 64); gsq[h] += __shfl_xor(gsq[h], o, 64); }
+            __syncthreads();                                   // every wave is done with its staging block
+            float* red = reinterpret_cast<float*>(conv_dyn_smem);      // [wave][32 groups][2]
+            if (lane < 16) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { red[(wave * 32 + lane * 2 + h) * 2] = gsum[h]; red[(wave * 32 + lane * 2 + h) * 2 + 1] = gsq[h]; }
+            }
+            __syncthreads();
+            if (t < 32) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) { a += red[(w * 32 + t) * 2]; b += red[(w * 32 + t) * 2 + 1]; }
+                float* dst = p.gn_partial + (((int64_t)to * (tiles_h * tiles_w) + th * tiles_w + tw) * 32 + t) * 2;
+                dst[0] = a; dst[1] = b;
             }
         }
     }

@@ -363,6 +363,26 @@ extern "C" int m4d_groupnorm_cl_planar(m4d_dtype dt, const void* x, void* out, f
                           out_group_stride, stream);
 }
 
+// the planar-16 GroupNorm with the statistics already reduced per block by the producer (m4d_conv_cl_planar_gnstats): finalize + apply
+extern "C" int m4d_groupnorm_cl_planar_apply(m4d_dtype dt, const void* x, void* out, const float* partial, int partial_blocks, float* stat,
+                                             const float* weight, const float* bias, int F, int64_t HW, int C, int G, float eps, int silu,
+                                             int frames_per_group, int64_t out_plane_stride, int64_t out_group_stride, m4d_stream stream) {
+    M4D_CHECK_ARG(dt == M4D_BF16 && C % 16 == 0 && x && out && partial && stat && weight && bias && F > 0 && HW > 0 && partial_blocks > 0,
+                  "groupnorm_cl_planar_apply: bf16, C %% 16, non-null arguments");
+    M4D_CHECK_ARG(G > 0 && G <= 64 && C % G == 0 && (C / G) % 4 == 0 && 256 % (C / 8) == 0, "groupnorm_cl_planar_apply: unsupported C / G");
+    M4D_CHECK_ARG(frames_per_group > 0 && out_plane_stride >= (int64_t)frames_per_group * HW * 16 && out_plane_stride % 8 == 0 &&
+                  out_group_stride >= (int64_t)(C / 16) * out_plane_stride, "groupnorm_cl_planar_apply: bad group / plane strides");
+    const int nblk = (int)((HW + GN_PPB - 1) / GN_PPB);
+    GnArgs p{x, out, const_cast<float*>(partial), stat, weight, bias, HW, F, C, G, partial_blocks, GN_PPB, silu, eps, out_plane_stride,
+             out_group_stride, frames_per_group};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(F), dim3(256), 0, st, p, C / G);
+    p.nblk = nblk;
+    hipLaunchKernelGGL((groupnorm_apply_kernel<bf16_t, 8>), dim3(nblk, F), dim3(256), 0, st, p);
+    M4D_CHECK_LAUNCH("groupnorm_cl_planar_apply");
+    return 0;
+}
+
 static int groupnorm_impl(m4d_dtype dt, const void* x, void* out, float* partial, int64_t partial_floats, const float* weight, const float* bias,
                           int F, int64_t HW, int C, int G, float eps, int silu, int fpg, int64_t out_plane, int64_t out_group, m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "groupnorm_cl: bad dtype");

@@ -92,25 +92,50 @@ class _AdaptorBase(nn.Module):
 
     PLANAR, PLANAR_MIN_PIXELS, PLANAR_MAX_BYTES, PLANAR_DTYPES = True, 1024, (1 << 31) - (1 << 20), (torch.bfloat16,)    # (tests force either path)
 
-    def _norm_conv(self, h, norm, conv, F, H, W, cin, resid=None):
-        """GroupNorm + swish + 3x3 conv (:54-71).  bf16 inference on real maps: the norm writes planar-16 frame groups (each below the
-        2 GiB the conv kernel addresses) and the LDS-halo conv reads them, so its halo DMA uses the lines it fetches."""
-        if self.PLANAR and self.dtype in self.PLANAR_DTYPES and cin % 16 == 0 and H * W >= self.PLANAR_MIN_PIXELS:
+    def _planar_ok(self, cin, H, W):
+        return self.PLANAR and self.dtype in self.PLANAR_DTYPES and cin % 16 == 0 and H * W >= self.PLANAR_MIN_PIXELS
+
+    def _stats_buf(self, cout, F, H, W):
+        """Where a conv writes the next GroupNorm's per-patch sums (32 groups of 4 channels = the adaptors' 128 channels), or None."""
+        if cout != 128:
+            return None
+        return torch.empty((F, ops.gnstats_blocks(H, W), 32, 2), device=self.device, dtype=torch.float32)
+
+    def _conv_groups(self, groups, conv, F, H, W, resid=None, stats=False):
+        """3x3 conv over planar-16 frame groups -> ([F*H*W, cop], cop, stats or None); stats = per-patch GroupNorm sums of the result."""
+        w, b, cip, cop = self._packed(conv)
+        out = torch.empty((F * H * W, cop), device=w.device, dtype=w.dtype)
+        st = self._stats_buf(conv.weight.shape[0], F, H, W) if stats else None
+        f0 = 0
+        for g in groups:
+            n = g.t.shape[1]
+            rows = slice(f0 * H * W, (f0 + n) * H * W)
+            ops.conv_cl_planar(g, w, b, Tin=n, Hin=H, Win=W, kt=1, resid=None if resid is None else resid[rows], out=out[rows],
+                               gn_stats=None if st is None else st[f0:f0 + n])
+            f0 += n
+        return out, cop, st
+
+    def _norm_conv(self, h, norm, conv, F, H, W, cin, resid=None, stats_in=None, stats_out=False):
+        """GroupNorm + swish + 3x3 conv (:54-71) -> (out, cop, stats).  bf16 inference on real maps: the norm writes planar-16 frame groups
+        (each below the 2 GiB the conv kernel addresses) and the LDS-halo conv reads them, so its halo DMA uses the lines it fetches;
+        stats_in = the producing conv's per-patch sums of h (no statistics pass), stats_out = have this conv write them for the next norm."""
+        if self._planar_ok(cin, H, W):
             most = max(1, self.PLANAR_MAX_BYTES // ((cin // 16) * H * W * 32))
             ng = -(-F // most)
             groups = ops.groupnorm_cl_planar(h.view(F, H * W, -1), self._f32(norm.weight), self._f32(norm.bias), F=F, HW=H * W,
-                                             groups=norm.num_groups, eps=norm.eps, silu=True, frames_per_group=-(-F // ng))
-            w, b, cip, cop = self._packed(conv)
-            assert cip == cin
-            out = torch.empty((F * H * W, cop), device=h.device, dtype=h.dtype)
-            f0 = 0
-            for g in groups:
-                n = g.t.shape[1]
-                rows = slice(f0 * H * W, (f0 + n) * H * W)
-                ops.conv_cl_planar(g, w, b, Tin=n, Hin=H, Win=W, kt=1, resid=None if resid is None else resid[rows], out=out[rows])
-                f0 += n
-            return out, cop
-        return self._conv(self._gn_swish(h, norm, F, H * W), conv, F, H, W, cin, resid=resid)
+                                             groups=norm.num_groups, eps=norm.eps, silu=True, frames_per_group=-(-F // ng),
+                                             stats=stats_in if norm.num_groups == 32 else None)
+            assert self._packed(conv)[2] == cin
+            return self._conv_groups(groups, conv, F, H, W, resid=resid, stats=stats_out)
+        y, cop = self._conv(self._gn_swish(h, norm, F, H * W), conv, F, H, W, cin, resid=resid)
+        return y, cop, None
+
+    def _conv_first(self, h16, conv, F, H, W):
+        """conv_in on the 16-channel padded input -> (out, stats): a [rows, 16] tensor IS planar-16 with one plane."""
+        if self._planar_ok(CIN_PAD, H, W) and F * H * W * 32 < self.PLANAR_MAX_BYTES:
+            out, _, st = self._conv_groups([ops.Planar16(h16.view(1, F, H * W, 16))], conv, F, H, W, stats=True)
+            return out, st
+        return self._conv(h16, conv, F, H, W, CIN_PAD)[0], None
 
     def _run(self, x):
         """Per-sample forward; under autograd (trainable adaptor or an input that needs its gradient, train_vae.py:438-455) every
@@ -120,11 +145,12 @@ class _AdaptorBase(nn.Module):
             return adaptor_train(self, x)
         return torch.stack([self._forward_one(u) for u in x])
 
-    def _resnet(self, h, blk, F, H, W):
+    def _resnet(self, h, blk, F, H, W, stats=None):
+        """-> (block output, per-patch GroupNorm sums of it for the next norm, or None)."""
         c = blk.in_channels
-        y, _ = self._norm_conv(h, blk.norm1, blk.conv1, F, H, W, c)
-        y, _ = self._norm_conv(y, blk.norm2, blk.conv2, F, H, W, c, resid=h)
-        return y
+        y, _, st = self._norm_conv(h, blk.norm1, blk.conv1, F, H, W, c, stats_in=stats, stats_out=True)
+        y, _, st = self._norm_conv(y, blk.norm2, blk.conv2, F, H, W, c, resid=h, stats_in=st, stats_out=True)
+        return y, st
 
 
 class VAEEncoderadaptor(_AdaptorBase):
@@ -164,10 +190,10 @@ class VAEEncoderadaptor(_AdaptorBase):
         T, dev = self.dtype, self.device
         xb = x.to(device=dev, dtype=T).contiguous()
         h = ops.ncthw_to_cl(xb, T, Cp=CIN_PAD).view(F * H * W, CIN_PAD)
-        h, _ = self._conv(h, self.conv_in, F, H, W, CIN_PAD)
+        h, st = self._conv_first(h, self.conv_in, F, H, W)
         for blk in self.down[0].block:
-            h = self._resnet(h, blk, F, H, W)
-        h, cop = self._norm_conv(h, self.norm_out, self.conv_out, F, H, W, self.ch)
+            h, st = self._resnet(h, blk, F, H, W, st)
+        h, cop, _ = self._norm_conv(h, self.norm_out, self.conv_out, F, H, W, self.ch, stats_in=st)
         return ops.cl_to_ncthw(h, T, C=C, T=F, H=H, W=W, pixel_stride=cop, act=2, aux=xb)
 
     def forward(self, x):
@@ -212,10 +238,10 @@ class VAEDecoderadaptor(_AdaptorBase):
         T, dev = self.dtype, self.device
         zb = z.to(device=dev, dtype=T).contiguous()
         h = ops.ncthw_to_cl(zb, T, Cp=CIN_PAD).view(F * H * W, CIN_PAD)
-        h, _ = self._conv(h, self.conv_in, F, H, W, CIN_PAD)
+        h, st = self._conv_first(h, self.conv_in, F, H, W)
         for blk in self.up[0].block:
-            h = self._resnet(h, blk, F, H, W)
-        h, cop = self._norm_conv(h, self.norm_out, self.conv_out, F, H, W, self.ch)
+            h, st = self._resnet(h, blk, F, H, W, st)
+        h, cop, _ = self._norm_conv(h, self.norm_out, self.conv_out, F, H, W, self.ch, stats_in=st)
         return ops.cl_to_ncthw(h, T, C=self.out_ch, T=F, H=H, W=W, pixel_stride=cop)
 
     def forward(self, z):

@@ -398,7 +398,12 @@ class Planar16:
         return self.t.shape[0] * 16
 
 
-def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True):
+def gnstats_blocks(Hin, Win):
+    """Rows per frame of the GroupNorm statistics conv_cl_planar(gn_stats=...) writes."""
+    return _lib.load().m4d_conv_cl_planar_gnstats_blocks(Hin, Win)
+
+
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True, gn_stats=None):
     """3x3(x3) stride-1 conv (pad (0,1,1), valid in T) of a Planar16 input; w / bias / resid / out as conv_cl.
     norm = (gamma float32 [Cout], dst Planar16, silu): the next layer's RMS_norm(+SiLU) fused into the epilogue, written to `dst`
     (rows == To*Hin*Win); with keep_raw=False the un-normalised result is not stored and None is returned."""
@@ -423,6 +428,15 @@ def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=
         if rm != M or resid.shape[-1] != Cout:
             raise ValueError("conv_cl_planar: resid shape mismatch")
     lib = _lib.load()
+    if gn_stats is not None:
+        # gn_stats: float32 [To, gnstats_blocks(Hin, Win), 32, 2] view: per-patch GroupNorm(32 x 4 channels) sums of the result (Cout = 128)
+        _dev(gn_stats)
+        if norm is not None or gn_stats.dtype != torch.float32 or not gn_stats.is_contiguous() or \
+                gn_stats.numel() != To * gnstats_blocks(Hin, Win) * 64:
+            raise ValueError("conv_cl_planar: gn_stats must be contiguous float32 [To, blocks, 32, 2] (and excludes norm=)")
+        check(lib.m4d_conv_cl_planar_gnstats(dt_code(w.dtype), _ptr(x.t), x.plane_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
+                                             Tin, Hin, Win, Cin, Cout, kt, To, _ptr(gn_stats), _stream()), "m4d_conv_cl_planar_gnstats")
+        return out
     if norm is None:
         check(lib.m4d_conv_cl_planar(dt_code(w.dtype), _ptr(x.t), x.plane_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
                                      Tin, Hin, Win, Cin, Cout, kt, To, _stream()), "m4d_conv_cl_planar")
@@ -485,9 +499,10 @@ def groupnorm_cl(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, out=
     return out
 
 
-def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, frames_per_group):
+def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, frames_per_group, stats=None):
     """groupnorm_cl with the result as a list of Planar16 views, one per group of `frames_per_group` frames (the last may be shorter),
-    ready for conv_cl_planar (kt = 1)."""
+    ready for conv_cl_planar (kt = 1).  stats: float32 [F, blocks, groups, 2] per-block sums written by the producing conv
+    (conv_cl_planar(gn_stats=...)): the statistics pass over x is skipped."""
     _dev(x, weight, bias)
     if not x.is_contiguous() or x.dtype != torch.bfloat16:
         raise ValueError("groupnorm_cl_planar: contiguous bf16 x")
@@ -495,10 +510,19 @@ def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=Tru
     ng = (F + frames_per_group - 1) // frames_per_group
     buf = torch.empty((ng, C // 16, frames_per_group, HW, 16), device=x.device, dtype=x.dtype)
     lib = _lib.load()
-    n = lib.m4d_groupnorm_cl_workspace(F, HW, groups)
-    ws = torch.empty(n, device=x.device, dtype=torch.float32)
-    check(lib.m4d_groupnorm_cl_planar(dt_code(x.dtype), _ptr(x), _ptr(buf), _ptr(ws), n, _ptr(weight), _ptr(bias), F, HW, C, groups, eps,
-                                      int(silu), frames_per_group, buf.stride(1), buf.stride(0), _stream()), "m4d_groupnorm_cl_planar")
+    if stats is not None:
+        _dev(stats)
+        if stats.dtype != torch.float32 or not stats.is_contiguous() or stats.dim() != 4 or stats.shape[0] != F or stats.shape[2:] != (groups, 2):
+            raise ValueError("groupnorm_cl_planar: stats must be contiguous float32 [F, blocks, groups, 2]")
+        st = torch.empty((F, groups, 2), device=x.device, dtype=torch.float32)
+        check(lib.m4d_groupnorm_cl_planar_apply(dt_code(x.dtype), _ptr(x), _ptr(buf), _ptr(stats), stats.shape[1], _ptr(st), _ptr(weight),
+                                                _ptr(bias), F, HW, C, groups, eps, int(silu), frames_per_group, buf.stride(1), buf.stride(0),
+                                                _stream()), "m4d_groupnorm_cl_planar_apply")
+    else:
+        n = lib.m4d_groupnorm_cl_workspace(F, HW, groups)
+        ws = torch.empty(n, device=x.device, dtype=torch.float32)
+        check(lib.m4d_groupnorm_cl_planar(dt_code(x.dtype), _ptr(x), _ptr(buf), _ptr(ws), n, _ptr(weight), _ptr(bias), F, HW, C, groups, eps,
+                                          int(silu), frames_per_group, buf.stride(1), buf.stride(0), _stream()), "m4d_groupnorm_cl_planar")
     return [Planar16(buf[g, :, :min(frames_per_group, F - g * frames_per_group)]) for g in range(ng)]
 
 

@@ -271,7 +271,17 @@ def _planar_to_cl(x):
     return x.t.permute(1, 2, 0, 3).reshape(fr * hw, c16 * 16)
 
 
-def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True):
+def gnstats_blocks(Hin, Win):
+    return 1
+
+
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True, gn_stats=None):
+    if gn_stats is not None:      # one block per frame: (sum, sum of squares) of every group of 4 channels
+        y = conv_cl_planar(x, w, bias, Tin=Tin, Hin=Hin, Win=Win, kt=kt, resid=resid, out=out)
+        v = y.float().view(Tin - kt + 1, Hin * Win, -1, 4)
+        gn_stats.view(Tin - kt + 1, -1, 2)[..., 0] = v.sum(dim=(1, 3))
+        gn_stats.view(Tin - kt + 1, -1, 2)[..., 1] = (v * v).sum(dim=(1, 3))
+        return y
     y = conv_cl(_planar_to_cl(x).contiguous(), w, bias, Tin=Tin, Hin=Hin, Win=Win, Cin=x.channels, k=(kt, 3, 3), pad=(0, 1, 1),
                 out_thw=(Tin - kt + 1, Hin, Win), resid=resid, out=out if (norm is None or keep_raw) else None)
     if norm is None:
@@ -288,8 +298,14 @@ def rmsnorm_silu_cl_planar(x, gamma, out, *, silu=True):
     return out
 
 
-def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, frames_per_group):
+def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, frames_per_group, stats=None):
     import more4d_amd.ops as real
+    if stats is not None:         # the producer's sums must be the statistics of x
+        C_ = x.shape[-1]
+        tot = stats.sum(dim=1)
+        v = x.float().view(F, HW, groups, C_ // groups)
+        assert torch.allclose(tot[..., 0], v.sum(dim=(1, 3)), rtol=1e-4, atol=1e-3) and \
+            torch.allclose(tot[..., 1], (v * v).sum(dim=(1, 3)), rtol=1e-4, atol=1e-3)
     y = groupnorm_cl(x, weight, bias, F=F, HW=HW, groups=groups, eps=eps, silu=silu).view(F, HW, -1)
     C = y.shape[-1]
     out = []
@@ -299,7 +315,7 @@ def groupnorm_cl_planar(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=Tru
     return out
 
 
-NAMES += ["conv_cl_planar", "rmsnorm_silu_cl_planar", "groupnorm_cl_planar"]
+NAMES += ["conv_cl_planar", "rmsnorm_silu_cl_planar", "groupnorm_cl_planar", "gnstats_blocks"]
 
 
 def groupnorm_cl(x, weight, bias, *, F, HW, groups=32, eps=1e-6, silu=True, out=None):

@@ -164,5 +164,36 @@ def test_adaptor_planar_groups_equal_channels_last_bf16(which):
     finally:
         base.PLANAR, base.PLANAR_MAX_BYTES = saved
     assert torch.isfinite(ref.float()).all()
+    # the planar path takes the GroupNorm statistics from the producing conv's epilogue (per-patch sums, another summation order than
+    # the statistics kernel's): mean / rstd agree to fp32 rounding, the bf16 results to one ulp (on ~10 % of the elements after six layers)
     for o in outs:
-        assert torch.equal(o, ref)
+        d = (o.float() - ref.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(ref.float().abs().max()) and float((d > 0).float().mean()) < 0.25
+    assert torch.equal(outs[0], outs[1])        # the frame grouping itself changes nothing (at limit 1 conv_in runs channels-last: its
+    #                                             statistics come from the statistics kernel again, covered by the bound above)
+
+
+def test_conv_gnstats_are_the_group_sums_of_the_result():
+    """m4d_conv_cl_planar_gnstats: the per-patch (sum, sum of squares) rows add up to the per-frame GroupNorm(32 x 4) sums of the stored
+    bf16 result, and m4d_groupnorm_cl_planar_apply on them equals the two-pass GroupNorm to fp32 rounding."""
+    from more4d_amd import ops as o
+    F, H, W, C = 3, 40, 72, 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(F * H * W, C, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(C, 9 * C, generator=g) * (9 * C) ** -0.5).bfloat16().to(DEV)
+    b = torch.randn(C, generator=g).bfloat16().to(DEV)
+    res = torch.randn(F * H * W, C, generator=g).bfloat16().to(DEV)
+    gw, gb = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    xin = o.groupnorm_cl_planar(x.view(F, H * W, C), gw, gb, F=F, HW=H * W, frames_per_group=F)[0]
+    st = torch.full((F, o.gnstats_blocks(H, W), 32, 2), float("nan"), device=DEV)
+    y = o.conv_cl_planar(xin, w, b, Tin=F, Hin=H, Win=W, kt=1, resid=res, gn_stats=st)
+    assert torch.equal(y, o.conv_cl_planar(xin, w, b, Tin=F, Hin=H, Win=W, kt=1, resid=res))
+    v = y.float().view(F, H * W, 32, 4)
+    tot = st.sum(dim=1)
+    assert torch.allclose(tot[..., 0], v.sum(dim=(1, 3)), rtol=1e-4, atol=0.05)
+    assert torch.allclose(tot[..., 1], (v * v).sum(dim=(1, 3)), rtol=1e-4, atol=0.05)
+    a = o.groupnorm_cl_planar(y.view(F, H * W, C), gw, gb, F=F, HW=H * W, frames_per_group=2, stats=st)
+    r = o.groupnorm_cl_planar(y.view(F, H * W, C), gw, gb, F=F, HW=H * W, frames_per_group=2)
+    for pa, pr in zip(a, r):
+        d = (pa.t.float() - pr.t.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(pr.t.float().abs().max()) and float((d > 0).float().mean()) < 0.02
