@@ -252,7 +252,7 @@ class _Runner:
     """Executes the encoder / decoder module trees with the HIP kernels.  One instance per encode()/decode() call
     (fresh streaming state = the reference's clear_cache(), wan_vae.py:717-724)."""
 
-    PLANAR, PLANAR_MIN_PIXELS, PLANAR_DTYPES, FUSE_NORM = True, 1024, (torch.bfloat16,), True     # (class attributes: tests force either path)
+    PLANAR, PLANAR_MIN_PIXELS, PLANAR_DTYPES, FUSE_NORM, BATCH_ATTN = True, 1024, (torch.bfloat16,), True, True     # (class attributes: tests force either path)
 
     def __init__(self, vae, device, dtype):
         self.vae, self.dev, self.T = vae, device, dtype
@@ -422,6 +422,20 @@ class _Runner:
         wq, bq, _, _, _ = self.packed(blk.to_qkv)          # [3C, C]
         wp, bp, _, _, _ = self.packed(blk.proj)
         outs = torch.empty((x.t * hw, C), device=self.dev, dtype=self.T)
+        if self.BATCH_ATTN and hwp == hw and x.t > 1:
+            # the per-token parts (norm, q/k/v projections, output projection + residual) over all frames of the chunk at once; only the
+            # scores / softmax / P.V are per frame.  Row-wise identical to the per-frame calls (same kernels, same K order).
+            xn = ops.rmsnorm_silu_cl(x.data, g, silu=False)
+            qk = ops.gemm_bt(xn, wq[:2 * C], bq[:2 * C])                                   # [t*hw, 2C]
+            vt = ops.gemm_bt(wq[2 * C:], xn, bq[2 * C:], bias_on_m=True)                   # V^T [C, t*hw]
+            o = torch.empty((x.t * hw, C), device=self.dev, dtype=self.T)
+            for f in range(x.t):
+                r = slice(f * hw, (f + 1) * hw)
+                s = ops.gemm_bt(qk[r, :C], qk[r, C:], None, epilogue=ops.EPI_STORE_F32)    # [hw, hw] fp32
+                p = ops.softmax_rows(s, self.T, C=hw, Cpad=hw, scale=1.0 / math.sqrt(C))
+                ops.gemm_bt(p, vt[:, r], None, out=o[r])
+            ops.conv_cl(o, wp, bp, Tin=1, Hin=1, Win=x.t * hw, Cin=C, k=(1, 1, 1), out_thw=(1, 1, x.t * hw), resid=x.data, out=outs)
+            return _Act(outs, x.t, x.h, x.w, C)
         for f in range(x.t):
             xf = x.data[f * hw:(f + 1) * hw]
             xn = torch.zeros((hwp, C), device=self.dev, dtype=self.T)
