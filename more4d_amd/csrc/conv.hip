@@ -391,7 +391,7 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
     }
     p.tiles_m = p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
     p.tiles_n = (p.Cout + NT * 32 - 1) / (NT * 32);
-    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT, MT>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512 / MT), LDS, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT, MT>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * halo::Cfg<KT, KH, TH, TW, NT, MT>::NWAVE), LDS, st, p);
     return 0;
 }
 
@@ -417,6 +417,26 @@ int launch_halo_nt(ConvArgs& p, hipStream_t st) {
     M4D_ENV_ONCE(small, "M4D_CONV_SMALL", 1);
     if (small && p.Cout % 32 == 0 && patches * ((p.Cout + 95) / 96) <= 256) return launch_halo<KT, KH, TH, TW, 1, 2>(p, st);
     return ((p.Cout + 31) / 32) % 3 == 0 ? launch_halo<KT, KH, TH, TW, 3, 2>(p, st) : launch_halo<KT, KH, TH, TW, 4, 2>(p, st);
+}
+
+// patch shape + tile shape of the LDS-halo kernel for this problem
+int launch_halo_auto(ConvArgs& p, hipStream_t st) {
+    const bool wide = (p.Wo % 32 == 0) || p.Wo >= 256;        // 32-column patches; narrow maps (104, 208 columns) use 16 columns
+    // 96-channel tiles on maps that divide into 12 x 32 / 24 x 16 patches: THREE pixel tiles per wave (4 waves, 384 pixels): 6 fragment
+    // reads feed 9 MFMAs (8 x 32 patches: 5 per 6), a third less weight traffic from L2, 7 % less halo: +5 % on the 96- / 192-channel layers
+    M4D_ENV_ONCE(mt3, "M4D_CONV_MT3", 1);
+    if (mt3 && ((p.Cout + 31) / 32) % 3 == 0 && p.Cout > 64 && (!p.post_out || p.Cout == 96) && !p.gn_partial) {
+        const int th = wide ? 12 : 24, tw = wide ? 32 : 16;
+        const int nh = (p.Ho + th - 1) / th;
+        const int64_t patches = (int64_t)p.To * nh * ((p.Wo + tw - 1) / tw);
+        const bool fits = (nh * th - p.Ho) * 20 <= p.Ho;      // at most 5 % of the rows are padding
+        if (fits && (p.post_out || patches * ((p.Cout + 95) / 96) > 256)) {      // (small maps: launch_halo_nt's 32-channel tiles)
+            if (p.kt == 3) return wide ? launch_halo<3, 3, 12, 32, 3, 3>(p, st) : launch_halo<3, 3, 24, 16, 3, 3>(p, st);
+            return wide ? launch_halo<1, 3, 12, 32, 3, 3>(p, st) : launch_halo<1, 3, 24, 16, 3, 3>(p, st);
+        }
+    }
+    if (p.kt == 3) return wide ? launch_halo_nt<3, 3, 8, 32>(p, st) : launch_halo_nt<3, 3, 16, 16>(p, st);
+    return wide ? launch_halo_nt<1, 3, 8, 32>(p, st) : launch_halo_nt<1, 3, 16, 16>(p, st);
 }
 
 }  // namespace
@@ -476,8 +496,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     if (halo_shape && xbytes < (1ll << 31) - (1ll << 20)) {        // (unsigned 32-bit byte offsets into a raw buffer descriptor)
         const bool wide = (Wo % 32 == 0) || Wo >= 256;        // 8 x 32 patches; narrow maps (104, 208 columns) use 16 x 16
         int rc;
-        if (kt == 3) rc = wide ? launch_halo_nt<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<3, 3, 16, 16>(p, (hipStream_t)stream);
-        else rc = wide ? launch_halo_nt<1, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<1, 3, 16, 16>(p, (hipStream_t)stream);
+        rc = launch_halo_auto(p, (hipStream_t)stream);
         if (rc) return rc;
         M4D_CHECK_LAUNCH("conv_cl");
         return 0;
@@ -542,8 +561,7 @@ static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stri
     p.post_gamma = norm_gamma; p.post_out = norm_out; p.post_plane = norm_plane; p.post_silu = norm_silu; p.gn_partial = gn_partial;
     const bool wide = (Win % 32 == 0) || Win >= 256;
     int rc;
-    if (kt == 3) rc = wide ? launch_halo_nt<3, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<3, 3, 16, 16>(p, (hipStream_t)stream);
-    else rc = wide ? launch_halo_nt<1, 3, 8, 32>(p, (hipStream_t)stream) : launch_halo_nt<1, 3, 16, 16>(p, (hipStream_t)stream);
+    rc = launch_halo_auto(p, (hipStream_t)stream);
     if (rc) return rc;
     M4D_CHECK_LAUNCH("conv_cl_planar");
     return 0;

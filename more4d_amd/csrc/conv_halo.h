@@ -36,7 +36,7 @@ constexpr int KW = 3;
 // LDS geometry of one instantiation (shared by the kernel and its launcher)
 template <int KT, int KH, int TH, int TW, int NT, int MT>
 struct Cfg {
-    static constexpr int NWAVE = 8 / MT;                                  // every wave owns MT 32-pixel tiles x NT 32-channel tiles
+    static constexpr int NWAVE = MT == 3 ? 4 : 8 / MT;                                  // every wave owns MT 32-pixel tiles x NT 32-channel tiles
     static constexpr int NB = NT * 32;                                    // output channels per workgroup
     static constexpr int WTAP = NB * PXB;                                 // bytes of one tap of the weight tile
     static constexpr int HH = TH + KH - 1;
@@ -53,7 +53,7 @@ struct Cfg {
 }  // namespace halo
 
 template <int KT, int KH, int TH, int TW, int NT, int MT>
-__global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p) {      // two workgroups per CU: 128 (MT = 1) / 256 (MT = 2) VGPRs
+__global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void conv_halo_kernel(ConvArgs p) {      // two workgroups per CU: 128 (MT = 1) / 256 (MT = 2) VGPRs
 #if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins exist only in the device pass; the host pass needs just the stub)
     using namespace halo;
     typedef bf16_t T;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512 / MT, 4 / MT) void conv_halo_kernel(ConvArgs p)
     static_assert(NG >= 2, "the halo reload assumes a weight group follows it");
     constexpr int ROWS_PER_MT = 32 / TW > 0 ? 32 / TW : 1;         // image rows covered by one 32-pixel MFMA tile (TW = 32: 1, TW = 16: 2)
     constexpr int ESW = NT % 2 == 0 ? 7 : 3;                       // epilogue swizzle mask: the XOR must stay inside the pixel's NT*4 chunks
-    static_assert(TH * TW == 256 && (TW == 32 || TW == 16), "256 output pixels per workgroup");
+    static_assert(TH * TW == NWAVE * MT * 32 && (TW == 32 || TW == 16), "256 (MT = 3: 384) output pixels per workgroup");
     static_assert(NT >= 1 && NT <= 4, "two workgroups per CU: <= 80 KiB of LDS (launch_halo sizes it for the epilogue blocks too)");
 
     const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
