@@ -599,6 +599,13 @@ class AutoencoderKLWan(nn.Module):
     # ---- encode
     CHUNK_LATENT = int(os.environ.get("M4D_VAE_CHUNK", "4"))      # latent frames per streaming chunk after the first frame
 
+    def _chunk_latent(self, H, W):
+        """Latent frames per streaming chunk: CHUNK_LATENT, less on maps whose full-resolution staging buffer ([tail + 4 frames per
+        latent frame] x H x W x dim channels, planar) would not fit the 2 GiB the conv kernel addresses (720p: 2, 1080p: 1)."""
+        dim = self.model.encoder.dim
+        most = _Stage.PLANAR_MAX_BYTES // (max(1, dim // 16) * H * W * 32)          # frames of a full-resolution planar buffer
+        return max(1, min(self.CHUNK_LATENT, (most - 2) // 4))
+
     def _encode_one(self, x):
         """x [3, T, H, W] -> [2z, T', h, w] (mu normalised | logvar), reference encode (:520-547)."""
         dev, T = self.device, self.dtype
@@ -612,7 +619,8 @@ class AutoencoderKLWan(nn.Module):
         pos = 0
         # the reference streams 1 + 4 + 4 + ... frames (:520-547); every conv is causal over the cached tail, so the chunk length
         # only changes how much work one launch carries: CHUNK_LATENT latent frames' worth per chunk after the first frame
-        bounds = [0, 1] + list(range(1 + 4 * self.CHUNK_LATENT, 1 + 4 * (lat_t - 1), 4 * self.CHUNK_LATENT)) + [1 + 4 * (lat_t - 1)]
+        cl = self._chunk_latent(x.shape[2], x.shape[3])
+        bounds = [0, 1] + list(range(1 + 4 * cl, 1 + 4 * (lat_t - 1), 4 * cl)) + [1 + 4 * (lat_t - 1)]
         for f0, f1 in zip(bounds[:-1], bounds[1:]):
             if f1 <= f0:
                 continue
@@ -663,7 +671,8 @@ class AutoencoderKLWan(nn.Module):
         zin = ops.ncthw_to_cl(z.to(dev), T, ch_scale=self.std.to(dev), ch_shift=self.mean.to(dev))      # z/(1/std)+mean
         a = run.conv_plain(_Act(zin.view(lt * h * w, zc), lt, h, w, zc), self.model.conv2)
         frames = []
-        bounds = [0, 1] + list(range(1 + self.CHUNK_LATENT, lt, self.CHUNK_LATENT)) + [lt]      # reference: one latent frame per chunk (:678-703)
+        cl = self._chunk_latent(8 * h, 8 * w)
+        bounds = [0, 1] + list(range(1 + cl, lt, cl)) + [lt]      # reference: one latent frame per chunk (:678-703)
         for i0, i1 in zip(bounds[:-1], bounds[1:]):
             if i1 <= i0:
                 continue
