@@ -378,12 +378,12 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
 
 #include "conv_halo.h"
 
-template <int KT, int KH, int TH, int TW, int NT, int MT>
+template <int KT, int KH, int TH, int TW, int NT, int MT, int SD = 1>
 int launch_halo(ConvArgs& p, hipStream_t st) {
-    constexpr int LDS = halo::Cfg<KT, KH, TH, TW, NT, MT>::LDS_BYTES;
+    constexpr int LDS = halo::Cfg<KT, KH, TH, TW, NT, MT, SD>::LDS_BYTES;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW, NT, MT, SD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             m4d_set_error("conv_cl: cannot enable %d bytes of LDS", LDS);
             return -3;
         }
@@ -391,7 +391,7 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
     }
     p.tiles_m = p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
     p.tiles_n = (p.Cout + NT * 32 - 1) / (NT * 32);
-    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT, MT>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * halo::Cfg<KT, KH, TH, TW, NT, MT>::NWAVE), LDS, st, p);
+    hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT, MT, SD>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * halo::Cfg<KT, KH, TH, TW, NT, MT, SD>::NWAVE), LDS, st, p);
     return 0;
 }
 
@@ -491,6 +491,20 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
                                        st, sh, sw, pad_t, pad_h, pad_w, nf, Ho, Wo, ups, tsplit, stream);
             if (rc) return rc;
         }
+        return 0;
+    }
+    // the Resample down-sampling conv (3x3, stride 2 in H and W, zero padding on the bottom / right only = reads past the map are zero)
+    const bool s2_shape = conv_variant == 3 && dt == M4D_BF16 && kt == 1 && kh == 3 && kw == 3 && st == 1 && sh == 2 && sw == 2 && pad_t == 0 &&
+                          pad_h == 0 && pad_w == 0 && !ups && !tsplit && To == Tin && Ho == (Hin + 1) / 2 && Wo == (Win + 1) / 2 &&
+                          Cin % 16 == 0 && Cout % 32 == 0 && p.M >= 1024;
+    if (s2_shape && xbytes < (1ll << 31) - (1ll << 20)) {
+        const bool wide = (Wo % 32 == 0) || Wo >= 256;
+        const bool n3 = (Cout / 32) % 3 == 0;
+        int rc;
+        if (wide) rc = n3 ? launch_halo<1, 3, 8, 32, 3, 2, 2>(p, (hipStream_t)stream) : launch_halo<1, 3, 8, 32, 4, 2, 2>(p, (hipStream_t)stream);
+        else rc = n3 ? launch_halo<1, 3, 16, 16, 3, 2, 2>(p, (hipStream_t)stream) : launch_halo<1, 3, 16, 16, 4, 2, 2>(p, (hipStream_t)stream);
+        if (rc) return rc;
+        M4D_CHECK_LAUNCH("conv_cl");
         return 0;
     }
     if (halo_shape && xbytes < (1ll << 31) - (1ll << 20)) {        // (unsigned 32-bit byte offsets into a raw buffer descriptor)

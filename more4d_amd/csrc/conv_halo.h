@@ -34,13 +34,17 @@ constexpr int PXB = CK * 2;            // bytes per halo pixel / per weight row 
 constexpr int KW = 3;
 
 // LDS geometry of one instantiation (shared by the kernel and its launcher)
-template <int KT, int KH, int TH, int TW, int NT, int MT>
+template <int KT, int KH, int TH, int TW, int NT, int MT, int SD = 1>
 struct Cfg {
     static constexpr int NWAVE = MT == 3 ? 4 : 8 / MT;                                  // every wave owns MT 32-pixel tiles x NT 32-channel tiles
     static constexpr int NB = NT * 32;                                    // output channels per workgroup
     static constexpr int WTAP = NB * PXB;                                 // bytes of one tap of the weight tile
-    static constexpr int HH = TH + KH - 1;
-    static constexpr int PITCH = (TW + KW - 1 + 7) / 8 * 8;               // (a multiple of 8 pixels = 256 B keeps the bank pattern of a row)
+    // SD = 2 (the Resample stride-2 conv, ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2), wan_vae.py:96-100): the patch needs 2 TH + 1 input
+    // rows of 2 TW + 1 pixels; a halo row is stored de-interleaved, [PE even pixels | PE odd pixels], so that the 32 output pixels of a
+    // fragment still read 32 CONSECUTIVE halo pixels for every tap (dw = 0: even j, dw = 1: odd j, dw = 2: even j + 1)
+    static constexpr int PE = (TW + 1 + 7) / 8 * 8;
+    static constexpr int HH = SD == 2 ? 2 * TH + 1 : TH + KH - 1;
+    static constexpr int PITCH = SD == 2 ? 2 * PE : (TW + KW - 1 + 7) / 8 * 8;     // (a multiple of 8 pixels = 256 B keeps the bank pattern of a row)
     static constexpr int NPIX = KT * HH * PITCH;
     static constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + NWAVE - 1) / NWAVE * NWAVE;    // 1 KiB wave-instructions per halo, a multiple of the waves
     static constexpr int HALO_BYTES = HINSTR * 1024;
@@ -52,12 +56,13 @@ struct Cfg {
 };
 }  // namespace halo
 
-template <int KT, int KH, int TH, int TW, int NT, int MT>
+template <int KT, int KH, int TH, int TW, int NT, int MT, int SD = 1>
 __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void conv_halo_kernel(ConvArgs p) {      // two workgroups per CU: 128 (MT = 1) / 256 (MT = 2) VGPRs
 #if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins exist only in the device pass; the host pass needs just the stub)
     using namespace halo;
     typedef bf16_t T;
-    using C = Cfg<KT, KH, TH, TW, NT, MT>;
+    using C = Cfg<KT, KH, TH, TW, NT, MT, SD>;
+    static_assert(SD == 1 || (SD == 2 && KT == 1), "stride 2: the 2-D down-sampling conv");
     constexpr int NWAVE = C::NWAVE, NB = C::NB, WTAP = C::WTAP, HH = C::HH, PITCH = C::PITCH, NPIX = C::NPIX, HINSTR = C::HINSTR;
     constexpr int HALO_BYTES = C::HALO_BYTES, WG_BYTES = C::WG_BYTES, NWB = C::NWB, EROW = C::EROW;
     constexpr int HPW = HINSTR / NWAVE;
@@ -107,9 +112,14 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         const int c = physc ^ ((ww >> 3) & 1);
         // logical coordinates: frame ti of Tin << tsplit (frame f = channels (f & 1) * Cin + [0, Cin) of physical frame f >> 1,
         // wan_vae.py:138-141), pixel (hi_, wi) of the nearest-exact 2x up-sampled map when ups (:61-67)
-        const int ti = to + fdt, hi_ = h0 - 1 + hh, wi = w0 - 1 + ww;
-        const bool ok = px < NPIX && ww < TW + KW - 1 && ti < (p.Tin << p.tsplit) && hi_ >= 0 && hi_ < (p.Hin << p.ups) && wi >= 0 &&
-                        wi < (p.Win << p.ups);
+        int ti = to + fdt, hi_ = h0 - 1 + hh, wi = w0 - 1 + ww;
+        bool ok = px < NPIX && ww < TW + KW - 1 && ti < (p.Tin << p.tsplit) && hi_ >= 0 && hi_ < (p.Hin << p.ups) && wi >= 0 &&
+                  wi < (p.Win << p.ups);
+        if constexpr (SD == 2) {        // slot ww of the de-interleaved row = input column 2 j (+ 1 in the odd half); no padding on top / left
+            const int part = ww / C::PE, j = ww % C::PE;
+            hi_ = 2 * h0 + hh; wi = 2 * w0 + 2 * j + part;
+            ok = px < NPIX && j < TW + 1 - part && hi_ < p.Hin && wi < p.Win;
+        }
         const int64_t pix = ((int64_t)(ti >> p.tsplit) * p.Hin + (hi_ >> p.ups)) * p.Win + (wi >> p.ups);
         hoff[i] = ok ? (int)(pix * (p.xplane ? 32 : p.xs * 2)) + (p.tsplit ? (ti & 1) * p.Cin * 2 : 0) + c * 16 : -1;
     }
@@ -149,8 +159,8 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         const int col = TW == 32 ? li : li % TW;
 #pragma unroll
         for (int dw = 0; dw < KW; ++dw) {
-            const int cc = col + dw;
-            abase[mi][dw] = (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
+            const int cc = SD == 2 ? (dw == 1 ? C::PE + col : col + (dw >> 1)) : col + dw;
+            abase[mi][dw] = (unsigned)((row * SD * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
         }
     }
     // MFMA "A" operand (weights): row n = ni*32 + li of the tap's [NB x 16] tile; further column tiles are +32 rows = +1024 bytes

@@ -437,6 +437,26 @@ def test_planar16_norm_and_conv_equal_channels_last(cin, cout, kt, thw):
             assert torch.isnan(ring2[:, :2].float()).all() and torch.isnan(ring2[:, 2 + To:].float()).all()
 
 
+@pytest.mark.parametrize("cin,cout,thw", [(96, 96, (3, 64, 96)), (192, 192, (2, 40, 104)), (48, 128, (2, 34, 70)), (32, 64, (1, 33, 65))])
+def test_conv_cl_production_kernel_stride2(cin, cout, thw):
+    """The Resample down-sampling conv (ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2), wan_vae.py:96-100) on conv_halo_kernel's stride-2
+    variant (halo rows stored as even | odd pixels): even and odd map sizes, wide and narrow patches, 96- and 128-channel tiles."""
+    import torch.nn.functional as F
+    o = ops()
+    T, H, W = thw
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(T, H, W, cin, generator=g).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (cin * 9) ** -0.5).bfloat16()
+    b = torch.randn(cout, generator=g).bfloat16()
+    xp = F.pad(x.float().permute(0, 3, 1, 2), (0, 2 * Wo + 1 - W, 0, 2 * Ho + 1 - H))
+    ref = F.conv2d(xp, w.float(), b.float(), stride=2).permute(0, 2, 3, 1).reshape(-1, cout)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = o.conv_cl(x.to(DEV), wp.to(DEV), b.to(DEV), Tin=T, Hin=H, Win=W, Cin=cin, k=(1, 3, 3), stride=(1, 2, 2), pad=(0, 0, 0),
+                    out_thw=(T, Ho, Wo))
+    assert ref.shape[0] == T * Ho * Wo and rel_err(out.float().cpu(), ref) < BF16_TOL
+
+
 @pytest.mark.parametrize("tsplit", [False, True])
 @pytest.mark.parametrize("cin,cout", [(192, 96), (384, 192), (32, 40)])
 def test_conv_cl_production_kernel_upsampled(cin, cout, tsplit):
