@@ -8,6 +8,7 @@
 * the geometry kernels against the oracle.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -347,3 +348,42 @@ def test_two_softmaxes_in_one_launch(Lq, accumulate):
     with pytest.raises(Exception):
         ops.attention(q.float(), [KV(s_.k.float(), s_.vt.float(), s_.k_bs, s_.k_ls, s_.vt_bs, s_.vt_ls, s_.len) for s_ in segs],
                       new_softmax=0b10, **kw)       # fp32 / generic kernels: refused, the model falls back to two launches
+
+
+def test_gemm_switch_paths_in_a_subprocess():
+    """The opt-in GEMM launch variants read their environment switch once per process, so they are exercised in a child process: the
+    split-K tail over the partial last tile round (M4D_GEMM_TAIL=1: float32 slabs + fixed-order fix-up, all epilogues) and the chunked
+    launches (M4D_GEMM_CHUNK=512: the same tiles in the same K order, bit-identical to the single launch)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from more4d_amd import ops
+g = torch.Generator().manual_seed(0)
+M, N, K = 8704, 2048, 2048                     # 34 x 8 = 272 tiles: one full round + 16 tail tiles (split 2-4 ways along K); chunk 64 -> 5 launches
+a = torch.randn(M, K, generator=g).bfloat16().cuda()
+w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+b = torch.randn(N, generator=g).bfloat16().cuda()
+ref = a.float() @ w.float().t() + b.float()          # (fp32 torch on the device: tool of the test, not a product path)
+out = ops.gemm_bt(a, w, b)
+err = float((out.float() - ref).abs().max() / ref.abs().max())
+res = torch.zeros(M, N, device="cuda")
+ops.gemm_bt(a, w, b, out=res, epilogue=ops.EPI_RESID_GATE)
+err2 = float((res - ref.bfloat16().float()).abs().max() / ref.abs().max())
+torch.save(out.cpu(), sys.argv[1])
+print("ERR", err, err2)
+'''
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("base", {}), ("tail", {"M4D_GEMM_TAIL": "1"}), ("chunk", {"M4D_GEMM_CHUNK": "64"})):
+            e = dict(os.environ, **env)
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(d, tag + ".pt")], capture_output=True, text=True, env=e,
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            errs = [float(v) for v in r.stdout.split("ERR")[1].split()]
+            assert errs[0] < 8e-3 and errs[1] < 8e-3, (tag, errs)
+            outs[tag] = torch.load(os.path.join(d, tag + ".pt"))
+    assert torch.equal(outs["chunk"], outs["base"])
+    assert float((outs["tail"].float() - outs["base"].float()).abs().max()) <= 2.0 ** -6 * float(outs["base"].float().abs().max())
