@@ -32,6 +32,29 @@ typedef void* m4d_stream;
 int m4d_version(void);
 const char* m4d_last_error(void);
 
+/* ---- diagnostics: which kernel structure the calls of this process dispatched to ----
+ * Every launcher counts its launches per kernel class (host side, process wide).  Tests use the counters to assert that a
+ * module-level parity case against the reference's outputs really ran the PRODUCTION tile paths (the reference has no counterpart:
+ * its kernels are chosen by cuDNN / flash-attn). */
+typedef enum {
+    M4D_KC_GEMM_PHASED = 0,        /* gemm_bt256p_kernel: 8 waves, two phased groups */
+    M4D_KC_GEMM_WIDE = 1,          /* gemm_bt256w_kernel: 4 waves x 128x128, AGPR accumulators */
+    M4D_KC_GEMM_GENERIC = 2,       /* 128x128 register-staged (small / ragged / fp32) and the A/B structures */
+    M4D_KC_ATTN_PHASED = 3,        /* attn128p_kernel */
+    M4D_KC_ATTN_OTHER = 4,
+    M4D_KC_CONV_HALO_MT3_12X32 = 5,/* conv_halo_kernel, three pixel tiles per wave, 12 x 32 patches */
+    M4D_KC_CONV_HALO_MT3_24X16 = 6,/* ... 24 x 16 patches */
+    M4D_KC_CONV_HALO = 7,          /* conv_halo_kernel, two pixel tiles per wave (8 x 32 / 16 x 16 patches) */
+    M4D_KC_CONV_GENERIC = 8,       /* conv_cl256_kernel / conv_cl_kernel */
+    M4D_KC_CONV_FUSED_NORM = 9,    /* a conv launch that wrote the next layer's RMS_norm(+SiLU) from its epilogue */
+    M4D_KC_CONV_FUSED_NORM_RESID = 10, /* ... of a residual block's conv2 (shortcut added, norm of the NEXT block / head) */
+    M4D_KC_CONV_GNSTATS = 11,      /* a conv launch that emitted GroupNorm partial statistics from its epilogue */
+    M4D_KC_COUNT = 12
+} m4d_kernel_class;
+/* launches of `kernel_class` since process start (or the last reset); reset != 0 clears that counter after reading it;
+ * kernel_class < 0 with reset != 0 clears all counters and returns 0. */
+int64_t m4d_launch_count(int kernel_class, int reset);
+
 /* ---- GEMM epilogues (m4d_gemm_bt) ---- */
 typedef enum {
     M4D_EPI_STORE = 0,      /* out[T]   = acc + bias                                   nn.Linear */

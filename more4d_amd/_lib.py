@@ -34,6 +34,7 @@ class AttnBwdArgs(Structure):
 # name -> (restype, argtypes); mirrors include/more4d_hip.h one to one
 SIGNATURES = {
     "m4d_version": (c_int, []),
+    "m4d_launch_count": (c_int64, [c_int, c_int]),
     "m4d_last_error": (c_char_p, []),
     "m4d_gemm_bt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64,
                             c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p]),

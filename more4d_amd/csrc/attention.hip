@@ -557,6 +557,7 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
                 configured_w = true;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
+            m4d_count_launch(M4D_KC_ATTN_OTHER);
             const dim3 gw((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
 #ifdef M4D_ABLATIONS
             switch (p.abl & 3) {   // timing ablations (tool builds only): 1 no softmax, 2 no MFMAs in the main loop
@@ -582,18 +583,22 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             M4D_ENV_ONCE(smx, "M4D_ATTN_SMX", 1);   // 1 = scalar softmax arithmetic (default: +9 % sustained over the packed form), 0 = packed
             M4D_ENV_ONCE(prio, "M4D_ATTN_PRIO", 1);
             const dim3 gp((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
+            m4d_count_launch(M4D_KC_ATTN_PHASED);
             if (smx == 0) hipLaunchKernelGGL((attn128p_kernel<0, 1>), gp, dim3(512), 4 * 32768, st, q);
             else if (prio == 0) hipLaunchKernelGGL((attn128p_kernel<1, 0>), gp, dim3(512), 4 * 32768, st, q);
             else if (prio == 2) hipLaunchKernelGGL((attn128p_kernel<1, 2>), gp, dim3(512), 4 * 32768, st, q);
             else hipLaunchKernelGGL((attn128p_kernel<1, 1>), gp, dim3(512), 4 * 32768, st, q);
         } else if (w8) {
             q.nq_tiles = (int)((p.Lq + 255) / 256);
+            m4d_count_launch(M4D_KC_ATTN_OTHER);
             hipLaunchKernelGGL(attn128_kernel<8>, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(512), 0, st, q);
         } else {
+            m4d_count_launch(M4D_KC_ATTN_OTHER);
             hipLaunchKernelGGL(attn128_kernel<4>, grid, block, 0, st, q);
         }
         return 0;
     }
+    m4d_count_launch(M4D_KC_ATTN_OTHER);
     switch (D) {
         case 32: hipLaunchKernelGGL((attn_kernel<T, 32>), grid, block, 0, st, p); break;
         case 64: hipLaunchKernelGGL((attn_kernel<T, 64>), grid, block, 0, st, p); break;

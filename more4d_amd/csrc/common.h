@@ -93,6 +93,7 @@ M4D_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // ---- host-side error plumbing (api.cpp owns the storage) ----
 extern "C" __attribute__((visibility("hidden"))) void m4d_set_error(const char* fmt, ...);   // library-internal: not part of the ABI
+extern "C" __attribute__((visibility("hidden"))) void m4d_count_launch(int kernel_class);       // m4d_kernel_class (more4d_hip.h)
 #define M4D_CHECK_ARG(cond, ...)                   \
     do {                                           \
         if (!(cond)) {                             \

@@ -391,6 +391,9 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
     }
     p.tiles_m = p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
     p.tiles_n = (p.Cout + NT * 32 - 1) / (NT * 32);
+    m4d_count_launch(MT == 3 ? (TH == 12 ? M4D_KC_CONV_HALO_MT3_12X32 : M4D_KC_CONV_HALO_MT3_24X16) : M4D_KC_CONV_HALO);
+    if (p.post_out) m4d_count_launch(p.resid ? M4D_KC_CONV_FUSED_NORM_RESID : M4D_KC_CONV_FUSED_NORM);
+    if (p.gn_partial) m4d_count_launch(M4D_KC_CONV_GNSTATS);
     hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT, MT, SD>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * halo::Cfg<KT, KH, TH, TW, NT, MT, SD>::NWAVE), LDS, st, p);
     return 0;
 }
@@ -527,6 +530,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
         p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (Cout + 127) / 128;
         const int64_t nwg2 = (int64_t)p.tiles_m * p.tiles_n;
         M4D_CHECK_ARG(nwg2 < (1ll << 31), "conv_cl: too many tiles");
+        m4d_count_launch(M4D_KC_CONV_GENERIC);
         hipLaunchKernelGGL(conv_cl256_kernel, dim3((unsigned)nwg2), dim3(512), 2 * (256 + 128) * ROWB, (hipStream_t)stream, p);
         M4D_CHECK_LAUNCH("conv_cl");
         return 0;
@@ -535,6 +539,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
     M4D_CHECK_ARG(nwg < (1ll << 31), "conv_cl: too many tiles");
     dim3 grid((unsigned)nwg), block(256);
+    m4d_count_launch(M4D_KC_CONV_GENERIC);
     if (dt == M4D_BF16) hipLaunchKernelGGL(conv_cl_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv_cl_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
     M4D_CHECK_LAUNCH("conv_cl");

@@ -19,6 +19,12 @@
 
 #include "gemm_common.h"
 
+// gemm_wide_*.hip: the 4-wave 128 x 128-per-wave kernel, one translation unit per epilogue
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_store(const void* args, unsigned nwg, hipStream_t st);
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_gelu(const void* args, unsigned nwg, hipStream_t st);
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_resid(const void* args, unsigned nwg, hipStream_t st);
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_f32(const void* args, unsigned nwg, hipStream_t st);
+
 namespace {
 
 // ============================================================================ 128x128, register staged
@@ -517,11 +523,29 @@ inline int tail_split(int64_t nwg, int64_t nk, int ncu) {
 
 }  // namespace
 
+// compute units of the current device (the tile-round arithmetic of the split-K tail); 256 on an MI355X
+static int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+// production structure for big bf16 problems: 5 (default) = 4-wave 128 x 128-per-wave kernel (gemm_wide.h), 4 = phased two-group
+// kernel (gemm_phased.h); 1 two-stage, 2 ping-pong, 3 staggered rings (older A/B structures)
+static int gemm_variant() { M4D_ENV_ONCE(v, "M4D_GEMM_VARIANT", 5); return v; }
+// M4D_GEMM_TAIL=1 (phased kernel only): split-K over the partial last tile round
+static bool gemm_tail_enabled() { M4D_ENV_ONCE(t, "M4D_GEMM_TAIL", 0); return t != 0 && gemm_variant() == 4; }
+
 extern "C" int64_t m4d_gemm_bt_workspace_bytes(m4d_dtype dt, int64_t M, int64_t N, int64_t K) {
+    if (!gemm_tail_enabled()) return 0;             // (callers then use the plain entry point: no workspace, no extra call)
     if (dt != M4D_BF16 || K % 64 || M < 512 || N < 512) return 0;
     const int64_t nwg = ((M + 255) / 256) * ((N + 255) / 256);
-    const int S = tail_split(nwg, K / 64, 256);
-    return S > 1 ? (nwg % 256) * S * 65536 * 4 : 0;
+    const int ncu = device_cus();
+    const int S = tail_split(nwg, K / 64, ncu);
+    return S > 1 ? (nwg % ncu) * S * 65536 * 4 : 0;
 }
 
 static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
@@ -551,11 +575,11 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
     hipStream_t st = (hipStream_t)stream;
     // production kernel: big bf16 problems with K a multiple of the 64-wide K-tile
     const bool big = dt == M4D_BF16 && K % 64 == 0 && M >= 512 && N >= 512;
+    int kclass = M4D_KC_GEMM_GENERIC;
     if (big) {
-        static int variant = -1;   // default 4: phased two-group kernel (gemm_phased.h); 1 two-stage, 2 ping-pong, 3 staggered rings (A/B)
-        if (variant < 0) {
-            const char* v = getenv("M4D_GEMM_VARIANT");
-            variant = v ? atoi(v) : 4;
+        const int variant = gemm_variant();
+        static bool configured = false;
+        if (!configured) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)gemm_bt256pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
@@ -563,7 +587,8 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
                 e = hipFuncSetAttribute((const void*)gemm_bt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * SLOT3);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)gemm_bt256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_BUF);
-            if (e != hipSuccess) { variant = -1; m4d_set_error("gemm_bt: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -3; }
+            if (e != hipSuccess) { m4d_set_error("gemm_bt: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -3; }
+            configured = true;
         }
         p.tiles_m = (int)((M + BM2 - 1) / BM2); p.tiles_n = (int)((N + BN2 - 1) / BN2);
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
@@ -572,19 +597,25 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
         // showed NO gain (1 663 / 1 660 vs 1 663 / 1 665 ms per step) although the 5120-wide GEMMs idle 4.6 % of their CU-rounds —
         // the step runs at the 1.4 kW power limit, so an idle partial round is paid back as clock on the full
         // ones — and it costs the bit-identical results of equal samples in one batch (split tiles sum K in a different order).
-        M4D_ENV_ONCE(tail_mode, "M4D_GEMM_TAIL", 0);
-        const int S = (variant == 4 && ws && tail_mode) ? tail_split(nwg, K / 64, 256) : 1;
-        if (S > 1 && ws_bytes >= (nwg % 256) * S * 65536 * 4) {
-            const int tail = (int)(nwg % 256), full = (int)(nwg - tail);
+        // wide kernel: 16-byte row-aligned bf16 outputs (or fp32 outputs), the four epilogues the DiT's big GEMMs use
+        const bool wide_ok = (epilogue == M4D_EPI_RESID_GATE || epilogue == M4D_EPI_STORE_F32 ||
+                              ((ldc & 7) == 0 && (epilogue == M4D_EPI_STORE || epilogue == M4D_EPI_GELU_TANH))) &&
+                             ((uintptr_t)out % 32) == 0;
+        const int ncu = device_cus();
+        const int S = (ws && gemm_tail_enabled()) ? tail_split(nwg, K / 64, ncu) : 1;
+        if (S > 1 && ws_bytes >= (nwg % ncu) * S * 65536 * 4) {
+            const int tail = (int)(nwg % ncu), full = (int)(nwg - tail);
             p.remap_n = full;
+            kclass = M4D_KC_GEMM_PHASED;
             hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)full), dim3(512), 2 * P_BUF, st, p);
             GemmArgs q = p;
             q.remap_n = 0; q.tile_base = full; q.ksplit = S; q.ws = (float*)ws;
             hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)(tail * S)), dim3(512), 2 * P_BUF, st, q);
             hipLaunchKernelGGL(gemm_tail_fixup_kernel<bf16_t>, dim3((unsigned)(tail * 16)), dim3(256), 0, st, q);
-        } else if (variant == 4) {
+        } else if (variant == 4 || (variant == 5 && !wide_ok)) {
             // M4D_GEMM_CHUNK=n: the tile grid in launches of n tiles (whole rounds of the 256 CUs): every launch boundary re-aligns the
             // workgroups that share A / W panels, whose K loops otherwise drift apart and stop hitting each other's lines in L2
+            kclass = M4D_KC_GEMM_PHASED;
             M4D_ENV_ONCE(chunk, "M4D_GEMM_CHUNK", 0);
             if (chunk > 0 && nwg > chunk) {
                 for (int64_t t0 = 0; t0 < nwg; t0 += chunk) {
@@ -593,6 +624,14 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
                     hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)q.remap_n), dim3(512), 2 * P_BUF, st, q);
                 }
             } else hipLaunchKernelGGL(gemm_bt256p_kernel, dim3((unsigned)nwg), dim3(512), 2 * P_BUF, st, p);
+        }
+        else if (variant == 5) {
+            kclass = M4D_KC_GEMM_WIDE;
+            const int rc = epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store(&p, (unsigned)nwg, st)
+                         : epilogue == M4D_EPI_GELU_TANH ? m4d_launch_gemm_wide_gelu(&p, (unsigned)nwg, st)
+                         : epilogue == M4D_EPI_RESID_GATE ? m4d_launch_gemm_wide_resid(&p, (unsigned)nwg, st)
+                         : m4d_launch_gemm_wide_f32(&p, (unsigned)nwg, st);
+            if (rc != 0) { m4d_set_error("gemm_bt: cannot enable 128 KiB LDS (wide kernel)"); return -3; }
         }
         else if (variant == 3) hipLaunchKernelGGL(gemm_bt256s_kernel, dim3((unsigned)nwg), dim3(512), 5 * SLOT3, st, p);
         else if (variant == 1) hipLaunchKernelGGL(gemm_bt256_kernel, dim3((unsigned)nwg), dim3(512), 2 * STAGE2_BYTES, st, p);
@@ -606,6 +645,7 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
         else hipLaunchKernelGGL(gemm_bt_kernel<float>, grid, block, 0, st, p);
     }
     M4D_CHECK_LAUNCH("gemm_bt");
+    m4d_count_launch(kclass);
     return 0;
 }
 

@@ -132,4 +132,93 @@ M4D_DEV void epilogue_tile(const GemmArgs& p, const f32x16& acc, int64_t m, int6
     }
 }
 
+// wave-uniform 64-bit value forced into SGPRs (keeps the DMA in its  vgpr_offset + sgpr_base  addressing form)
+M4D_DEV const char* uniform_ptr(const char* q) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
+// Epilogue of one 64(m) x 64(n) half of a wave's sub-tile THROUGH LDS.  The accumulator layout gives every lane its own
+// output ROW (lane = m), so direct stores touch 64 different rows per instruction (16-byte pieces of 64 cache lines:
+// measured 1.4 TB/s, 16 % of a K = 5120 GEMM).  Here the half-tile is written to a wave-private LDS region with bias /
+// activation / gate applied, then read back row-wise so that 8 (bf16) or 16 (fp32) consecutive lanes cover one
+// contiguous 128 / 256-byte row segment of the output.  16-byte chunks are XOR-swizzled by the row index.
+template <typename T>
+M4D_DEV void epilogue_half_lds(const GemmArgs& p, char* wl, const f32x16& a00, const f32x16& a01, const f32x16& a10,
+                               const f32x16& a11, int64_t m_base, int64_t n_base, int64_t m_lo, int64_t n_lo, int lane) {
+    // a[ni][mi2]: a00 = (ni 0, mi2 0), a01 = (ni 0, mi2 1), a10 = (ni 1, mi2 0), a11 = (ni 1, mi2 1)
+    const int li = lane & 31, hi = lane >> 5;
+    const T* bias = (const T*)p.bias;
+    const bool f32out = p.epilogue == M4D_EPI_RESID_GATE || p.epilogue == M4D_EPI_STORE_F32;
+#pragma unroll
+    for (int mi2 = 0; mi2 < 2; ++mi2) {
+        const int r = mi2 * 32 + li;
+        const int64_t m = m_base + r;
+        const float bm = (bias && p.bias_on_m) ? (float)bias[m] : 0.f;
+        const float* grow = (p.epilogue == M4D_EPI_RESID_GATE && p.gate) ? p.gate + (m / p.rows_per_sample) * p.gate_stride : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const f32x16& acc = ni == 0 ? (mi2 == 0 ? a00 : a01) : (mi2 == 0 ? a10 : a11);
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int nl = ni * 32 + rq * 8 + hi * 4;
+                const int64_t nb = n_base + nl;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[rq * 4 + e];
+                if (bias) { if (p.bias_on_m) v += bm; else v += load4(bias + nb); }
+                if (p.epilogue == M4D_EPI_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (p.epilogue == M4D_EPI_GELU_ERF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if (p.epilogue == M4D_EPI_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (f32out) {
+                    if (!p.nb1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = round_through<T>(v[e]);
+                    }
+                    if (grow) v = v * load4(grow + nb);
+                    const int ch = nl >> 2;                                   // 16 chunks of 4 floats per 256-byte row
+                    *reinterpret_cast<f32x4*>(wl + r * 256 + ((ch ^ (r & 15)) << 4)) = v;
+                } else {
+                    const int ch = nl >> 3;                                   // 8 chunks of 8 bf16 per 128-byte row
+                    store4(reinterpret_cast<T*>(wl + r * 128 + ((ch ^ (r & 7)) << 4) + (nl & 4) * 2), v);
+                }
+            }
+        }
+    }
+    // wave-private region: program order + the compiler's lgkmcnt wait order the reads after the writes
+    if (f32out) {
+        const int ch = lane & 15;
+        const int64_t nb = n_base + ch * 4;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + (lane >> 4);
+            const int64_t m = m_base + r;
+            f32x4 v = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((ch ^ (r & 15)) << 4));
+            if (m < m_lo || nb < n_lo) continue;
+            float* dst = (float*)p.out + m * p.ldc + nb;
+            if (p.epilogue == M4D_EPI_RESID_GATE) v += load4(dst);
+            store4(dst, v);
+        }
+    } else {
+        const int ch = lane & 7;
+        const int64_t nb = n_base + ch * 8;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 8 + (lane >> 3);
+            const int64_t m = m_base + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(wl + r * 128 + ((ch ^ (r & 7)) << 4));
+            if (m < m_lo || nb + 8 <= n_lo) continue;      // a chunk straddling n_lo rewrites identical values (benign)
+            *reinterpret_cast<uint4*>((T*)p.out + m * p.ldc + nb) = v;
+        }
+    }
+}
+
 }  // namespace

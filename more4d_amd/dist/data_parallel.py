@@ -44,6 +44,7 @@ class ShardedDataParallel:
         self.state_dtype = state_dtype
         self.step_count = 0
         self._handles = []
+        self._defer = False         # no_sync(): micro-batches whose gradients only accumulate locally
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("ShardedDataParallel: the model has no trainable parameter")
@@ -108,9 +109,16 @@ class ShardedDataParallel:
             if p.grad is not None:
                 view.add_(p.grad.to(view.dtype))
             p.grad = view
+        if b.ready:
+            # the bucket's reduce-scatter is already on the wire (or done): this rank's slice holds GLOBAL sums, a second
+            # backward would add local gradients on top of them and never reduce those
+            raise RuntimeError("ShardedDataParallel: backward() reached a bucket whose gradients were already reduced; run the "
+                               "earlier micro-batches under `with dp.no_sync():` (gradient accumulation) or call zero_grad()")
         b.pending -= 1
-        if b.pending == 0:
+        if b.pending == 0 and not self._defer:
             self._launch(b)
+        if b.pending == 0 and self._defer:
+            b.pending = len(b.params)          # re-arm for the next micro-batch; the LAST one launches
 
     def _launch(self, b):
         if b.ready:
@@ -124,17 +132,41 @@ class ShardedDataParallel:
         except (RuntimeError, NotImplementedError, AttributeError):
             b.work = dist.all_reduce(b.flat_g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def reduce_gradients(self):
-        """Issue the reduce-scatter of every bucket backward did not complete (unused parameters keep zero gradients), wait for
-        all of them (the current stream waits, not the host) and return the global L2 norm of the AVERAGED gradients as a 0-d
-        device tensor (`torch.norm(stack(norm(g)))` of train_wan.py:1991-1993 on what DDP would have left in .grad)."""
+    def no_sync(self):
+        """Context manager for gradient accumulation (`accelerator.accumulate` / --gradient_accumulation_steps,
+        train_wan.py:1916): backward() inside it only accumulates into the local buckets; the first backward outside it
+        issues the reduce-scatters.  Mirrors torch DDP's no_sync()."""
+        dp = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, dp._defer = dp._defer, True
+
+            def __exit__(self, *exc):
+                dp._defer = self.prev
+                for b in dp.buckets:             # a partially finished bucket (unused parameters) restarts its count
+                    if not b.ready:
+                        b.pending = len(b.params)
+                return False
+
+        return _NoSync()
+
+    def _wait_all(self):
+        """Launch what backward left unlaunched and make the current stream wait for every outstanding reduce-scatter."""
         for b in self.buckets:
             self._launch(b)
-        acc = torch.zeros((), device=self.device, dtype=torch.float32)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
+
+    def reduce_gradients(self):
+        """Issue the reduce-scatter of every bucket backward did not complete (unused parameters keep zero gradients), wait for
+        all of them (the current stream waits, not the host) and return the global L2 norm of the AVERAGED gradients as a 0-d
+        device tensor (`torch.norm(stack(norm(g)))` of train_wan.py:1991-1993 on what DDP would have left in .grad)."""
+        self._wait_all()
+        acc = torch.zeros((), device=self.device, dtype=torch.float32)
+        for b in self.buckets:
             ops.sumsq(self._slice(b, b.flat_g), acc)
         if self.world > 1:
             dist.all_reduce(acc, group=self.group)
@@ -145,8 +177,9 @@ class ShardedDataParallel:
     def step(self, max_norm=None, total_norm=None):
         """Clip (coefficient fused into the update: no pass over the gradients) + AdamW on this rank's slice of every bucket +
         all-gather of the updated parameters.  `total_norm`: what reduce_gradients() returned (required with max_norm)."""
-        if any(not b.ready for b in self.buckets):
-            total_norm = self.reduce_gradients() if total_norm is None else total_norm
+        # "ready" only means the reduce-scatter was LAUNCHED (asynchronously, from the backward hooks): the update below reads
+        # the gradient slice on the compute stream, so every outstanding collective is waited for here, unconditionally
+        self._wait_all()
         scale = torch.full((), 1.0 / self.world, device=self.device, dtype=torch.float32)       # sum -> mean
         if max_norm is not None:
             if total_norm is None:
@@ -176,11 +209,36 @@ class ShardedDataParallel:
     def zero_grad(self):
         """Clear the buckets (one memset each) and re-arm the per-bucket counters; .grad stays the bucket view."""
         for b in self.buckets:
+            if b.work is not None:          # never clear a buffer a collective may still be writing
+                b.work.wait()
             b.flat_g.zero_()
             b.pending, b.ready, b.work = len(b.params), False, None
             for p, o in zip(b.params, b.offsets):
                 if p.grad is None or p.grad.data_ptr() != b.flat_g.data_ptr() + o * b.flat_g.element_size():
                     p.grad = b.flat_g[o:o + p.numel()].view(p.shape)
+
+    # ------------------------------------------------------------------ checkpoint / resume (accelerator.save_state)
+    def state_dict(self):
+        """This rank's shard of the optimizer state (moments of its slice of every bucket) + the step counter and the
+        hyper-parameters.  Parameters are saved through the model (they are replicated); the shard is only valid for the same
+        world size, rank and bucket layout, which `load_state_dict` checks."""
+        return {"step": self.step_count, "world": self.world, "rank": self.rank,
+                "layout": [(b.numel, len(b.params)) for b in self.buckets],
+                "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                "exp_avg": [b.exp_avg.detach().clone() for b in self.buckets],
+                "exp_avg_sq": [b.exp_avg_sq.detach().clone() for b in self.buckets]}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        if sd["world"] != self.world or sd["rank"] != self.rank:
+            raise ValueError(f"optimizer shard of rank {sd['rank']}/{sd['world']} loaded on rank {self.rank}/{self.world}")
+        if [tuple(x) for x in sd["layout"]] != [(b.numel, len(b.params)) for b in self.buckets]:
+            raise ValueError("ShardedDataParallel.load_state_dict: bucket layout differs (model or bucket_bytes changed)")
+        self.step_count = int(sd["step"])
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        for b, m, v in zip(self.buckets, sd["exp_avg"], sd["exp_avg_sq"]):
+            b.exp_avg.copy_(m.to(b.exp_avg.device, b.exp_avg.dtype))
+            b.exp_avg_sq.copy_(v.to(b.exp_avg_sq.device, b.exp_avg_sq.dtype))
 
     def state_bytes(self):
         return sum(b.exp_avg.numel() * b.exp_avg.element_size() * 2 for b in self.buckets)

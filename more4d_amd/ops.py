@@ -59,6 +59,20 @@ class Packed:
         self.data, self.rows, self.K = data, rows, K
 
 
+KERNEL_CLASSES = ("gemm_phased", "gemm_wide", "gemm_generic", "attn_phased", "attn_other", "conv_halo_mt3_12x32",
+                  "conv_halo_mt3_24x16", "conv_halo", "conv_generic", "conv_fused_norm", "conv_fused_norm_resid", "conv_gnstats")
+
+
+def launch_counts(reset=False):
+    """{kernel class: launches} of this process (m4d_launch_count; include/more4d_hip.h: m4d_kernel_class) — diagnostics for tests
+    that must prove which tile path a module-level case ran."""
+    lib = _lib.load()
+    out = {n: int(lib.m4d_launch_count(i, 0)) for i, n in enumerate(KERNEL_CLASSES)}
+    if reset:
+        lib.m4d_launch_count(-1, 1)
+    return out
+
+
 def pack_frag(w):
     """bf16 weight [rows, K] (row-strided) -> Packed (fragment order, rows padded to 32)."""
     _dev(w)
@@ -107,20 +121,35 @@ def gemm_bt(a, w, bias=None, *, out=None, epilogue=EPI_STORE, gate=None, gate_st
     if gate is not None and gate.dtype != torch.float32:
         raise TypeError("gemm_bt: gate must be float32")
     lib = _lib.load()
-    nws = lib.m4d_gemm_bt_workspace_bytes(dt_code(a.dtype), M, N, K)
-    ws = _gemm_workspace(a.device, nws) if nws else None
-    check(lib.m4d_gemm_bt_ws(dt_code(a.dtype), _ptr(a), lda, _ptr(w), ldw, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
-                             M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _ptr(ws), nws if ws is not None else 0,
-                             _stream()), "m4d_gemm_bt_ws")
+    if _gemm_tail_mode():          # opt-in split-K tail (M4D_GEMM_TAIL=1 with the phased kernel): the only caller of the workspace ABI
+        nws = lib.m4d_gemm_bt_workspace_bytes(dt_code(a.dtype), M, N, K)
+        if nws:
+            ws = _gemm_workspace(a.device, nws)
+            check(lib.m4d_gemm_bt_ws(dt_code(a.dtype), _ptr(a), lda, _ptr(w), ldw, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
+                                     M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _ptr(ws), nws, _stream()), "m4d_gemm_bt_ws")
+            return out
+    check(lib.m4d_gemm_bt(dt_code(a.dtype), _ptr(a), lda, _ptr(w), ldw, _ptr(bias), int(bias_on_m), _ptr(out), ldc,
+                          M, N, K, epilogue, _ptr(gate), gate_stride, rows_per_sample, _stream()), "m4d_gemm_bt")
     return out
 
 
 _GEMM_WS = {}
+_GEMM_TAIL = None
+
+
+def _gemm_tail_mode():
+    global _GEMM_TAIL
+    if _GEMM_TAIL is None:
+        import os
+        _GEMM_TAIL = os.environ.get("M4D_GEMM_TAIL", "0") not in ("", "0")
+    return _GEMM_TAIL
 
 
 def _gemm_workspace(device, nbytes):
     """Per-device split-K workspace of m4d_gemm_bt_ws (grown on demand; GEMMs on one stream are ordered, so one buffer serves all)."""
     key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    if len(_GEMM_WS) > 8 and key not in _GEMM_WS:      # streams come and go: keep the table bounded
+        _GEMM_WS.clear()
     buf = _GEMM_WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, device=device, dtype=torch.uint8)

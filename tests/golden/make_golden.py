@@ -453,6 +453,44 @@ def make_vae(ref):
     npz_save("adaptor_dec.npz", x=xt, out=da(xt), **sd_arrays("sd.", da))
 
 
+def _probe_samples(t, step):
+    """every `step`-th element (flat) + per-(channel, frame) L2 norms of a [1, C, T, H, W] tensor"""
+    return t.reshape(-1)[::step].clone(), t[0].flatten(2).norm(dim=-1)
+
+
+def make_vae_probe(ref):
+    """The whole Motion-Sensitive VAE chain of train_vae.py:434-453 (encoder adaptor -> x*2-1 -> encode -> mode -> decode -> decoder
+    adaptor) at map sizes where the PRODUCTION bf16 tile paths of our conv kernels are selected: 9 x 120 x 208 (BASELINE.md section 3's
+    probe: 24 x 16 three-pixel-tile patches at the 96-channel level) and 5 x 96 x 128 (12 x 32 patches).  Weights by recipe
+    (weights.py); the hand-offs between stages are rounded to fp16 BEFORE the next reference stage consumes them, so every stored
+    stage output is the reference's exact output for the stored (fp16) stage input and the stages can be tested in isolation."""
+    import json
+    from weights import fill
+    v, t = ref.vae, ref.traj
+    vae = v.AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(json.load(open(os.path.join(HERE, "vae_keys.json"))), seed=2024))
+    ea, da = t.VAEEncoderadaptor().eval(), t.VAEDecoderadaptor().eval()
+    ea.load_state_dict(fill(json.load(open(os.path.join(HERE, "adaptor_enc_keys.json"))), seed=31))
+    da.load_state_dict(fill(json.load(open(os.path.join(HERE, "adaptor_dec_keys.json"))), seed=32))
+    for name, (T, H, W), seed in (("vae_probe_120x208.npz", (9, 120, 208), 120208), ("vae_probe_96x128.npz", (5, 96, 128), 96128)):
+        g = torch.Generator().manual_seed(seed)
+        traj = torch.rand(1, 3, T, H, W, generator=g)                  # normalised coordinates (regenerated from the seed by the test)
+        pseudo = ea(traj) * 2 - 1
+        pv16 = pseudo.half()
+        enc = vae._encode(pv16.float())                                # [1, 32, (T-1)/4+1, H/8, W/8]: mu (normalised) | logvar
+        z16 = enc[:, :16].half()
+        dec = vae._decode(z16.float()).sample
+        dec16 = dec.half()
+        rec = da(dec16.float())
+        ps, pn = _probe_samples(pseudo, 11)
+        ds, dn = _probe_samples(dec, 11)
+        rs, rn = _probe_samples(rec, 11)
+        print(name, "abs-mean pseudo / enc / dec / rec:", float(pseudo.abs().mean()), float(enc.abs().mean()),
+              float(dec.abs().mean()), float(rec.abs().mean()))
+        npz_save(name, shape=np.array([T, H, W]), seed=np.array(seed), pv16=pv16, enc=enc, dec16=dec16,
+                 pseudo_s=ps, pseudo_n=pn, dec_s=ds, dec_n=dn, rec_s=rs, rec_n=rn)
+
+
 def make_block_14b_long(ref):
     """One 14B-width block at L = 2080 (grid (4, 20, 26)): long enough that the PRODUCTION bf16 kernels are on the path
     (gemm_bt256p_kernel needs M, N >= 512; attn128p_kernel needs Lq > 1024 and >= 2048 keys).  Weights and inputs are
@@ -818,6 +856,8 @@ if __name__ == "__main__":
         make_loop(ref)
     if what in ("vae", "all"):
         make_vae(ref)
+    if what in ("vaeprobe", "all"):
+        make_vae_probe(ref)
     if what in ("sched", "all"):
         make_sched(ref)
         make_sched_api(ref)

@@ -155,6 +155,8 @@ def test_host_logic_loop(monkeypatch):
 
 
 def _sp_worker(rank, world, port, q):
+    import os as _os
+    torch.set_num_threads(max(1, (_os.cpu_count() or 8) // world))      # `world` processes share the host's cores
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -198,6 +200,8 @@ def test_sequence_parallel_equals_single_rank(world):
 
 
 def _sp_guid_worker(rank, world, port, q):
+    import os as _os
+    torch.set_num_threads(max(1, (_os.cpu_count() or 8) // world))      # `world` processes share the host's cores
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -244,6 +248,7 @@ def test_sequence_parallel_with_spatial_guidance(world):
 
 def _cfgp_worker(rank, world, port, q):
     import torch.distributed as dist
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # world processes share the host's cores
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -276,10 +281,11 @@ def _cfgp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_cfg_parallel_loop_equals_single_rank(world):
     """CFG-parallel x token-sharded denoise loop under gloo (world 2 = one branch per rank, no per-layer collective; world 4
-    = 2 branches x 2 token shards): every rank ends with the latents of the single-rank loop."""
+    = 2 branches x 2 token shards; world 8 = the cfg2 x sp4 layout of BASELINE configs[3]): every rank ends with the latents
+    of the single-rank loop."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

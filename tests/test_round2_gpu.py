@@ -377,7 +377,9 @@ print("ERR", err, err2)
     import tempfile
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("base", {}), ("tail", {"M4D_GEMM_TAIL": "1"}), ("chunk", {"M4D_GEMM_CHUNK": "64"})):
+        # base = the default structure (4-wave wide kernel); the launch variants belong to the phased kernel (M4D_GEMM_VARIANT=4)
+        for tag, env in (("base", {}), ("phased", {"M4D_GEMM_VARIANT": "4"}), ("tail", {"M4D_GEMM_VARIANT": "4", "M4D_GEMM_TAIL": "1"}),
+                         ("chunk", {"M4D_GEMM_VARIANT": "4", "M4D_GEMM_CHUNK": "64"})):
             e = dict(os.environ, **env)
             r = subprocess.run([sys.executable, "-c", code, os.path.join(d, tag + ".pt")], capture_output=True, text=True, env=e,
                                cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
@@ -385,5 +387,6 @@ print("ERR", err, err2)
             errs = [float(v) for v in r.stdout.split("ERR")[1].split()]
             assert errs[0] < 8e-3 and errs[1] < 8e-3, (tag, errs)
             outs[tag] = torch.load(os.path.join(d, tag + ".pt"))
+    assert torch.equal(outs["phased"], outs["base"])       # both structures accumulate K in the same MFMA order: same bits
     assert torch.equal(outs["chunk"], outs["base"])
     assert float((outs["tail"].float() - outs["base"].float()).abs().max()) <= 2.0 ** -6 * float(outs["base"].float().abs().max())

@@ -315,6 +315,8 @@ def test_sequence_parallel_schedules_in_process(monkeypatch, mode, world):
 
 
 def _ulysses_gloo_worker(rank, world, port, q):
+    import os as _os
+    torch.set_num_threads(max(1, (_os.cpu_count() or 8) // world))      # `world` processes share the host's cores
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -1,0 +1,121 @@
+"""Round-3 GPU parity: the Motion-Sensitive VAE chain pinned to the REFERENCE at map sizes where the production bf16 tile paths are
+selected, BASELINE configs[2] at its full 49 frames (weak #2), and the launch-class diagnostics that prove
+which kernels a case ran."""
+import pytest
+import torch
+
+from util import load_keys, load_npz, rel_err, rms_rel_err
+from weights import fill
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _chain_modules(dtype):
+    from more4d_amd.models.trajectory_module import VAEDecoderadaptor, VAEEncoderadaptor
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    vae = AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(load_keys("vae_keys.json"), 2024))
+    ea, da = VAEEncoderadaptor().eval(), VAEDecoderadaptor().eval()
+    ea.load_state_dict(fill(load_keys("adaptor_enc_keys.json"), 31))
+    da.load_state_dict(fill(load_keys("adaptor_dec_keys.json"), 32))
+    return vae.to(DEV, dtype), ea.to(DEV, dtype), da.to(DEV, dtype)
+
+
+def _check(name, got, samples, norms, tol_max, tol_rms, report):
+    """got [1, C, T, H, W] against the reference's every-11th element and per-(channel, frame) L2 norms"""
+    g = got.float().cpu()
+    e_max = rel_err(g.reshape(-1)[::11], samples)
+    e_rms = rms_rel_err(g.reshape(-1)[::11], samples)
+    e_nrm = rel_err(g[0].flatten(2).norm(dim=-1), norms)
+    report[name] = (e_max, e_rms, e_nrm)
+    assert e_max < tol_max and e_rms < tol_rms and e_nrm < tol_rms, (name, e_max, e_rms, e_nrm)
+
+
+@pytest.mark.parametrize("size", ["120x208", "96x128"])
+@pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["fp32", "bf16"])
+def test_vae_chain_vs_reference_production_tiles(size, dtype):
+    """train_vae.py:434-453's chain (encoder adaptor -> x*2-1 -> encode -> decode -> decoder adaptor; wan_vae.py:190-224, 520-547,
+    678-703; trajectory_module.py:125-279) against the reference's own outputs at 9 x 120 x 208 (BASELINE.md section 3's probe size)
+    and 5 x 96 x 128.  Every stage is fed the reference's (fp16-rounded, stored) input of that stage, so the stages are judged in
+    isolation; the last check runs the chain end to end on our own hand-offs.
+    fp32: north_star's 1e-3.  bf16: the production kernels — asserted through the launch-class counters: the three-pixel-tile
+    LDS-halo kernels (24 x 16 patches at 120 x 208, 12 x 32 at 96 x 128), the conv epilogues that write the next layer's RMS-norm
+    (inside a residual block and across blocks) and the GroupNorm statistics of the adaptors."""
+    from more4d_amd import ops
+    z = load_npz(f"vae_probe_{size}.npz")
+    T, H, W = (int(v) for v in z["shape"])
+    traj = torch.rand(1, 3, T, H, W, generator=torch.Generator().manual_seed(int(z["seed"])))
+    vae, ea, da = _chain_modules(dtype)
+    fp32 = dtype == torch.float32
+    tmax, trms = (1e-3, 1e-3) if fp32 else (8e-2, 2.5e-2)      # first run: <= 3.7e-2 max, <= 1.7e-2 rms per stage in bf16, <= 1e-5 in fp32
+    rep = {}
+    ops.launch_counts(reset=True)
+    with torch.no_grad():
+        pseudo = ea(traj.to(DEV, dtype)) * 2 - 1
+        _check("enc-adaptor", pseudo, z["pseudo_s"], z["pseudo_n"], tmax, trms, rep)
+        enc = vae._encode(z["pv16"].float().to(DEV, dtype))
+        e_enc = (rel_err(enc.float().cpu(), z["enc"]), rms_rel_err(enc.float().cpu(), z["enc"]))
+        rep["encode"] = e_enc
+        assert e_enc[0] < tmax and e_enc[1] < trms, e_enc
+        dec = vae.decode(z["enc"][:, :16].half().float().to(DEV, dtype)).sample
+        _check("decode", dec, z["dec_s"], z["dec_n"], tmax, 3e-2 if not fp32 else trms, rep)
+        rec = da(z["dec16"].float().to(DEV, dtype))
+        _check("dec-adaptor", rec, z["rec_s"], z["rec_n"], tmax, trms, rep)
+        counts = ops.launch_counts()
+        # end to end on our own hand-offs (the reference's hand-offs were rounded to fp16: noise of 5e-4 per stage on its side)
+        chain = da(vae.decode(vae._encode(pseudo)[:, :16].contiguous()).sample)
+        _check("chain", chain, z["rec_s"], z["rec_n"], 5e-3 if fp32 else 1e-1, 3e-3 if fp32 else 6e-2, rep)
+    print(size, dtype, {k: tuple(f"{x:.2e}" for x in v) for k, v in rep.items()}, {k: v for k, v in counts.items() if v})
+    if fp32:
+        assert counts["conv_generic"] > 0 and counts["conv_halo"] + counts["conv_halo_mt3_12x32"] + counts["conv_halo_mt3_24x16"] == 0
+    else:
+        mt3 = "conv_halo_mt3_24x16" if size == "120x208" else "conv_halo_mt3_12x32"
+        assert counts[mt3] > 0, counts                     # three pixel tiles per wave
+        assert counts["conv_halo"] > 0, counts             # the 8 x 32 / 16 x 16 patch kernels of the deeper levels
+        assert counts["conv_fused_norm"] > 0 and counts["conv_fused_norm_resid"] > 0, counts
+        assert counts["conv_gnstats"] > 0, counts
+
+
+def test_launch_counters_follow_the_dispatch():
+    """m4d_launch_count: a big bf16 GEMM lands in one of the two production structures, a ragged-K one in the generic kernel."""
+    from more4d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(0)
+    a = torch.randn(1024, 512, device=DEV, dtype=BF, generator=g)
+    w = torch.randn(768, 512, device=DEV, dtype=BF, generator=g)
+    ops.launch_counts(reset=True)
+    ops.gemm_bt(a, w)
+    c = ops.launch_counts()
+    assert c["gemm_phased"] + c["gemm_wide"] == 1 and c["gemm_generic"] == 0, c
+    ops.gemm_bt(a[:, :72].contiguous(), w[:, :72].contiguous())
+    c = ops.launch_counts(reset=True)
+    assert c["gemm_generic"] == 1, c
+    assert sum(ops.launch_counts().values()) == 0
+
+
+def test_vae_configs2_full_49_frames():
+    """BASELINE configs[2] at its FULL length: 49 x 480 x 832 through encode and decode (13 latent frames; the first frame alone,
+    then twelve 4-frame encoder chunks / latent-frame decoder steps — the staging ring wraps around several times).  Properties the
+    chunked causal network must have (wan_vae.py:520-547, 678-703): the 17-frame prefix of the input encodes to exactly the first
+    5 latent frames of the 49-frame encode, 5 latent frames decode to exactly the first 17 frames of the full decode, a second run
+    is bit-identical (no state leaks through clear_cache), outputs finite and clamped to [-1, 1]."""
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    vae = AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(load_keys("vae_keys.json"), 2024))
+    vae = vae.to(DEV, BF)
+    g = torch.Generator(device=DEV).manual_seed(49)
+    x = (torch.rand(1, 3, 49, 480, 832, device=DEV, generator=g) * 2 - 1).to(BF)
+    with torch.no_grad():
+        full = vae.encode(x)[0].mode()
+        assert full.shape == (1, 16, 13, 60, 104) and bool(torch.isfinite(full.float()).all())
+        part = vae.encode(x[:, :, :17].contiguous())[0].mode()
+        assert torch.equal(part, full[:, :, :5])
+        dec = vae.decode(full).sample
+        assert dec.shape == (1, 3, 49, 480, 832)
+        assert bool(torch.isfinite(dec.float()).all()) and float(dec.float().abs().max()) <= 1.0
+        dec_part = vae.decode(full[:, :, :5].contiguous()).sample
+        assert torch.equal(dec_part, dec[:, :, :17])
+        del dec_part
+        assert torch.equal(vae.encode(x)[0].mode(), full)
+        assert torch.equal(vae.decode(full).sample, dec)

@@ -70,6 +70,8 @@ def test_product_backward_host_logic(monkeypatch):
 
 
 def _ddp_worker(rank, world, port, q):
+    import os as _os
+    torch.set_num_threads(max(1, (_os.cpu_count() or 8) // world))      # `world` processes share the host's cores
     import os
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
@@ -212,6 +214,8 @@ def test_product_guided_backward_host_logic(monkeypatch):
 
 
 def _sharded_dp_worker(rank, world, port, q):
+    import os as _os
+    torch.set_num_threads(max(1, (_os.cpu_count() or 8) // world))      # `world` processes share the host's cores
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -292,3 +296,119 @@ def test_sharded_data_parallel_equals_single_process_gloo():
     assert err < 2e-4, err
     assert all(abs(a - b) < 1e-4 * b for a, b in zip(totals, ref_totals)), (totals, ref_totals)
     assert moved > 0 and diverge == 0.0 and 0.45 < state_frac < 0.6
+
+
+def _sharded_dp8_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import more4d_amd.ops as real
+        for n in cpu_ops.NAMES + ["adamw_", "sumsq"]:
+            setattr(real, n, getattr(cpu_ops, n))
+        from more4d_amd.dist.data_parallel import ShardedDataParallel
+        from more4d_amd.models import WanTransformer4DModel
+        from more4d_amd.optim import AdamW
+        z, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_grads.npz")
+        sd0 = fill(load_keys("dit_tiny_keys.json"), 1234)
+        hp = dict(lr=1e-3, weight_decay=3e-2, eps=1e-6)     # (eps 1e-10 turns fp32 summation order into +-lr on ~0 gradients)
+        kw = dict(seq_len=int(z["seq_len_pad"]))
+
+        def fwd_bwd(model, i):          # sample i of the fixture's batch of two
+            r = slice(i, i + 1)
+            pred = model(x=z["x"][r], t=z["t"][r], context=[[z["ctx0"], z["ctx1"]][i]], clip_fea=z["clip"][r], y=z["y"][r],
+                         full_ref=z["full_ref"][r], **kw)
+            custom_mse_loss(pred, zg["target"][r]).backward()
+
+        m = WanTransformer4DModel(**TINY)
+        m.load_state_dict(sd0)
+        m.train()
+        dp = ShardedDataParallel(m, bucket_bytes=300_000, **hp)
+        # step 1: plain `backward(); step()` with NO reduce_gradients() and no clipping (step() must wait for the
+        # reduce-scatters the hooks launched asynchronously).  Rank r holds sample r % 2: the global batch of 8 has the mean
+        # gradient of the fixture's batch of 2.
+        fwd_bwd(m, rank % 2)
+        dp.step()
+        dp.zero_grad()
+        # step 2: gradient accumulation over two micro-batches (both samples on every rank), the first under no_sync()
+        with dp.no_sync():
+            fwd_bwd(m, 0)
+        assert all(not b.ready and b.work is None for b in dp.buckets), "no_sync() must not launch a collective"
+        fwd_bwd(m, 1)
+        raised = False
+        try:
+            fwd_bwd(m, 0)               # a third backward after the reduce-scatter went out must not be silently wrong
+        except RuntimeError as e:
+            raised = "no_sync" in str(e)
+        # (the failed backward may have left partial local gradients in some buckets: redo the step cleanly)
+        dp.zero_grad()
+        with dp.no_sync():
+            fwd_bwd(m, 0)
+        fwd_bwd(m, 1)
+        total = dp.reduce_gradients()
+        dp.step(max_norm=1e9, total_norm=total)
+        dp.zero_grad()
+        state = dp.state_dict()
+        mine = {n: p.detach().clone() for n, p in m.named_parameters()}
+
+        # single-process reference: step 1 on the batch of two (mean), step 2 on the SUM of the two per-sample gradients
+        # averaged over ranks = 2 x the batch-mean gradient
+        ref = WanTransformer4DModel(**TINY)
+        ref.load_state_dict(sd0)
+        ref.train()
+        opt = AdamW(ref.parameters(), **hp)
+        for it in range(2):
+            pred = ref(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], clip_fea=z["clip"], y=z["y"], full_ref=z["full_ref"], **kw)
+            (custom_mse_loss(pred[:1], zg["target"][:1]) + custom_mse_loss(pred[1:], zg["target"][1:])).mul(0.5 if it == 0 else 1.0).backward()
+            opt.step()
+            opt.zero_grad()
+        err = max(float((mine[n] - p.detach()).abs().max() / p.detach().abs().max().clamp_min(1e-6)) for n, p in ref.named_parameters())
+
+        # resume: a fresh wrapper that loads the shard continues exactly like the original
+        m2 = WanTransformer4DModel(**TINY)
+        m2.load_state_dict({n: v.clone() for n, v in mine.items()}, strict=False)
+        m2.train()
+        dp2 = ShardedDataParallel(m2, bucket_bytes=300_000, **hp)
+        dp2.load_state_dict(state)
+        for model, d in ((m, dp), (m2, dp2)):
+            fwd_bwd(model, rank % 2)
+            d.step()
+            d.zero_grad()
+        resume = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(m.parameters(), m2.parameters()))
+        bad_rank = False
+        try:
+            dp2.load_state_dict(dict(state, rank=(rank + 1) % world))
+        except ValueError:
+            bad_rank = True
+        digest = torch.stack([p.detach().double().sum() for p in m.parameters()]).sum().reshape(1)
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        spread = float(max((g - gathered[0]).abs() for g in gathered))
+        q.put((rank, err, raised, resume, bad_rank, spread, dp.state_bytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_data_parallel_world8_accumulate_resume_gloo():
+    """BASELINE configs[4] layout (8 data-parallel ranks) under gloo: `backward(); step()` without reduce_gradients(),
+    gradient accumulation under no_sync(), the loud failure of an un-guarded second backward, and state_dict resume."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 28900 + (os.getpid() % 1000)
+    world = 8
+    procs = [ctx.Process(target=_sharded_dp8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, err, raised, resume, bad_rank, spread, state in res:
+        assert err < 3e-4, (rank, err)
+        assert raised and bad_rank and resume == 0.0 and spread == 0.0, (rank, raised, bad_rank, resume, spread)
