@@ -173,7 +173,8 @@ def secondary_figures(model, cfg, dev):
     return out
 
 
-PROBE_SHAPES = ((5120, 5120, 6), (13824, 5120, 1), (5120, 13824, 1))      # (N, K, launches per DiT block) of gemm_bt256p_kernel
+PROBE_SHAPES = ((5120, 5120, 6), (13824, 5120, 1), (5120, 13824, 1))      # (N, K, launches per DiT block) of the production GEMM kernel
+GEMM_KERNELS = ("gemm_bt256w_kernel", "gemm_bt256p_kernel")               # 4-wave wide kernel (default) / phased kernel (M4D_GEMM_VARIANT=4)
 
 
 def pmc_probe():
@@ -221,12 +222,19 @@ def measure_traffic(timeout=240):
                 return None, {"error": f"rocprofv3 --pmc {counter} failed (rc {r.returncode})", "stderr": r.stderr[-300:]}
             vals = {}
             for row in csv.DictReader(open(files[0])):
-                if "gemm_bt256p_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                    vals[row["Dispatch_Id"]] = vals.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                if any(k in row["Kernel_Name"] for k in GEMM_KERNELS) and row["Counter_Name"] == counter:
+                    vals[int(row["Dispatch_Id"])] = vals.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
             if not vals:
-                return None, {"error": f"no gemm_bt256p_kernel rows in the {counter} pass"}
+                return None, {"error": f"no {' / '.join(GEMM_KERNELS)} rows in the {counter} pass"}
             per[counter] = sum(vals.values()) / len(vals) * 1024.0          # the counters are reported in KiB
             per[counter + "_launches"] = len(vals)
+            # the probe launches the shapes in PROBE_SHAPES order, `reps` launches each: bucket the dispatches by that order
+            ordered = [vals[k] * 1024.0 for k in sorted(vals)]
+            if len(ordered) == sum(r for _, _, r in PROBE_SHAPES):
+                i = 0
+                for N, K, reps in PROBE_SHAPES:
+                    per.setdefault("per_shape", {}).setdefault(f"N{N}_K{K}", {})[counter] = sum(ordered[i:i + reps]) / reps
+                    i += reps
     except Exception as ex:
         return None, {"error": repr(ex)}
     finally:
@@ -235,7 +243,15 @@ def measure_traffic(timeout=240):
     nl = sum(r for _, _, r in PROBE_SHAPES)
     algo = sum(r * 2 * (M * K + N * K + M * N) for N, K, r in PROBE_SHAPES) / nl      # bf16 A + W read once, out written once
     fetch, write = 2.0 * per["FETCH_SIZE"], per["WRITE_SIZE"]
+    shapes = {}
+    for N, K, reps in PROBE_SHAPES:
+        d = per.get("per_shape", {}).get(f"N{N}_K{K}")
+        if d and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            a_ = 2.0 * (M * K + N * K + M * N)
+            shapes[f"M{M}_N{N}_K{K}"] = {"launches_per_block": reps, "fetch_x2_bytes": 2.0 * d["FETCH_SIZE"], "write_bytes": d["WRITE_SIZE"],
+                                         "algorithmic_bytes": a_, "counter_over_algorithmic": (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) / a_}
     return fetch + write, {
+        "per_shape": shapes,
         "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "algorithmic_bytes_per_launch": algo,
         "counter_over_algorithmic": (fetch + write) / algo, "launches_profiled": per["FETCH_SIZE_launches"],
         "note": "rocprofv3 --kernel-trace --pmc, one pass per counter, inside bench.py after the timed region (bench.py --pmc-probe: the "
@@ -530,7 +546,8 @@ def main():
             ks = kt.summary()
             gk = ks.get("gemm_bt", {})
             out["roofline"] = {
-                "kernel": "gemm_bt256p_kernel via m4d_gemm_bt (all DiT projections / FFN, bf16; flops-weighted over its launches)",
+                "kernel": ("gemm_bt256p_kernel" if os.environ.get("M4D_GEMM_VARIANT") == "4" else "gemm_bt256w_kernel") +
+                          " via m4d_gemm_bt (all DiT projections / FFN, bf16; flops-weighted over its launches)",
                 "bound": "mfma", "achieved": gk.get("tflops", 0.0), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                 "frac": gk.get("tflops", 0.0) / MFMA_BF16_PEAK_TF, "traffic": None, "traffic_unit": "bytes per launch",
                 "launches": gk.get("launches", 0), "avg_launch_ms": gk.get("ms", 0.0) / max(1, gk.get("launches", 1)),

@@ -301,7 +301,15 @@ int launch_gemm_wide(const GemmArgs& p, unsigned nwg, hipStream_t st) {
     } while (0)
 #ifdef M4D_ABLATIONS
     if constexpr (EPI == M4D_EPI_STORE) {
-        if (p.abl & 64) { W_LAUNCH(64); return 0; }
+        if (p.abl & 64) {                       // timeline stamps, alone or on top of a timing ablation (clock = power proxy)
+            switch (p.abl & 15) {
+                case 1: W_LAUNCH(65); return 0;
+                case 2: W_LAUNCH(66); return 0;
+                case 3: W_LAUNCH(67); return 0;
+                case 7: W_LAUNCH(71); return 0;
+                default: W_LAUNCH(64); return 0;
+            }
+        }
         switch (p.abl & 15) {                  // (bit 16 = every workgroup on tile (0, 0): handled by tile_coords at run time)
             case 1: W_LAUNCH(1); return 0;
             case 2: W_LAUNCH(2); return 0;

@@ -11,7 +11,7 @@ M, N, K = map(int, sys.argv[1:4]) if len(sys.argv) > 3 else (43680, 5120, 5120)
 a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
 w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * K ** -0.5
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-for _ in range(6):
+for _ in range(int(os.environ.get("TIMELINE_LAUNCHES", "60"))):
     ops.gemm_bt(a, w, None, out=out)
 torch.cuda.synchronize()
 o = out.cpu().view(torch.int16).numpy()
@@ -28,6 +28,7 @@ print(f"tiles {len(r)}  kernel span {(w1.max() - w0.min()) / 100.0:.1f} us   sha
 for name, d in (("prologue", t1 - t0), ("main loop", t2 - t1), ("drain + barrier", t3 - t2), ("epilogue + store ack", t4 - t3), ("total", t4 - t0)):
     print(f"  {name:22s} mean {d.mean():9.0f} cyc  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}   = {d.mean() / np.median(clk) / 1e3:7.2f} us")
 nk = K // 64
+print(f"  effective {2.0 * M * N * K / ((w1.max() - w0.min()) / 100.0) / 1e6:.0f} TF over the kernel span (ablation {os.environ.get('M4D_GEMM_ABL')})")
 print(f"  main loop per K-tile: {np.mean(t2 - t1) / nk:.0f} cycles (MFMA floor 2048)")
 # gaps on the same CU: key = (xcc, se/cu bits of HW_ID)
 key = (hw >> 32) * 65536 + ((hw & 0xffffffff) >> 8 & 0xfff)
