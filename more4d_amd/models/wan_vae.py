@@ -150,6 +150,45 @@ class AutoencoderKLWan_(nn.Module):
         self.conv1 = CausalConv3d(z_dim * 2, z_dim * 2, 1)
         self.conv2 = CausalConv3d(z_dim, z_dim, 1)
         self.decoder = Decoder3d(dim, z_dim, dim_mult, num_res_blocks, attn_scales, self.temperal_upsample, dropout)
+        self.clear_cache()
+
+    # ---- the inner model's own entry points (reference wan_vae.py:520, :549, :633, :678, :717).  The released callers go through the
+    # AutoencoderKLWan wrapper (train_vae.py:444-453, the pipeline); these keep `vae.model.encode(x, vae.scale)` etc. working by name.
+    # `scale` = [mean, 1 / std] (tensors of z_dim entries or two floats), as the wrapper passes it (:770-776).
+    def encode(self, x, scale):
+        """x [B, 3, T, H, W] -> [B, 2 z_dim, T', H/8, W/8] = (mu normalised by `scale` | logvar)  (:520-547)."""
+        v = _InnerView(self, scale)
+        return torch.stack([v._encode_one(u) for u in x])
+
+    def encode_full(self, x, scale):
+        """encode with the per-chunk checkpointed backward of :549-613 (forward values identical to `encode`)."""
+        v = _InnerView(self, scale)
+        if v._wants_grad(x, [self.encoder, self.conv1]):
+            from ..vae_autograd import vae_encode_train
+            return vae_encode_train(v, x)
+        return torch.stack([v._encode_one(u) for u in x])
+
+    def decode(self, z, scale):
+        """z [B, z_dim, T', h, w] -> video [B, 3, T, 8h, 8w], NOT clamped (the wrapper clamps, :825-832)  (:678-703)."""
+        v = _InnerView(self, scale)
+        return torch.stack([v._decode_one(u, clamp=False) for u in z])
+
+    def decode_full(self, z, scale):
+        """decode with the per-latent-frame checkpointed backward of :633-676 (forward values identical to `decode`)."""
+        v = _InnerView(self, scale)
+        if v._wants_grad(z, [self.decoder, self.conv2]):
+            from ..vae_autograd import vae_decode_train
+            return vae_decode_train(v, z)
+        return torch.stack([v._decode_one(u, clamp=False) for u in z])
+
+    def clear_cache(self):
+        """:717-725.  The streaming state of this implementation lives in a per-call runner (every conv's tail frames in its staging
+        buffer), so nothing survives a call; the reference's bookkeeping attributes are kept for code that reads them."""
+        count = lambda m: sum(isinstance(c, CausalConv3d) for c in m.modules())      # noqa: E731
+        self._conv_num, self._conv_idx = count(self.decoder), [0]
+        self._feat_map = [None] * self._conv_num
+        self._enc_conv_num, self._enc_conv_idx = count(self.encoder), [0]
+        self._enc_feat_map = [None] * self._enc_conv_num
 
 
 # --------------------------------------------------------------------------------------------- runner
@@ -570,23 +609,14 @@ def _video_vae(z_dim=None, **kwargs):
     return AutoencoderKLWan_(**cfg)
 
 
-class AutoencoderKLWan(nn.Module):
-    def __init__(self, latent_channels=16, temporal_compression_ratio=4, spatial_compression_ratio=8, **vae_kwargs):
-        super().__init__()
-        self.config = _Config(latent_channels=latent_channels, temporal_compression_ratio=temporal_compression_ratio,
-                              spatial_compression_ratio=spatial_compression_ratio)
-        self.latent_channels = latent_channels                       # read as plain attributes by the pipeline
-        self.temporal_compression_ratio = temporal_compression_ratio  # (pipeline_wan_fun_control.py:185-186, 736)
-        self.spatial_compression_ratio = spatial_compression_ratio
-        mean = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
-                0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
-        std = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
-               3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
-        self.mean = torch.tensor(mean[:latent_channels], dtype=torch.float32)
-        self.std = torch.tensor(std[:latent_channels], dtype=torch.float32)
-        self.scale = [self.mean, 1.0 / self.std]
-        self.model = _video_vae(z_dim=latent_channels, **vae_kwargs)
-        self._pack_cache = {}
+class _VaeCore:
+    """What encode / decode need from their owner: `model` (AutoencoderKLWan_), `mean` / `std` (latent normalisation), the packed-weight
+    cache.  Shared by the AutoencoderKLWan wrapper and the views the inner model's own entry points build."""
+    clamp_output = True      # decode: clamp(-1, 1) fused into the layout kernel (the wrapper's behaviour, :825-832)
+
+    @property
+    def _pack_cache(self):
+        return self.model.__dict__.setdefault("_m4d_pack_cache", {})
 
     @property
     def dtype(self):
@@ -596,7 +626,9 @@ class AutoencoderKLWan(nn.Module):
     def device(self):
         return self.model.conv1.weight.device
 
-    # ---- encode
+    def _wants_grad(self, x, mods):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
+
     CHUNK_LATENT = int(os.environ.get("M4D_VAE_CHUNK", "4"))      # latent frames per streaming chunk after the first frame
 
     def _chunk_latent(self, H, W):
@@ -640,11 +672,58 @@ class AutoencoderKLWan(nn.Module):
         return (torch.cat([inv, torch.ones(zc, device=dev)]),
                 torch.cat([-self.mean.to(dev) * inv, torch.zeros(zc, device=dev)]))
 
+    def _decode_one(self, z, clamp=None):
+        """z [zc, T', h, w] -> clamp(-1,1) video [3, T, 8h, 8w], reference decode (:678-703, :825-832)."""
+        dev, T = self.device, self.dtype
+        clamp = self.clamp_output if clamp is None else clamp
+        zc, lt, h, w = z.shape
+        run = _Runner(self, dev, T)
+        zin = ops.ncthw_to_cl(z.to(dev), T, ch_scale=self.std.to(dev), ch_shift=self.mean.to(dev))      # z/(1/std)+mean
+        a = run.conv_plain(_Act(zin.view(lt * h * w, zc), lt, h, w, zc), self.model.conv2)
+        frames = []
+        cl = self._chunk_latent(8 * h, 8 * w)
+        bounds = [0, 1] + list(range(1 + cl, lt, cl)) + [lt]      # reference: one latent frame per chunk (:678-703)
+        for i0, i1 in zip(bounds[:-1], bounds[1:]):
+            if i1 <= i0:
+                continue
+            o = run.decoder(_Act(a.data[i0 * h * w:i1 * h * w], i1 - i0, h, w, zc))
+            frames.append(ops.cl_to_ncthw(o.data, T, C=3, T=o.t, H=o.h, W=o.w, pixel_stride=o.data.stride(0), act=1 if clamp else 0))
+        return torch.cat(frames, dim=1)
+
+
+
+class _InnerView(_VaeCore):
+    """AutoencoderKLWan_.encode / decode (x, scale): the inner model + the caller's `scale` = [mean, 1 / std]."""
+    clamp_output = False
+
+    def __init__(self, model, scale):
+        self.model = model
+        zc = model.z_dim
+        self.latent_channels = zc
+        mean, inv = scale[0], scale[1]
+        as_vec = lambda v: (v.detach().float().reshape(-1).cpu() if isinstance(v, torch.Tensor) else torch.tensor([float(v)])).expand(zc).contiguous()      # noqa: E731
+        self.mean, self.std = as_vec(mean), 1.0 / as_vec(inv)
+
+
+class AutoencoderKLWan(_VaeCore, nn.Module):
+    def __init__(self, latent_channels=16, temporal_compression_ratio=4, spatial_compression_ratio=8, **vae_kwargs):
+        super().__init__()
+        self.config = _Config(latent_channels=latent_channels, temporal_compression_ratio=temporal_compression_ratio,
+                              spatial_compression_ratio=spatial_compression_ratio)
+        self.latent_channels = latent_channels                       # read as plain attributes by the pipeline
+        self.temporal_compression_ratio = temporal_compression_ratio  # (pipeline_wan_fun_control.py:185-186, 736)
+        self.spatial_compression_ratio = spatial_compression_ratio
+        mean = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+                0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+        std = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+               3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+        self.mean = torch.tensor(mean[:latent_channels], dtype=torch.float32)
+        self.std = torch.tensor(std[:latent_channels], dtype=torch.float32)
+        self.scale = [self.mean, 1.0 / self.std]
+        self.model = _video_vae(z_dim=latent_channels, **vae_kwargs)
+
     def _encode(self, x):
         return torch.stack([self._encode_one(u) for u in x])
-
-    def _wants_grad(self, x, mods):
-        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in mods for p in m.parameters()))
 
     def encode(self, x, return_dict=True):
         dist = DiagonalGaussianDistribution(self._encode(x))
@@ -661,24 +740,6 @@ class AutoencoderKLWan(nn.Module):
             params = self._encode(x)
         dist = DiagonalGaussianDistribution(params)
         return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
-
-    # ---- decode
-    def _decode_one(self, z):
-        """z [zc, T', h, w] -> clamp(-1,1) video [3, T, 8h, 8w], reference decode (:678-703, :825-832)."""
-        dev, T = self.device, self.dtype
-        zc, lt, h, w = z.shape
-        run = _Runner(self, dev, T)
-        zin = ops.ncthw_to_cl(z.to(dev), T, ch_scale=self.std.to(dev), ch_shift=self.mean.to(dev))      # z/(1/std)+mean
-        a = run.conv_plain(_Act(zin.view(lt * h * w, zc), lt, h, w, zc), self.model.conv2)
-        frames = []
-        cl = self._chunk_latent(8 * h, 8 * w)
-        bounds = [0, 1] + list(range(1 + cl, lt, cl)) + [lt]      # reference: one latent frame per chunk (:678-703)
-        for i0, i1 in zip(bounds[:-1], bounds[1:]):
-            if i1 <= i0:
-                continue
-            o = run.decoder(_Act(a.data[i0 * h * w:i1 * h * w], i1 - i0, h, w, zc))
-            frames.append(ops.cl_to_ncthw(o.data, T, C=3, T=o.t, H=o.h, W=o.w, pixel_stride=o.data.stride(0), act=1))
-        return torch.cat(frames, dim=1)
 
     def _decode(self, zs):
         return DecoderOutput(sample=torch.stack([self._decode_one(u) for u in zs]))

@@ -358,7 +358,8 @@ class VaeDecodeFn(Function):
         for i in range(lt):
             snaps.append(run.snapshot())
             o = run.decoder(_Act(a.data[i * h * w:(i + 1) * h * w], 1, h, w, zc))
-            frames.append(ops.cl_to_ncthw(o.data, T, C=3, T=o.t, H=o.h, W=o.w, pixel_stride=o.data.stride(0), act=1))
+            frames.append(ops.cl_to_ncthw(o.data, T, C=3, T=o.t, H=o.h, W=o.w, pixel_stride=o.data.stride(0),
+                                          act=1 if vae.clamp_output else 0))     # (the inner model's decode_full does not clamp)
         ctx.vae, ctx.snaps, ctx.params = vae, snaps, params
         ctx.save_for_backward(z.detach())
         ctx.zdtype = z.dtype
@@ -384,7 +385,8 @@ class VaeDecodeFn(Function):
             dv = dvideo[:, pos:pos + o.t].to(dev, T).contiguous()
             pos += o.t
             g = ops.ncthw_to_cl(dv, T, Cp=o.c).view(o.t * o.h * o.w, o.c)
-            ops.act_bwd_(g, o.data.contiguous(), ops.ACT_CLAMP1)        # clamp_(-1, 1): gradient only where the value passed through
+            if vae.clamp_output:
+                ops.act_bwd_(g, o.data.contiguous(), ops.ACT_CLAMP1)    # clamp_(-1, 1): gradient only where the value passed through
             o.g = g
             tr.backward()
             if ai.g is not None:

@@ -33,6 +33,18 @@ def test_vae_roundtrip_host_logic(monkeypatch):
         assert torch.equal(d.mode(), enc[:, :16])
         dec = vae.decode(z["enc"][:, :16]).sample
         assert rel_err(dec, z["dec"]) < 1e-4
+        # the inner model's own entry points (reference wan_vae.py:520, :549, :633, :678, :717), called the way the reference's
+        # wrapper calls them (:770-776, :825-832): same values; decode / decode_full are NOT clamped
+        m = vae.model
+        assert rel_err(m.encode(z["x"], vae.scale), enc) < 1e-5 and torch.equal(m.encode_full(z["x"], vae.scale), m.encode(z["x"], vae.scale))
+        raw = m.decode(z["enc"][:, :16], vae.scale)
+        assert rel_err(raw.clamp(-1, 1), dec) < 1e-5 and torch.equal(m.decode_full(z["enc"][:, :16], vae.scale), raw)     # (std = 1 / (1 / std))
+        assert float(raw.abs().max()) > 1.0                      # (this fixture does leave [-1, 1] before the clamp)
+        # another normalisation than the wrapper's: two floats (the reference accepts both forms, :539-545)
+        mu = m.encode(z["x"], [0.5, 2.0])[:, :16]
+        assert rel_err(mu, (enc[:, :16] / vae.scale[1].view(1, -1, 1, 1, 1) + vae.scale[0].view(1, -1, 1, 1, 1) - 0.5) * 2.0) < 1e-5
+        m.clear_cache()
+        assert m._conv_idx == [0] and len(m._feat_map) == m._conv_num > 0 and len(m._enc_feat_map) == m._enc_conv_num > 0
 
 
 def test_vae_planar_staging_host_logic(monkeypatch):
