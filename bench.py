@@ -408,10 +408,31 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-        ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)                           # proves every rank is on the RCCL communicator
-        rccl_ranks = int(ones.item())
+        # bring-up = what --launch-check does; a failure here (no RCCL transport between the GPUs, a rank that never arrives, a
+        # sub-group that cannot be created) is reported as ONE JSON diagnostic line instead of a bare non-zero exit code
+        stage = "init_process_group(nccl)"
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            stage = "all_reduce"
+            ones = torch.ones(1, device=dev)
+            dist.all_reduce(ones)                       # proves every rank is on the RCCL communicator
+            rccl_ranks = int(ones.item())
+            if args.mode == "denoise":
+                stage = "new_group (sequence / CFG-parallel sub-groups)"
+                probe = dist.new_group(list(range(world)))
+                dist.barrier(group=probe)
+                dist.destroy_process_group(probe)
+        except Exception as ex:
+            print(json.dumps({"metric": "4D-STraG denoise-steps/sec, 49x480x832 bf16", "value": None, "n_gpus": world, "valid": False,
+                              "error": {"stage": stage, "rank": rank, "local_rank": local_rank, "exception": repr(ex)[:600],
+                                        "visible_gpus": torch.cuda.device_count(), "backend": "nccl (RCCL)",
+                                        "ranks_seen": rccl_ranks,
+                                        "env": {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE",
+                                                                               "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")}}}),
+                  flush=True)
+            raise SystemExit(3)
+        if rccl_ranks != world and rank == 0:
+            print(json.dumps({"warning": f"RCCL all-reduce counted {rccl_ranks} ranks, WORLD_SIZE is {world}"}), file=sys.stderr, flush=True)
     if args.mode == "train":
         return train_mode(args, world, rank, local_rank, dev, rccl_ranks, overrides)
 

@@ -292,8 +292,9 @@ int m4d_bilinear_cl(m4d_dtype dt, const void* x, void* out, int B, int Hi, int W
  *   with nan / < 1e-5 replaced by 1 (:823-825).
  * depth_control (:826-828): out [3, hw] (dtype out_dt) = 2 (zclean - min) / (max - min + 1e-8) - 1, three identical channels.
  * flow_recover: rel [B,3,F,hw] (dtype in_dt) = decoded displacements, frame0 float [B,3,hw] = first-frame coordinates;
- *   out float [B,3,F,hw]: frame 0 = frame0 (:870), frames f > 0 = (rel + frame0/diff) * diff with diff = max over the three
- *   axes of (max - min) of frame0 (0 -> 1), minmax float [B*3, 2] from m4d_minmax (mode 0, inverse_flow_norm_transform_no_diff
+ *   out float [B,3,F,hw]: frame 0 = frame0 (:870; mode | 2 keeps the recovered frame 0 instead, what :198-219 itself returns),
+ *   frames f > 0 = (rel + frame0/diff) * diff with diff = max over the three
+ *   axes of (max - min) of frame0 (0 -> 1), minmax float [B*3, 2] from m4d_minmax (fminf / fmaxf: NaN inputs are skipped where torch.min / max would propagate them) (mode 0, inverse_flow_norm_transform_no_diff
  *   :198-219), or rel + frame0 (mode 1, --normalize_track_z :857-861; minmax may be NULL). */
 int m4d_minmax(const float* x, int64_t n_groups, int64_t group_len, float* out, m4d_stream stream);
 int m4d_backproject(const float* depth, int H, int W, float inv_fx, float inv_fy, float* coords, float* zclean, m4d_stream stream);

@@ -481,11 +481,15 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     const bool halo_shape = conv_variant == 3 && v2_base && kw == 3 && kh == 3 && (kt == 3 || kt == 1) && pad_t == 0 && pad_h == 1 &&
                             pad_w == 1 && Ho == (Hin << ups) && Wo == (Win << ups) && To == (Tin << tsplit) - kt + 1 && Cin % 16 == 0 &&
                             (!tsplit || kt == 1);
-    if (v2_shape && xbytes >= (1ll << 31) - (1ll << 20) && kt == 1 && pad_t == 0 && To == Tin) {
+    // byte extent the kernel this problem lands on can address: the LDS-halo kernel takes unsigned 32-bit offsets into a raw buffer
+    // descriptor (just under 2 GiB), the DMA-gather implicit GEMM (1x1 shortcut convs, M4D_CONV_VARIANT=2) signed 31-bit element
+    // arithmetic on 2-byte elements (1 GiB)
+    const int64_t xlimit = halo_shape ? (1ll << 31) - (1ll << 20) : (1ll << 30);
+    if (v2_shape && xbytes >= xlimit && kt == 1 && pad_t == 0 && To == Tin) {
         // 2-D convolution over many frames (the adaptors: 49 x 480 x 832 x 128): frames are independent, so launch groups of
-        // frames whose input fits the kernel's 31-bit offsets
+        // frames whose input fits the target kernel's offsets (otherwise the group would fall through to the register-staged kernel)
         const int64_t frame_bytes = (int64_t)Hin * Win * x_pixel_stride * 2;
-        const int per = (int)std::max<int64_t>(1, ((1ll << 31) - (1ll << 20) - 1) / frame_bytes);
+        const int per = (int)std::max<int64_t>(1, (xlimit - 1) / frame_bytes);
         for (int f0 = 0; f0 < Tin; f0 += per) {
             const int nf = std::min(per, Tin - f0);
             const int rc = m4d_conv_cl(dt, (const char*)x + (int64_t)f0 * frame_bytes, x_pixel_stride, w, bias,

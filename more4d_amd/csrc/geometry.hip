@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void depth_control_kernel(const float* zclean,
     }
 }
 
-// out[b, c, 0] = frame0[b, c]; out[b, c, f > 0] = (rel + frame0 / diff_b) * diff_b   (mode 0, infer.py:198-219, :870)
-//                                             or  rel + frame0                      (mode 1, --normalize_track_z :857-861)
+// out[b, c, f] = (rel + frame0 / diff_b) * diff_b   (mode 0 / 2, infer.py:198-219)   or   rel + frame0   (mode 1 / 3, --normalize_track_z
+// :857-861); modes 0 / 1 replace frame 0 by frame0[b, c] itself (the stored point cloud of :870), modes 2 / 3 keep the recovered frame 0
+// (what the reference's inverse_flow_norm_transform_no_diff returns)
 template <typename T>
 __global__ __launch_bounds__(256) void flow_recover_kernel(const T* rel, const float* frame0, const float* minmax, float* out, int B,
                                                            int F, int64_t hw, int mode) {
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256) void flow_recover_kernel(const T* rel, const f
         const int b = (int)(r / 3);
         const float f0 = frame0[((int64_t)b * 3 + c) * hw + p];
         float v;
-        if (f == 0) v = f0;
-        else if (mode == 1) v = (float)rel[i] + f0;
+        if (f == 0 && !(mode & 2)) v = f0;
+        else if (mode & 1) v = (float)rel[i] + f0;
         else {
             const float* mm = minmax + (int64_t)b * 6;
             float diff = fmaxf(fmaxf(mm[1] - mm[0], mm[3] - mm[2]), mm[5] - mm[4]);
@@ -112,7 +113,7 @@ extern "C" int m4d_depth_control(m4d_dtype out_dt, const float* zclean, const fl
 extern "C" int m4d_flow_recover(m4d_dtype in_dt, const void* rel, const float* frame0, const float* minmax, float* out, int B, int F,
                                 int64_t hw, int mode, m4d_stream stream) {
     M4D_CHECK_ARG(rel && frame0 && out && B > 0 && F > 0 && hw > 0, "flow_recover: null/empty");
-    M4D_CHECK_ARG(mode == 1 || (mode == 0 && minmax), "flow_recover: mode 0 needs the first frame's per-channel min/max");
+    M4D_CHECK_ARG(mode >= 0 && mode <= 3 && ((mode & 1) || minmax), "flow_recover: modes 0 / 2 need the first frame's per-channel min/max");
     const dim3 grid(grid_for((int64_t)B * 3 * F * hw));
     if (in_dt == M4D_BF16) hipLaunchKernelGGL(flow_recover_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)rel, frame0, minmax, out, B, F, hw, mode);
     else if (in_dt == M4D_F32) hipLaunchKernelGGL(flow_recover_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)rel, frame0, minmax, out, B, F, hw, mode);

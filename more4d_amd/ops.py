@@ -774,8 +774,12 @@ def depth_control(zclean, mm, out_dtype):
     return out
 
 
-def flow_recover(rel, frame0, mm=None, track_z=False):
-    """rel [B,3,F,H,W] (T), frame0 float32 [B,3,H,W], mm float32 [B*3,2] -> float32 [B,3,F,H,W] point trajectories."""
+def flow_recover(rel, frame0, mm=None, track_z=False, first_frame="coords"):
+    """rel [B,3,F,H,W] (T), frame0 float32 [B,3,H,W], mm float32 [B*3,2] -> float32 [B,3,F,H,W] point trajectories.
+    first_frame: "coords" = frame 0 of the result is frame0 itself (the stored cloud, infer.py:870), "recovered" = computed like every
+    other frame (what the reference's inverse_flow_norm_transform_no_diff returns)."""
+    if first_frame not in ("coords", "recovered"):
+        raise ValueError("flow_recover: first_frame must be 'coords' or 'recovered'")
     _dev(rel, frame0, mm)
     rel = rel.contiguous()
     B, C, F, H, W = rel.shape
@@ -783,7 +787,7 @@ def flow_recover(rel, frame0, mm=None, track_z=False):
         raise ValueError("flow_recover: rel [B,3,F,H,W], frame0 float32 contiguous [B,3,H,W]")
     out = torch.empty((B, 3, F, H, W), device=rel.device, dtype=torch.float32)
     check(_lib.load().m4d_flow_recover(dt_code(rel.dtype), _ptr(rel), _ptr(frame0), _ptr(mm), _ptr(out), B, F, H * W,
-                                       1 if track_z else 0, _stream()), "m4d_flow_recover")
+                                       (1 if track_z else 0) | (2 if first_frame == "recovered" else 0), _stream()), "m4d_flow_recover")
     return out
 
 

@@ -47,11 +47,13 @@ def depth_conditioning(depth_map, H, W, dtype=torch.float32):
 
 def inverse_flow_norm_transform_no_diff(rel_flow, first_frame_coords):
     """Decoded displacement video [B,3,F,H,W] + first-frame coordinates [1 or B,3,1,H,W] -> (recovered points [B,3,F,H,W],
-    diff [B,3]) (infer.py:198-219).  Frame 0 of the result is the first frame's coordinates themselves (what :870 stores)."""
+    diff [B,3]) (infer.py:198-219), frame 0 included: (rel[:, :, 0] + f0 / diff) * diff like the reference (its caller drops that frame
+    for the first-frame coordinates, :870 — `recover_stage1_coords` below).  The per-channel min / max come from `m4d_minmax` (fminf /
+    fmaxf: a NaN coordinate is skipped, where torch.min / max would propagate it)."""
     B, _, F, H, W = rel_flow.shape
     f0 = first_frame_coords[:, :, 0].to(rel_flow.device, torch.float32).expand(B, 3, H, W).contiguous()
     mm = ops.minmax(f0, B * 3)
-    out = ops.flow_recover(rel_flow, f0, mm)
+    out = ops.flow_recover(rel_flow, f0, mm, first_frame="recovered")
     ext = (mm[:, 1] - mm[:, 0]).view(B, 3).max(dim=1).values
     diff = torch.where(ext == 0, torch.ones_like(ext), ext)
     return out, diff.view(B, 1).repeat(1, 3)

@@ -192,7 +192,7 @@ def test_geometry_kernels_vs_oracle():
     f0 = torch.randn(1, 3, 1, H, W, generator=g) * 2
     want, wdiff = og.recover_flow(rel, f0)
     got, gdiff = geo.inverse_flow_norm_transform_no_diff(rel.to(DEV), f0.to(DEV))
-    assert rel_err(got[:, :, 1:].cpu(), want[:, :, 1:]) < 1e-6 and rel_err(gdiff.cpu(), wdiff) < 1e-7
+    assert rel_err(got.cpu(), want) < 1e-6 and rel_err(gdiff.cpu(), wdiff) < 1e-7       # frame 0 included
     coords = geo.recover_stage1_coords(rel.to(DEV), f0.to(DEV))
     assert rel_err(coords.cpu(), og.stage1_coords(rel, f0)) < 1e-6
     cz = geo.recover_stage1_coords(rel.to(DEV), f0.to(DEV), normalize_track_z=True)
@@ -245,7 +245,7 @@ def test_stage1_chain_matches_reference():
         coords = geo.recover_stage1_coords(recon, ffc)
         assert rel_err(coords.cpu(), z["coords_rel"]) < 1e-3
         flow, diff = geo.inverse_flow_norm_transform_no_diff(z["recon"].to(DEV), z["first_frame_coords"].to(DEV))
-        assert rel_err(flow[:, :, 1:].cpu(), z["flow_rel"][:, :, 1:]) < 1e-6 and rel_err(diff.cpu(), z["diff"]) < 1e-7
+        assert rel_err(flow.cpu(), z["flow_rel"]) < 1e-6 and rel_err(diff.cpu(), z["diff"]) < 1e-7
 
 
 def _run_sharded(m, kw, world, mode):
@@ -301,7 +301,50 @@ def test_n_rank_schedule_full_size_bf16(mode, world):
               full_ref=torch.randn(1, 16, H_, W_, generator=g, device=DEV).to(BF))
     with torch.no_grad():
         single = m(**kw).float()
-    outs = _run_sharded(m, kw, world, mode)
+    #  the end-to-end budget below would not notice a wrong-but-close merge on a few rows: record the FIRST
+    # local-first merge of every emulated rank (layer 0) and recompute sampled (query, head) rows of it in fp32 over ALL keys
+    import threading
+    import more4d_amd.ops as ops
+    rec, tl = {}, threading.local()
+    o_att, o_merge = ops.attention, ops.attn_merge_
+
+    def att(q, segs, **kk):
+        out = o_att(q, segs, **kk)
+        if kk.get("lse") is not None and not getattr(tl, "done", False):
+            tl.calls = getattr(tl, "calls", []) + [(q, list(segs), out)]
+        return out
+
+    def merge(o_a, lse_a, o_b, lse_b, **kk):
+        res = o_merge(o_a, lse_a, o_b, lse_b, **kk)
+        if not getattr(tl, "done", False):
+            tl.done = True
+            (q, loc, _), (_, rem, _) = tl.calls[-2:]
+            rec[threading.get_ident()] = (q, loc + rem, o_a.clone(), kk)
+        return res
+    ops.attention, ops.attn_merge_ = att, merge
+    try:
+        outs = _run_sharded(m, kw, world, mode)
+    finally:
+        ops.attention, ops.attn_merge_ = o_att, o_merge
+    if mode == "allgather":
+        assert len(rec) == world, (len(rec), world)                    # every rank merged a local and a remote partial softmax
+        worst = 0.0
+        for q, segs, merged, kk in rec.values():
+            B_, Lq, n, d = kk["B"], kk["L"], kk["heads"], kk["head_dim"]
+            C_ = n * d
+            assert B_ == 1 and sum(s_.len for s_ in segs) == kw["seq_len"] + H_ * W_ // 4      # all real keys, each exactly once
+            qf = q.view(Lq, C_)
+            for row in (0, Lq // 2, Lq - 1):
+                for h in (0, n // 2, n - 1):
+                    sl = slice(h * d, (h + 1) * d)
+                    sc = torch.cat([s_.k.reshape(-1, C_)[:s_.len, sl].float() @ qf[row, sl].float() for s_ in segs]) * d ** -0.5
+                    p = torch.softmax(sc, dim=0)
+                    vs = torch.cat([s_.vt[sl, :s_.len].float() for s_ in segs], dim=1)           # [d, keys]
+                    want = vs @ p
+                    got = merged.view(Lq, C_)[row, sl].float()
+                    worst = max(worst, float((got - want).abs().max() / want.abs().max()))
+        print(f"merged attention vs fp32 over all keys: worst sampled row {worst:.2e}")
+        assert worst < 1.5e-2          # two bf16 roundings (partial outputs, merged output) of a ~N(0, 1/sqrt(keys)) result
     for o in outs:
         assert torch.equal(o, outs[0])                                  # every rank ends with the same gathered output
     err = rms_rel_err(outs[0].float().cpu(), single.cpu())
