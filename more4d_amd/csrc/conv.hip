@@ -33,6 +33,7 @@ struct ConvArgs {
     int abl;               // timing ablations (tool builds only)
     int64_t xplane;        // != 0: input is planar-16, [Cin/16][rows][16] with xplane elements between planes (conv_halo_kernel only)
     const float* post_gamma; void* post_out; int64_t post_plane; int post_silu;      // fused RMS_norm(+SiLU) of the next layer (conv_halo.h)
+    unsigned long long* dbg;   // tool builds only (M4D_CONV_ABL & 64): per-workgroup timestamps, 8 words each (tools/conv_timeline.py)
     float* gn_partial;     // per-patch GroupNorm(32 x 4 channels) statistics of the result, [To][patches][32][2] (Cout = 128)
 };
 
@@ -467,9 +468,12 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.To = To; p.Ho = Ho; p.Wo = Wo; p.ups = ups; p.tsplit = tsplit;
     p.M = (int64_t)To * Ho * Wo;
     p.K = (int64_t)kt * kh * kw * Cin;
-    p.abl = 0; p.xplane = 0; p.post_gamma = nullptr; p.post_out = nullptr; p.post_plane = 0; p.post_silu = 0; p.gn_partial = nullptr;
+    p.abl = 0; p.xplane = 0; p.post_gamma = nullptr; p.post_out = nullptr; p.post_plane = 0; p.post_silu = 0; p.gn_partial = nullptr; p.dbg = nullptr;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0); p.abl = conv_abl; }
+    { static unsigned long long* dbgp = nullptr; static bool rd = false;
+      if (!rd) { rd = true; const char* v = getenv("M4D_CONV_DBG_PTR"); if (v) dbgp = (unsigned long long*)strtoull(v, nullptr, 0); }
+      p.dbg = dbgp; }
     { M4D_ENV_ONCE(conv_planar, "M4D_CONV_PLANAR", 0); if (conv_planar) p.xplane = (int64_t)Tin * Hin * Win * 16; }     // timing experiment: same bytes read as planar-16
 #endif
     // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
@@ -580,7 +584,7 @@ static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stri
     p.To = To; p.Ho = Hin; p.Wo = Win; p.ups = 0; p.tsplit = 0;
     p.M = (int64_t)To * Hin * Win;
     p.K = (int64_t)kt * 9 * Cin;
-    p.abl = 0; p.xplane = x_plane_stride;
+    p.abl = 0; p.xplane = x_plane_stride; p.dbg = nullptr;
     p.post_gamma = norm_gamma; p.post_out = norm_out; p.post_plane = norm_plane; p.post_silu = norm_silu; p.gn_partial = gn_partial;
     const bool wide = (Win % 32 == 0) || Win >= 256;
     int rc;

@@ -45,7 +45,9 @@ struct Cfg {
     static constexpr int PE = (TW + 1 + 7) / 8 * 8;
     static constexpr int HH = SD == 2 ? 2 * TH + 1 : TH + KH - 1;
     static constexpr int PITCH = SD == 2 ? 2 * PE : (TW + KW - 1 + 7) / 8 * 8;     // (a multiple of 8 pixels = 256 B keeps the bank pattern of a row)
-    static constexpr int NPIX = KT * HH * PITCH;
+    // (the pitch padding behind the last row is never read: trimming it is what lets the 12 x 32 x 3-frame halo + THREE weight buffers
+    //  fit one half of the CU's LDS, i.e. weight groups requested two steps ahead instead of one)
+    static constexpr int NPIX = KT * HH * PITCH - (SD == 1 ? PITCH - (TW + KW - 1) : 0);
     static constexpr int HINSTR = ((NPIX * 2 + 63) / 64 + NWAVE - 1) / NWAVE * NWAVE;    // 1 KiB wave-instructions per halo, a multiple of the waves
     static constexpr int HALO_BYTES = HINSTR * 1024;
     static constexpr int WG_BYTES = KW * WTAP;                            // one (dt, dh) group of 3 taps
@@ -62,6 +64,8 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
     using namespace halo;
     typedef bf16_t T;
     using C = Cfg<KT, KH, TH, TW, NT, MT, SD>;
+    unsigned long long ts[4] = {0, 0, 0, 0}, rt0 = 0;
+    if (M4D_ABL(p) & 64) { ts[0] = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     static_assert(SD == 1 || (SD == 2 && KT == 1), "stride 2: the 2-D down-sampling conv");
     constexpr int NWAVE = C::NWAVE, NB = C::NB, WTAP = C::WTAP, HH = C::HH, PITCH = C::PITCH, NPIX = C::NPIX, HINSTR = C::HINSTR;
     constexpr int HALO_BYTES = C::HALO_BYTES, WG_BYTES = C::WG_BYTES, NWB = C::NWB, EROW = C::EROW;
@@ -102,6 +106,13 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         0x00027000);                                       // (physical extent, < 2 GiB)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
     const int plane_bytes = (int)(p.xplane * 2);            // planar-16 input: [Cin/16][rows >= Tin*Hin*Win][16], p.xplane elements between planes
+    // ROLL (three-frame halos): the halo of the next 16-channel chunk replaces the current one FRAME BY FRAME — frame f is re-staged
+    // right after the last step that reads it (step (f, KH - 1)), six steps before its first use in the next chunk — instead of all
+    // at once between two chunks with the DMA latency exposed (measured with the timeline build: 21 % of the 96 -> 96 decoder conv).
+    // Pieces are 1 KiB = 32 pixels and frames are not piece aligned, so a piece that straddles two frames is issued under an EXEC mask
+    // (inactive lanes write nothing).  hfr: 2 bits per piece = the frame of this lane's pixel (3 = beyond the halo).
+    constexpr bool ROLL = KT == 3 && SD == 1;
+    unsigned hfr = 0;
     int hoff[HPW];
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
@@ -122,6 +133,7 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         }
         const int64_t pix = ((int64_t)(ti >> p.tsplit) * p.Hin + (hi_ >> p.ups)) * p.Win + (wi >> p.ups);
         hoff[i] = ok ? (int)(pix * (p.xplane ? 32 : p.xs * 2)) + (p.tsplit ? (ti & 1) * p.Cin * 2 : 0) + c * 16 : -1;
+        if constexpr (ROLL) hfr |= (unsigned)(px < NPIX ? fdt : 3) << (2 * i);
     }
     int woff[WPW];          // (weights of one layer are far below 2 GiB)
 #pragma unroll
@@ -138,6 +150,22 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
 #pragma unroll
         for (int i = 0; i < HPW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * NWAVE + wave) * 1024), 16, hoff[i], soff, 0, 0);
+    };
+    // frame f of the chunk at channel ck0, under the lanes' frame mask; returns the number of DMA instructions this wave issued
+    int nhf[ROLL ? KT : 1] = {};
+    if constexpr (ROLL) {
+#pragma unroll
+        for (int f = 0; f < KT; ++f)
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) nhf[f] += __builtin_amdgcn_ballot_w64(((hfr >> (2 * i)) & 3u) == (unsigned)f) != 0 ? 1 : 0;
+    }
+    auto issue_halo_frame = [&](int ck0, int f) {
+        char* dst = conv_dyn_smem;
+        const int soff = p.xplane ? (ck0 >> 4) * plane_bytes : ck0 * 2;
+#pragma unroll
+        for (int i = 0; i < HPW; ++i)
+            if (((hfr >> (2 * i)) & 3u) == (unsigned)f)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * NWAVE + wave) * 1024), 16, hoff[i], soff, 0, 0);
     };
     auto issue_w = [&](int buf, int ck0, int g) {
         if (M4D_ABL(p) & 4) return;
@@ -180,27 +208,55 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
     // weight groups stream through a ring of NWB buffers, requested NWB-1 steps ahead (one step = MT*NT*3 MFMAs per wave is shorter
     // than an L2 round trip); jc/jg/jb = chunk, group and buffer of the next group to request
     int jc = 0, jg = 0, jb = 0;
-    auto next_w = [&]() {
-        if (jc < nchunk) issue_w(jb, jc * CK, jg);
+    const bool wfull = WINSTR % NWAVE == 0 || wave < WINSTR % NWAVE;       // this wave issues WPW (else WPW - 1) pieces per group
+    auto next_w = [&]() -> int {      // returns the number of DMA instructions this wave issued
+        const bool live = jc < nchunk;
+        if (live) issue_w(jb, jc * CK, jg);
         jb = jb + 1 == NWB ? 0 : jb + 1;
         if (++jg == NG) { jg = 0; ++jc; }
+        return live && !(M4D_ABL(p) & 4) ? (wfull ? WPW : WPW - 1) : 0;
     };
-    const bool wfull = WINSTR % NWAVE == 0 || wave < WINSTR % NWAVE;       // this wave issues WPW (else WPW - 1) pieces per group
     // wait until at most `n` of my weight groups are still in flight (everything older - halo pieces included - has landed)
 #define HL_WAIT_W(n)                                                                                             \
     do {                                                                                                         \
         if (wfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * WPW) : "memory");                              \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * (WPW - 1)) : "memory");                              \
     } while (0)
+    // wait until at most n of this wave's DMA instructions are outstanding (n is wave uniform; s_waitcnt takes an immediate)
+    auto wait_le = [&](int n) {
+        n = __builtin_amdgcn_readfirstlane(n);
+        switch (n) {
+#define HL_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+            HL_CASE(0) HL_CASE(1) HL_CASE(2) HL_CASE(3) HL_CASE(4) HL_CASE(5) HL_CASE(6) HL_CASE(7) HL_CASE(8) HL_CASE(9) HL_CASE(10)
+            HL_CASE(11) HL_CASE(12) HL_CASE(13) HL_CASE(14) HL_CASE(15) HL_CASE(16) HL_CASE(17) HL_CASE(18) HL_CASE(19) HL_CASE(20)
+#undef HL_CASE
+            default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;      // (fewer than asked for: stricter, still correct)
+        }
+    };
+    int wn1 = 0, h1 = 0, h2 = 0;      // ROLL: DMA instructions of the newest weight request / of the halo frames issued one and two steps ago
     next_w();
     issue_halo(0);
 #pragma unroll
-    for (int d = 1; d < NWB - 1; ++d) next_w();
+    for (int d = 1; d < NWB - 1; ++d) wn1 = next_w();
     int s = 0, rb = 0;
+    if (M4D_ABL(p) & 64) ts[1] = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int ci = 0; ci < nchunk; ++ci) {
 #pragma unroll 1
         for (int g = 0; g < NG; ++g, ++s) {       // (kept rolled: unrolled, hipcc hoists every fragment address and spills)
+            if constexpr (ROLL) {
+                // issue order of a step: [weight group s + NWB - 1][halo frame, every KH-th step].  Younger than weight group s, and
+                // allowed to stay in flight: NWB = 3: halo(s - 2), weights(s + 1), halo(s - 1); NWB = 2: halo(s - 1)
+                wait_le(NWB == 3 ? h2 + wn1 + h1 : h1);
+                if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
+                wn1 = next_w();
+                int hn = 0;
+                if (!(M4D_ABL(p) & 8)) {
+                    if (g == 0 && ci > 0) { issue_halo_frame(ci * CK, KT - 1); hn = nhf[KT - 1]; }      // last frame: free since step (ci - 1, NG - 1)
+                    else if (g > 0 && g % KH == 0 && ci + 1 < nchunk) { issue_halo_frame((ci + 1) * CK, g / KH - 1); hn = nhf[g / KH - 1]; }
+                }
+                h2 = h1; h1 = hn;
+            } else {
             // my share of weight group s (and of the first halo): group s+1 may stay in flight (NWB = 3)
             if (NWB == 2 || s + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else HL_WAIT_W(1);
@@ -216,6 +272,7 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
                 if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
             } else {
                 next_w();
+            }
             }
             const int fdt = g / KH, dh = g % KH;
             const unsigned hb = lds_base + (unsigned)((fdt * HH + dh) * PITCH * PXB);
@@ -261,6 +318,7 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
     // buffers, pixel-major with an XOR swizzle of the 16-byte chunks, and writes them back out as contiguous row segments ----
     const T* bias = (const T*)p.bias;
     const T* resid = (const T*)p.resid;
+    if (M4D_ABL(p) & 64) ts[2] = __builtin_readcyclecounter();
     __syncthreads();                                       // all fragment reads of the last step are done
     if (M4D_ABL(p) & 32) return;                           // ablation: no epilogue
     char* blk = conv_dyn_smem + wave * (32 * EROW);        // [32 pixels][NB channels] bf16; chunk c of pixel px at c ^ (px & ESW)
@@ -382,6 +440,18 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
                 *reinterpret_cast<uint2*>(dst) = make_uint2(raw.x, raw.y);
                 if (nb + 8 <= p.Cout) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(raw.z, raw.w);
             }
+        }
+    }
+    if (M4D_ABL(p) & 64) {          // tool build: entry / loop start / loop end / stores acknowledged, 100 MHz wall clock, hardware id
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[3] = __builtin_readcyclecounter();
+        if (t == 0 && p.dbg) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
+            d[0] = ts[0]; d[1] = ts[1]; d[2] = ts[2]; d[3] = ts[3]; d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+            d[6] = ((unsigned long long)xcc << 32) | hwid; d[7] = 1;
         }
     }
     if constexpr (NT == 4) {
