@@ -66,7 +66,8 @@ class KernelTimer:
     def __init__(self):
         self.rec = {}
 
-    def wrap(self, ops_mod, name, flops_fn):
+    def wrap(self, ops_mod, name, flops_fn, class_fn=None):
+        """class_fn(*args, **kwargs) -> suffix: launches are also summarised per class as `name:suffix`"""
         orig = getattr(ops_mod, name)
         timer = self
 
@@ -75,7 +76,10 @@ class KernelTimer:
             s.record()
             out = orig(*a, **k)
             e.record()
-            timer.rec.setdefault(name, []).append((s, e, flops_fn(*a, **k)))
+            rec = (s, e, flops_fn(*a, **k))
+            timer.rec.setdefault(name, []).append(rec)
+            if class_fn is not None:
+                timer.rec.setdefault(f"{name}:{class_fn(*a, **k)}", []).append(rec)
             return out
         setattr(ops_mod, name, timed)
         return orig
@@ -498,7 +502,8 @@ def main():
             def attn_flops(q, segs, *aa, **kk):
                 klen = sum(max(0, s.len) for s in segs)
                 return 4 * kk["B"] * kk["Lq"] * klen * kk["heads"] * kk["head_dim"]
-            originals = {"gemm_bt": kt.wrap(ops, "gemm_bt", gemm_flops), "attention": kt.wrap(ops, "attention", attn_flops)}
+            originals = {"gemm_bt": kt.wrap(ops, "gemm_bt", gemm_flops), "attention": kt.wrap(ops, "attention", attn_flops,
+                                              lambda q, segs, **kk: "cross" if sum(sg.len for sg in segs) < 2048 else "self")}
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -581,6 +586,11 @@ def main():
                 "kernel": "attn128p_kernel (self) + attn128_kernel<4> (cross) via m4d_attention", "bound": "mfma", "achieved": ak.get("tflops", 0.0),
                 "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ak.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
                 "launches": ak.get("launches", 0), "share_of_step_time": ak.get("ms", 0.0) / (dt * 1e3),
+                "by_class": {c: {"achieved": ks.get(f"attention:{c}", {}).get("tflops", 0.0),
+                                 "frac": ks.get(f"attention:{c}", {}).get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
+                                 "launches": ks.get(f"attention:{c}", {}).get("launches", 0),
+                                 "share_of_step_time": ks.get(f"attention:{c}", {}).get("ms", 0.0) / (dt * 1e3)}
+                             for c in ("self", "cross")},
             }
         if world == 1 and not args.no_secondary and args.layers == 40:
             out["secondary"] = secondary_figures(model, cfg, dev)

@@ -144,6 +144,8 @@ def load():
             "(the HIP extension is the only compute path; there is no CPU fallback)")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if ABLATION_BUILD and not hasattr(lib, name):
+            continue             # side builds for same-box A/B (M4D_LIB=<tag>) may predate an entry point; the shipping library may not
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

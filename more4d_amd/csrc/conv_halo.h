@@ -106,13 +106,6 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         0x00027000);                                       // (physical extent, < 2 GiB)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
     const int plane_bytes = (int)(p.xplane * 2);            // planar-16 input: [Cin/16][rows >= Tin*Hin*Win][16], p.xplane elements between planes
-    // ROLL (three-frame halos): the halo of the next 16-channel chunk replaces the current one FRAME BY FRAME — frame f is re-staged
-    // right after the last step that reads it (step (f, KH - 1)), six steps before its first use in the next chunk — instead of all
-    // at once between two chunks with the DMA latency exposed (measured with the timeline build: 21 % of the 96 -> 96 decoder conv).
-    // Pieces are 1 KiB = 32 pixels and frames are not piece aligned, so a piece that straddles two frames is issued under an EXEC mask
-    // (inactive lanes write nothing).  hfr: 2 bits per piece = the frame of this lane's pixel (3 = beyond the halo).
-    constexpr bool ROLL = KT == 3 && SD == 1;
-    unsigned hfr = 0;
     int hoff[HPW];
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
@@ -133,7 +126,6 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         }
         const int64_t pix = ((int64_t)(ti >> p.tsplit) * p.Hin + (hi_ >> p.ups)) * p.Win + (wi >> p.ups);
         hoff[i] = ok ? (int)(pix * (p.xplane ? 32 : p.xs * 2)) + (p.tsplit ? (ti & 1) * p.Cin * 2 : 0) + c * 16 : -1;
-        if constexpr (ROLL) hfr |= (unsigned)(px < NPIX ? fdt : 3) << (2 * i);
     }
     int woff[WPW];          // (weights of one layer are far below 2 GiB)
 #pragma unroll
@@ -150,22 +142,6 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
 #pragma unroll
         for (int i = 0; i < HPW; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * NWAVE + wave) * 1024), 16, hoff[i], soff, 0, 0);
-    };
-    // frame f of the chunk at channel ck0, under the lanes' frame mask; returns the number of DMA instructions this wave issued
-    int nhf[ROLL ? KT : 1] = {};
-    if constexpr (ROLL) {
-#pragma unroll
-        for (int f = 0; f < KT; ++f)
-#pragma unroll
-            for (int i = 0; i < HPW; ++i) nhf[f] += __builtin_amdgcn_ballot_w64(((hfr >> (2 * i)) & 3u) == (unsigned)f) != 0 ? 1 : 0;
-    }
-    auto issue_halo_frame = [&](int ck0, int f) {
-        char* dst = conv_dyn_smem;
-        const int soff = p.xplane ? (ck0 >> 4) * plane_bytes : ck0 * 2;
-#pragma unroll
-        for (int i = 0; i < HPW; ++i)
-            if (((hfr >> (2 * i)) & 3u) == (unsigned)f)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (LDS_AS void*)(dst + (i * NWAVE + wave) * 1024), 16, hoff[i], soff, 0, 0);
     };
     auto issue_w = [&](int buf, int ck0, int g) {
         if (M4D_ABL(p) & 4) return;
@@ -209,12 +185,10 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
     // than an L2 round trip); jc/jg/jb = chunk, group and buffer of the next group to request
     int jc = 0, jg = 0, jb = 0;
     const bool wfull = WINSTR % NWAVE == 0 || wave < WINSTR % NWAVE;       // this wave issues WPW (else WPW - 1) pieces per group
-    auto next_w = [&]() -> int {      // returns the number of DMA instructions this wave issued
-        const bool live = jc < nchunk;
-        if (live) issue_w(jb, jc * CK, jg);
+    auto next_w = [&]() {
+        if (jc < nchunk) issue_w(jb, jc * CK, jg);
         jb = jb + 1 == NWB ? 0 : jb + 1;
         if (++jg == NG) { jg = 0; ++jc; }
-        return live && !(M4D_ABL(p) & 4) ? (wfull ? WPW : WPW - 1) : 0;
     };
     // wait until at most `n` of my weight groups are still in flight (everything older - halo pieces included - has landed)
 #define HL_WAIT_W(n)                                                                                             \
@@ -222,41 +196,16 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         if (wfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * WPW) : "memory");                              \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * (WPW - 1)) : "memory");                              \
     } while (0)
-    // wait until at most n of this wave's DMA instructions are outstanding (n is wave uniform; s_waitcnt takes an immediate)
-    auto wait_le = [&](int n) {
-        n = __builtin_amdgcn_readfirstlane(n);
-        switch (n) {
-#define HL_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-            HL_CASE(0) HL_CASE(1) HL_CASE(2) HL_CASE(3) HL_CASE(4) HL_CASE(5) HL_CASE(6) HL_CASE(7) HL_CASE(8) HL_CASE(9) HL_CASE(10)
-            HL_CASE(11) HL_CASE(12) HL_CASE(13) HL_CASE(14) HL_CASE(15) HL_CASE(16) HL_CASE(17) HL_CASE(18) HL_CASE(19) HL_CASE(20)
-#undef HL_CASE
-            default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;      // (fewer than asked for: stricter, still correct)
-        }
-    };
-    int wn1 = 0, h1 = 0, h2 = 0;      // ROLL: DMA instructions of the newest weight request / of the halo frames issued one and two steps ago
     next_w();
     issue_halo(0);
 #pragma unroll
-    for (int d = 1; d < NWB - 1; ++d) wn1 = next_w();
+    for (int d = 1; d < NWB - 1; ++d) next_w();
     int s = 0, rb = 0;
     if (M4D_ABL(p) & 64) ts[1] = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int ci = 0; ci < nchunk; ++ci) {
 #pragma unroll 1
         for (int g = 0; g < NG; ++g, ++s) {       // (kept rolled: unrolled, hipcc hoists every fragment address and spills)
-            if constexpr (ROLL) {
-                // issue order of a step: [weight group s + NWB - 1][halo frame, every KH-th step].  Younger than weight group s, and
-                // allowed to stay in flight: NWB = 3: halo(s - 2), weights(s + 1), halo(s - 1); NWB = 2: halo(s - 1)
-                wait_le(NWB == 3 ? h2 + wn1 + h1 : h1);
-                if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
-                wn1 = next_w();
-                int hn = 0;
-                if (!(M4D_ABL(p) & 8)) {
-                    if (g == 0 && ci > 0) { issue_halo_frame(ci * CK, KT - 1); hn = nhf[KT - 1]; }      // last frame: free since step (ci - 1, NG - 1)
-                    else if (g > 0 && g % KH == 0 && ci + 1 < nchunk) { issue_halo_frame((ci + 1) * CK, g / KH - 1); hn = nhf[g / KH - 1]; }
-                }
-                h2 = h1; h1 = hn;
-            } else {
             // my share of weight group s (and of the first halo): group s+1 may stay in flight (NWB = 3)
             if (NWB == 2 || s + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else HL_WAIT_W(1);
@@ -272,7 +221,6 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
                 if (!(M4D_ABL(p) & 16)) __builtin_amdgcn_s_barrier();
             } else {
                 next_w();
-            }
             }
             const int fdt = g / KH, dh = g % KH;
             const unsigned hb = lds_base + (unsigned)((fdt * HH + dh) * PITCH * PXB);
@@ -319,12 +267,48 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
     const T* bias = (const T*)p.bias;
     const T* resid = (const T*)p.resid;
     if (M4D_ABL(p) & 64) ts[2] = __builtin_readcyclecounter();
+    // the bias of this lane's NT x 4 channel quads: the same for every pixel tile, loaded ONCE and before the barrier (the loads were
+    // inside the mi / ni / rq loops: MT x NT x 4 dependent L2 round trips in front of the first store)
+    bf16x4 bv[NT][4];                                      // (kept packed: 2 registers per quad)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int nb = n0 + ni * 32 + rq * 8 + hi * 4;
+            bv[ni][rq] = (bias && nb < p.Cout) ? *reinterpret_cast<const bf16x4*>(bias + nb) : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        }
     __syncthreads();                                       // all fragment reads of the last step are done
     if (M4D_ABL(p) & 32) return;                           // ablation: no epilogue
     char* blk = conv_dyn_smem + wave * (32 * EROW);        // [32 pixels][NB channels] bf16; chunk c of pixel px at c ^ (px & ESW)
     float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};       // GroupNorm statistics of the result (p.gn_partial): this lane's two 4-channel groups
+    // fused next-layer norm: 16 lanes per pixel, lane & 15 = this lane's 8-channel chunk in EVERY read-back iteration, so its gamma
+    // is loaded once (it was two dependent loads per iteration behind a branch)
+    f32x4 pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0;
+    if (p.post_out && (lane & 15) < NT * 4) { pg0 = load4(p.post_gamma + (lane & 15) * 8); pg1 = load4(p.post_gamma + (lane & 15) * 8 + 4); }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {                      // (a wave's LDS operations execute in order: round mi+1 may overwrite the block)
+        // shortcut / residual rows of this round's pixels: requested BEFORE the accumulators go through LDS, so that the L2 round
+        // trip overlaps the conversion + LDS transposition instead of sitting between the read-back and the store
+        constexpr int NJ = (32 * NT * 4 + 63) / 64;
+        uint4 rpre[NJ];
+        // (MT = 3 kernels sit at the 256-register limit: the prefetch would spill)
+        const bool rwide = MT < 3 && resid && !p.post_out && ((p.ldo | p.ldr) & 7) == 0 && (p.Cout & 7) == 0;
+        if (rwide) {
+            const int mt_ = wave * MT + mi;
+            const int row0_ = TW == 32 ? mt_ : mt_ * ROWS_PER_MT;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int q = j * 64 + lane;
+                const int pl = q / (NT * 4), ch = q % (NT * 4);
+                const int row = TW == 32 ? row0_ : row0_ + pl / TW;
+                const int col = TW == 32 ? pl : pl % TW;
+                const int ho = h0 + row, wo = w0 + col;
+                const int nb = n0 + ch * 8;
+                rpre[j] = make_uint4(0, 0, 0, 0);
+                if (pl < 32 && ho < p.Ho && wo < p.Wo && nb < p.Cout)
+                    rpre[j] = *reinterpret_cast<const uint4*>(resid + (((int64_t)to * p.Ho + ho) * p.Wo + wo) * p.ldr + nb);
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -334,7 +318,10 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][rq * 4 + e];
-                if (bias && nb < p.Cout) v += load4(bias + nb);
+                if (bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)bv[ni][rq][e];
+                }
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
@@ -389,7 +376,7 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
                 bf16x8 y;
 #pragma unroll
                 for (int e = 0; e < 8; e += 4) {
-                    const f32x4 g = load4(p.post_gamma + ch * 8 + e);
+                    const f32x4 g = e == 0 ? pg0 : pg1;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float u = v[e + k] * sc * g[k];
@@ -416,7 +403,8 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
             const bool wide = nb + 8 <= p.Cout && ((p.ldo | (resid ? p.ldr : 0)) & 7) == 0;      // else 4-channel halves (Cout % 4 == 0)
             if (resid) {
                 bf16_t rr[8] = {};
-                if (wide) *reinterpret_cast<uint4*>(rr) = *reinterpret_cast<const uint4*>(resid + m * p.ldr + nb);
+                if (rwide) *reinterpret_cast<uint4*>(rr) = rpre[j];
+                else if (wide) *reinterpret_cast<uint4*>(rr) = *reinterpret_cast<const uint4*>(resid + m * p.ldr + nb);
                 else {
                     *reinterpret_cast<uint2*>(rr) = *reinterpret_cast<const uint2*>(resid + m * p.ldr + nb);
                     if (nb + 8 <= p.Cout) *reinterpret_cast<uint2*>(rr + 4) = *reinterpret_cast<const uint2*>(resid + m * p.ldr + nb + 4);
