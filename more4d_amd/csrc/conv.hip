@@ -443,6 +443,18 @@ int launch_halo_auto(ConvArgs& p, hipStream_t st) {
     return wide ? launch_halo_nt<1, 3, 8, 32>(p, st) : launch_halo_nt<1, 3, 16, 16>(p, st);
 }
 
+#ifdef M4D_ABLATIONS
+// tool builds: timing ablations (M4D_CONV_ABL) and the timeline buffer (M4D_CONV_DBG_PTR = device address, tools/conv_timeline.py)
+inline void conv_tool_switches(ConvArgs& p) {
+    M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0);
+    p.abl = conv_abl;
+    static unsigned long long* dbgp = nullptr;
+    static bool rd = false;
+    if (!rd) { rd = true; const char* v = getenv("M4D_CONV_DBG_PTR"); if (v) dbgp = (unsigned long long*)strtoull(v, nullptr, 0); }
+    p.dbg = dbgp;
+}
+#endif
+
 }  // namespace
 
 extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
@@ -470,10 +482,7 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     p.K = (int64_t)kt * kh * kw * Cin;
     p.abl = 0; p.xplane = 0; p.post_gamma = nullptr; p.post_out = nullptr; p.post_plane = 0; p.post_silu = 0; p.gn_partial = nullptr; p.dbg = nullptr;
 #ifdef M4D_ABLATIONS
-    { M4D_ENV_ONCE(conv_abl, "M4D_CONV_ABL", 0); p.abl = conv_abl; }
-    { static unsigned long long* dbgp = nullptr; static bool rd = false;
-      if (!rd) { rd = true; const char* v = getenv("M4D_CONV_DBG_PTR"); if (v) dbgp = (unsigned long long*)strtoull(v, nullptr, 0); }
-      p.dbg = dbgp; }
+    conv_tool_switches(p);
     { M4D_ENV_ONCE(conv_planar, "M4D_CONV_PLANAR", 0); if (conv_planar) p.xplane = (int64_t)Tin * Hin * Win * 16; }     // timing experiment: same bytes read as planar-16
 #endif
     // production kernel: bf16, unit stride, no fused up-sampling / time split, <= 32 taps, input extent addressable in 31 bits
@@ -585,6 +594,9 @@ static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stri
     p.M = (int64_t)To * Hin * Win;
     p.K = (int64_t)kt * 9 * Cin;
     p.abl = 0; p.xplane = x_plane_stride; p.dbg = nullptr;
+#ifdef M4D_ABLATIONS
+    conv_tool_switches(p);
+#endif
     p.post_gamma = norm_gamma; p.post_out = norm_out; p.post_plane = norm_plane; p.post_silu = norm_silu; p.gn_partial = gn_partial;
     const bool wide = (Win % 32 == 0) || Win >= 256;
     int rc;

@@ -284,7 +284,8 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
     // fused next-layer norm: 16 lanes per pixel, lane & 15 = this lane's 8-channel chunk in EVERY read-back iteration, so its gamma
     // is loaded once (it was two dependent loads per iteration behind a branch)
     f32x4 pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0;
-    if (p.post_out && (lane & 15) < NT * 4) { pg0 = load4(p.post_gamma + (lane & 15) * 8); pg1 = load4(p.post_gamma + (lane & 15) * 8 + 4); }
+    constexpr bool GAMMA_ONCE = NT < 4;       // (the 128-channel kernels are at the register limit with the shortcut prefetch: they load it per stage)
+    if (GAMMA_ONCE && p.post_out && (lane & 15) < NT * 4) { pg0 = load4(p.post_gamma + (lane & 15) * 8); pg1 = load4(p.post_gamma + (lane & 15) * 8 + 4); }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {                      // (a wave's LDS operations execute in order: round mi+1 may overwrite the block)
         // shortcut / residual rows of this round's pixels: requested BEFORE the accumulators go through LDS, so that the L2 round
@@ -337,54 +338,78 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
             // channels of its pixels, so the normalised result goes straight into the next conv's planar-16 staging buffer and the raw
             // output is written only if somebody else reads it (p.out).  16 lanes per pixel and the reduction order of
             // rmsnorm_silu_cl_kernel<T, 16, 1>: bit-identical to the separate kernel.
+            // Staged four iterations at a time so that the L2 round trips of the shortcut rows, the LDS reads and the dependent
+            // reduce -> sqrt -> divide -> SiLU chains of different pixels overlap (one iteration at a time, behind branches, the
+            // fused-norm epilogue took 29 us of a 100 us workgroup, 44 us with a shortcut: tools/conv_timeline.py); the 16-lane sum
+            // uses DPP row rotations by 8, 4, 2, 1 — the same operands per step as the xor butterfly of the separate kernel (after a
+            // step the values repeat with that period), so the bits are unchanged — instead of four LDS permutes.
+            const int ch = lane & 15;
+            const bool act = ch < CPP;
+            const float root_c = sqrtf((float)p.Cout);
+            constexpr int JG = NT == 4 ? 1 : 4;        // (the 128-channel kernels also carry the shortcut prefetch: fewer rows in flight)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int q = j * 64 + lane;
-                const int pl = q >> 4, ch = q & 15;
-                const bool act = ch < CPP;
-                const int row = TW == 32 ? row0 : row0 + pl / TW;
-                const int col = TW == 32 ? pl : pl % TW;
-                const int ho = h0 + row, wo = w0 + col;
-                const bool inside = ho < p.Ho && wo < p.Wo;
-                const int64_t m = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
-                float v[8];
+            for (int jb = 0; jb < 8; jb += JG) {
+                uint4 raw[JG], rr[JG];
+                int64_t mrow[JG];
+                bool inside[JG];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
-                uint4 raw = make_uint4(0, 0, 0, 0);
-                if (act) {
-                    raw = *reinterpret_cast<const uint4*>(blk + pl * EROW + ((ch ^ (pl & ESW)) << 4));
-                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw);
-                    if (resid && inside) {
-                        const uint4 rr = *reinterpret_cast<const uint4*>(resid + m * p.ldr + ch * 8);
-                        const bf16_t* b = reinterpret_cast<const bf16_t*>(&rr);
+                for (int jj = 0; jj < JG; ++jj) {
+                    const int pl = ((jb + jj) * 64 + lane) >> 4;
+                    const int row = TW == 32 ? row0 : row0 + pl / TW;
+                    const int col = TW == 32 ? pl : pl % TW;
+                    const int ho = h0 + row, wo = w0 + col;
+                    inside[jj] = ho < p.Ho && wo < p.Wo;
+                    mrow[jj] = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
+                    raw[jj] = make_uint4(0, 0, 0, 0);
+                    rr[jj] = make_uint4(0, 0, 0, 0);
+                    if (act) raw[jj] = *reinterpret_cast<const uint4*>(blk + pl * EROW + ((ch ^ (pl & ESW)) << 4));
+                    if (act && resid && inside[jj]) rr[jj] = *reinterpret_cast<const uint4*>(resid + mrow[jj] * p.ldr + ch * 8);
+                }
+                float ss[JG];
+#pragma unroll
+                for (int jj = 0; jj < JG; ++jj) {
+                    if (resid && act && inside[jj]) {           // conv output is T, then x + h rounded to T (:224)
+                        const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw[jj]);
+                        const bf16_t* b = reinterpret_cast<const bf16_t*>(&rr[jj]);
                         bf16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)b[e]);
-                        raw = *reinterpret_cast<const uint4*>(&o);
+                        raw[jj] = *reinterpret_cast<const uint4*>(&o);
                     }
+                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw[jj]);
+                    float s_ = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+                    for (int e = 0; e < 8; ++e) s_ += (float)a[e] * (float)a[e];
+                    ss[jj] = s_;
                 }
-                float ss = 0.f;
+#define HL_ROR_ADD(N)                                                                                                   \
+                _Pragma("unroll") for (int jj = 0; jj < JG; ++jj)                                                      \
+                    ss[jj] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss[jj]), 0x120 + N, 0xf, 0xf, false))
+                HL_ROR_ADD(8); HL_ROR_ADD(4); HL_ROR_ADD(2); HL_ROR_ADD(1);
+#undef HL_ROR_ADD
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+                for (int jj = 0; jj < JG; ++jj) {
+                    if constexpr (!GAMMA_ONCE) {
+                        if (act) { pg0 = load4(p.post_gamma + ch * 8); pg1 = load4(p.post_gamma + ch * 8 + 4); }
+                    }
+                    const float sc = root_c / fmaxf(sqrtf(ss[jj]), 1e-12f);
+                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw[jj]);
+                    bf16x8 y;
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                const float sc = sqrtf((float)p.Cout) / fmaxf(sqrtf(ss), 1e-12f);
-                if (!act || !inside) continue;
-                if (p.out) *reinterpret_cast<uint4*>((T*)p.out + m * p.ldo + ch * 8) = raw;
-                bf16x8 y;
+                    for (int e = 0; e < 8; e += 4) {
+                        const f32x4 g = e == 0 ? pg0 : pg1;
 #pragma unroll
-                for (int e = 0; e < 8; e += 4) {
-                    const f32x4 g = e == 0 ? pg0 : pg1;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float u = v[e + k] * sc * g[k];
-                        if (p.post_silu) u = silu_f(round_through<T>(u));
-                        y[e + k] = (bf16_t)u;
+                        for (int k = 0; k < 4; ++k) {
+                            float u = (float)a[e + k] * sc * g[k];
+                            if (p.post_silu) u = silu_f(round_through<T>(u));
+                            y[e + k] = (bf16_t)u;
+                        }
+                    }
+                    if (act && inside[jj]) {
+                        if (p.out) *reinterpret_cast<uint4*>((T*)p.out + mrow[jj] * p.ldo + ch * 8) = raw[jj];
+                        *reinterpret_cast<bf16x8*>((T*)p.post_out + (int64_t)(ch >> 1) * p.post_plane + mrow[jj] * 16 + (ch & 1) * 8) = y;
                     }
                 }
-                *reinterpret_cast<bf16x8*>((T*)p.post_out + (int64_t)(ch >> 1) * p.post_plane + m * 16 + (ch & 1) * 8) = y;
             }
             continue;
         }

@@ -16,10 +16,27 @@ Tin = t + kt - 1
 x = torch.randn(Tin, H, W, ci, generator=g, device="cuda").bfloat16()
 w = (torch.randn(co, kt * 9 * ci, generator=g, device="cuda") * (kt * 9 * ci) ** -0.5).bfloat16()
 b = torch.zeros(co, device="cuda", dtype=torch.bfloat16)
-kw = dict(Tin=Tin, Hin=H, Win=W, Cin=ci, k=(kt, 3, 3), pad=(0, 1, 1), out_thw=(t, H, W))
-out = ops.conv_cl(x, w, b, **kw)
+mode = sys.argv[2] if len(sys.argv) > 2 else "plain"       # plain (channels-last input) | planar | norm | normresid (production forms)
+if mode == "plain":
+    kw = dict(Tin=Tin, Hin=H, Win=W, Cin=ci, k=(kt, 3, 3), pad=(0, 1, 1), out_thw=(t, H, W))
+    out = ops.conv_cl(x, w, b, **kw)
+    run = lambda: ops.conv_cl(x, w, b, out=out, **kw)
+else:
+    xp = ops.Planar16(x.view(Tin, H * W, ci // 16, 16).permute(2, 0, 1, 3).contiguous())
+    M = t * H * W
+    out = torch.empty(M, co, device="cuda", dtype=torch.bfloat16)
+    res = torch.randn(M, co, generator=g, device="cuda").bfloat16() if mode == "normresid" else None
+    norm = None
+    if mode in ("norm", "normresid"):
+        dst = ops.Planar16(torch.empty(co // 16, t, H * W, 16, device="cuda", dtype=torch.bfloat16))
+        norm = (torch.ones(co, device="cuda"), dst, True)
+        if co not in (32, 64, 96, 128):
+            raise SystemExit("fused norm: Cout must be 32 / 64 / 96 / 128")
+    run = lambda: ops.conv_cl_planar(xp, w, b, Tin=Tin, Hin=H, Win=W, kt=kt, resid=res, out=out, norm=norm, keep_raw=True)
+    run()
+name = f"{name} [{mode}]"
 for _ in range(40):
-    ops.conv_cl(x, w, b, out=out, **kw)
+    run()
 torch.cuda.synchronize()
 r = dbg.cpu().numpy().reshape(-1, 8)
 r = r[r[:, 7] == 1]
