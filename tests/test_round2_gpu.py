@@ -73,14 +73,18 @@ def test_block_14b_width_long_sequence_vs_reference(dtype):
         return oa(q, segs, **kk)
     import more4d_amd.models.wan_transformer4d as wt
     ops.gemm_bt, ops.attention = gemm, attn
+    ops.launch_counts(reset=True)
     try:
         with torch.no_grad():
             out = blk(x, e0, torch.tensor([L]), z["grid"].view(1, 3), freqs, ctx.to(dtype) if dtype == BF else ctx, None,
                       dtype=torch.float32, t=0)
     finally:
         ops.gemm_bt, ops.attention = og, oa
+    counts = ops.launch_counts()
     assert wt.ops is ops
     assert calls["gemm_big"] >= 8 and calls["attn_big"] >= 1, calls       # q,k,v,o, cross q,o, ffn up/down; self-attention
+    if dtype == BF:       # ... and the C side agrees: the 4-wave wide GEMM (default structure) and the phased attention kernel ran
+        assert counts["gemm_wide"] + counts["gemm_phased"] >= 8 and counts["attn_phased"] >= 1, counts
     out = out.float().cpu()[0]
     rows = z["rows"].long()
     if dtype == torch.float32:
