@@ -423,9 +423,8 @@ def main():
             rccl_ranks = int(ones.item())
             if args.mode == "denoise":
                 stage = "new_group (sequence / CFG-parallel sub-groups)"
-                probe = dist.new_group(list(range(world)))
+                probe = dist.new_group(list(range(world)))      # (left alive: an idle communicator costs nothing)
                 dist.barrier(group=probe)
-                dist.destroy_process_group(probe)
         except Exception as ex:
             print(json.dumps({"metric": "4D-STraG denoise-steps/sec, 49x480x832 bf16", "value": None, "n_gpus": world, "valid": False,
                               "error": {"stage": stage, "rank": rank, "local_rank": local_rank, "exception": repr(ex)[:600],
