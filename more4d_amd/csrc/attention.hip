@@ -545,7 +545,8 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         for (int i = 0; i < p.kv.nseg; ++i) keys += p.kv.len[i] > 0 ? p.kv.len[i] : 0;
         // 256-query workgroups (8 waves share each K/V tile) for long self-attention; short key loops (cross-attention)
         // keep the 4-wave workgroups (measured: 1000 vs 924 TF at Lk = 21840, 657 vs 678 TF at Lk = 512)
-        const bool w8 = p.Lq > 1024 && keys >= 2048 && !force_w4;
+        M4D_ENV_ONCE(min_keys8, "M4D_ATTN_W8_MIN_KEYS", 2048);     // (A/B: the 8-wave kernels on shorter key loops)
+        const bool w8 = p.Lq > 1024 && keys >= min_keys8 && !force_w4;
         AttnArgs q = p;
         bool same_strides = true;     // the phased kernel shares one per-lane DMA offset across segments
         for (int i = 1; i < p.kv.nseg; ++i)

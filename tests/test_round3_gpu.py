@@ -119,3 +119,31 @@ def test_vae_configs2_full_49_frames():
         del dec_part
         assert torch.equal(vae.encode(x)[0].mode(), full)
         assert torch.equal(vae.decode(full).sample, dec)
+
+
+def test_inner_model_entry_points_on_device():
+    """vae.model.encode / encode_full / decode / decode_full / clear_cache under the reference's names (wan_vae.py:520, 549, 633, 678,
+    717), called the way the reference's wrapper calls them (:770-776, :825-832), against the reference's own outputs (fp32, 1e-3):
+    decode is NOT clamped there; under autograd the *_full twins give the same values as the plain forward."""
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    z = load_npz("vae_roundtrip.npz")
+    vae = AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(load_keys("vae_keys.json"), 2024))
+    vae = vae.to(DEV)
+    m = vae.model
+    x, lat = z["x"].to(DEV), z["enc"][:, :16].to(DEV)
+    with torch.no_grad():
+        enc = m.encode(x, vae.scale)
+        assert rel_err(enc.cpu(), z["enc"]) < 1e-3 and torch.equal(m.encode_full(x, vae.scale), enc)
+        raw = m.decode(lat, vae.scale)
+        assert float(raw.abs().max()) > 1.0 and rel_err(raw.clamp(-1, 1).cpu(), z["dec"]) < 1e-3
+        assert torch.equal(m.decode_full(lat, vae.scale), raw)
+    m.clear_cache()
+    assert m._conv_idx == [0] and len(m._feat_map) == m._conv_num > 0
+    # with gradients: same forward values, a gradient for the decoder parameters and for the latent
+    lat_g = lat.clone().requires_grad_(True)
+    out = m.decode_full(lat_g, vae.scale)
+    assert rel_err(out.detach().cpu(), raw.cpu()) < 1e-5
+    out.square().mean().backward()
+    assert lat_g.grad is not None and bool(torch.isfinite(lat_g.grad).all()) and float(lat_g.grad.abs().max()) > 0
+    assert m.decoder.head[2].weight.grad is not None
