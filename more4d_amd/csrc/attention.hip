@@ -30,7 +30,8 @@ struct AttnArgs {
     int B, heads, nq_tiles, accumulate;
     float sc;  // softmax scale * log2(e)
     float* lse;  // optional [B, heads, Lq]: log2-domain log-sum-exp of the scaled scores (training)
-    int abl;     // timing ablations of attn128p_kernel (tools only, results wrong): 1 no softmax math, 2 no M-phase stream
+    int abl;     // timing ablations of attn128p_kernel (tools only, results wrong): 1 no softmax math, 2 no M-phase stream; 64 = stamps
+    unsigned long long* dbg;   // tool builds (abl & 64): per-workgroup shader-clock / wall-clock stamps, 4 words each (tools/attn_clock.py)
 };
 
 template <typename T, int D>
@@ -651,9 +652,12 @@ static int attention_impl(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_l
     p.B = B; p.heads = heads; p.nq_tiles = (int)((Lq + 127) / 128); p.accumulate = accumulate;
     p.sc = scale * 1.4426950408889634f;
     p.lse = lse;
-    p.abl = 0;
+    p.abl = 0; p.dbg = nullptr;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(abl, "M4D_ATTN_ABL", 0); p.abl = abl; }
+    { static unsigned long long* dbgp = nullptr; static bool rd = false;
+      if (!rd) { rd = true; const char* v = getenv("M4D_ATTN_DBG_PTR"); if (v) dbgp = (unsigned long long*)strtoull(v, nullptr, 0); }
+      p.dbg = dbgp; }
 #endif
     int rc = dt == M4D_BF16 ? launch<bf16_t>(p, head_dim, (hipStream_t)stream) : launch<float>(p, head_dim, (hipStream_t)stream);
     if (rc) { m4d_set_error("attention: unsupported configuration"); return rc; }

@@ -58,6 +58,8 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
     constexpr int D = 128, KVB = 64, STAGE = 32768, VOFF = 16384, QB = 256, NST = 4;
     extern __shared__ __attribute__((aligned(16))) char psmem[];   // NST * STAGE
 
+    unsigned long long ts0 = 0, rt0 = 0;
+    if (M4D_ABL(p) & 64) { ts0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     const int HB = p.heads * p.B;
     int qt, hb;
     if ((HB & 7) == 0) {
@@ -402,5 +404,9 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
                 }
                 store4(dst, v);
             }
+    }
+    if ((M4D_ABL(p) & 64) && p.dbg && t == 0) {     // tool build: shader cycles and 100 MHz wall clock of this workgroup's lifetime
+        unsigned long long* d = p.dbg + (size_t)blockIdx.x * 4;
+        d[0] = ts0; d[1] = __builtin_readcyclecounter(); d[2] = rt0; d[3] = __builtin_amdgcn_s_memrealtime();
     }
 }

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Shader clock the phased self-attention kernel runs at (tool build): M4D_LIB=abl M4D_ATTN_ABL=64 python tools/attn_clock.py
+Every workgroup stamps s_memtime and the 100 MHz wall clock at entry and exit; clock = cycles / time, as tools/gemm_timeline.py."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+dbg = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
+os.environ["M4D_ATTN_DBG_PTR"] = str(dbg.data_ptr())
+from more4d_amd import ops  # noqa: E402
+B, L, n, D = 2, 21840, 40, 128
+C = n * D
+q = torch.randn(B, L, C, device="cuda", dtype=torch.bfloat16)
+k = torch.randn(B, L, C, device="cuda", dtype=torch.bfloat16)
+vt = torch.randn(C, B * L, device="cuda", dtype=torch.bfloat16)
+out = torch.empty_like(q)
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for i in range(8):
+    if i == 3:
+        s.record()
+    ops.attention(q, [ops.KV(k, vt, L * C, C, L, B * L, L)], B=B, Lq=L, heads=n, head_dim=D, out=out)
+e.record()
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / 5
+r = dbg.cpu().numpy().reshape(-1, 4)
+r = r[r[:, 1] > 0]
+cyc, us = r[:, 1] - r[:, 0], (r[:, 3] - r[:, 2]) / 100.0
+clk = cyc / np.maximum(us, 1e-9) / 1e3
+tf = 4.0 * B * L * L * n * D / ms / 1e9
+print(f"attn128p self-attention (abl {os.environ.get('M4D_ATTN_ABL')}): {ms:.2f} ms = {tf:.0f} TF; workgroups {len(r)}, lifetime {us.mean():.1f} us, shader clock "
+      f"{np.median(clk):.3f} GHz (p10 {np.percentile(clk, 10):.3f}, p90 {np.percentile(clk, 90):.3f}); MFMA floor per workgroup "
+      f"{(L / 64) * 32 * 32 * 2:.0f} cycles of {cyc.mean():.0f} = {(L / 64) * 32 * 32 * 2 / cyc.mean():.3f} busy")
