@@ -30,6 +30,7 @@ cp(f"{src}/conv_timeline.log", "conv_timeline.log")
 cp(f"{src}/ab_gemm.log", "ab_gemm.log")
 cp(f"{src}/atomic_probe.log", "atomic_probe.log")
 cp(f"{src}/race_screen.log", "race_screen.log")
+cp(f"{src}/attn_clock.log", "attn_clock.log")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "train_4layers_kernel_stats.csv")
 subprocess.run([sys.executable, "tools/summarize_prof.py", tag], check=False)

@@ -19,6 +19,7 @@ M4D_LIB=abl M4D_GEMM_ABL=64 timeout 200 python tools/gemm_timeline.py 43680 5120
 for a in 65 66 71; do M4D_LIB=abl M4D_GEMM_ABL=$a timeout 200 python tools/gemm_timeline.py 43680 5120 5120 >> $O/gemm_timeline.log 2>&1; done
 for m in plain planar norm normresid; do M4D_LIB=abl M4D_CONV_ABL=64 timeout 120 python tools/conv_timeline.py 0 $m >> $O/conv_timeline.log 2>&1; done
 M4D_LIB=abl M4D_CONV_ABL=64 timeout 120 python tools/conv_timeline.py 5 planar >> $O/conv_timeline.log 2>&1
+for a in 64 65 66; do M4D_LIB=abl M4D_ATTN_ABL=$a timeout 200 python tools/attn_clock.py 2>&1 | grep -v amdgpu >> $O/attn_clock.log; done
 timeout 500 python tools/ab_gemm.py 4 5 --reps 2 --n 40 2>&1 | grep "^variant" > $O/ab_gemm.log
 timeout 300 tools/probes/atomic_dq.bin 171 > $O/atomic_probe.log 2>&1
 timeout 300 python tools/race_screen.py 20 > $O/race_screen.log 2>&1; tail -1 $O/race_screen.log
