@@ -100,8 +100,11 @@ def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=N
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
+    for i in range(steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -110,7 +113,7 @@ def run_train(model, cfg, dev, steps=2, warmup=1, fp32_state=False, act_budget=N
     # fwd + recompute + bwd: GEMMs 1 + 1 + 2, attention 1 + 1 + 2.5 (five matmuls per pair instead of two)
     model_flops = 4 * gf + 4.5 * af
     out = {"metric": "train-step seconds, 14B DiT fwd+recompute+bwd+AdamW, batch 1/GPU, 49x480x832 bf16",
-           "value": dt, "unit": "s/step", "n_gpus": world, "layers": cfg["num_layers"], "loss": float(loss.detach()),
+           "value": dt, "unit": "s/step", "each_step_s": [marks[i].elapsed_time(marks[i + 1]) / 1e3 for i in range(steps)], "n_gpus": world, "layers": cfg["num_layers"], "loss": float(loss.detach()),
            "model_tflop": model_flops / 1e12, "mfma_frac": model_flops / dt / 1e12 / MFMA_BF16_PEAK_TF,
            "max_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "stored_blocks": [model.last_stored_blocks, model.last_full_blocks],
            "state_dtype": "float32" if fp32_state else "bfloat16",
