@@ -24,6 +24,8 @@ extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_store(
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_gelu(const void* args, unsigned nwg, hipStream_t st);
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_resid(const void* args, unsigned nwg, hipStream_t st);
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_f32(const void* args, unsigned nwg, hipStream_t st);
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_store_persistent(const void* args, unsigned nwg, unsigned ncu, hipStream_t st);
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_gelu_persistent(const void* args, unsigned nwg, unsigned ncu, hipStream_t st);
 
 namespace {
 
@@ -627,7 +629,22 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
         }
         else if (variant == 5) {
             kclass = M4D_KC_GEMM_WIDE;
-            const int rc = epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store(&p, (unsigned)nwg, st)
+            // persistent form (M4D_GEMM_PERSIST, default on): bf16 epilogues, bias along n, K/64 even and >= 4, operands below 4 GiB,
+            // more tiles than CUs
+            M4D_ENV_ONCE(persist, "M4D_GEMM_PERSIST", 1);
+            const int64_t nkt = K / 64;
+#ifdef M4D_ABLATIONS
+            M4D_ENV_ONCE(pgrid, "M4D_GEMM_PERSIST_GRID", 0);     // tool builds: workgroups of the persistent launch (any count >= 1)
+            const int ncu_p = pgrid > 0 ? (int)std::min<int64_t>(pgrid, nwg > 1 ? nwg - 1 : 1) : ncu;
+#else
+            const int ncu_p = ncu;
+#endif
+            // (tool builds: the timing ablations / timeline stamps exist for the one-tile form only; 128.. = persistent epilogue debug bits)
+            const bool pers_ok = persist && (p.abl & 127) == 0 && (epilogue == M4D_EPI_STORE || epilogue == M4D_EPI_GELU_TANH) && !(bias && bias_on_m) &&
+                                 nkt >= 4 && (nkt & 1) == 0 && M * lda * 2 < (1ll << 32) && N * ldw * 2 < (1ll << 32) && nwg > ncu_p;
+            const int rc = pers_ok ? (epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store_persistent(&p, (unsigned)nwg, (unsigned)ncu_p, st)
+                                                                : m4d_launch_gemm_wide_gelu_persistent(&p, (unsigned)nwg, (unsigned)ncu_p, st))
+                         : epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store(&p, (unsigned)nwg, st)
                          : epilogue == M4D_EPI_GELU_TANH ? m4d_launch_gemm_wide_gelu(&p, (unsigned)nwg, st)
                          : epilogue == M4D_EPI_RESID_GATE ? m4d_launch_gemm_wide_resid(&p, (unsigned)nwg, st)
                          : m4d_launch_gemm_wide_f32(&p, (unsigned)nwg, st);

@@ -23,6 +23,7 @@
 #include "gemm_common.h"
 
 namespace {
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (native vector type: inline-asm register operands)
 constexpr int BM2 = 256, BN2 = 256;
 extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
 
@@ -104,18 +105,82 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
     }
 }
 
+// Persistent kernel: one 32(m) x 64(n) block (8 KiB of wave-private LDS next to the two live K-tile buffers), bf16 outputs, the bias
+// of the block's columns already in registers.  Same arithmetic and order as epilogue_block64.  Stores go out as
+// `global_store_dwordx4 voff, data, sbase` with ONE per-lane 32-bit offset for the whole kernel (row (lane >> 3), 8 columns (lane & 7))
+// and a scalar base per (block, iteration): written as plain pointer arithmetic hipcc hoists the 32 per-lane 64-bit addresses of a
+// tile's stores out of the tile loop and spills inside the K loop.
+template <typename T, int EPI>
+M4D_DEV void epilogue_block32(const GemmArgs& p, char* wl, const f32x16& a0, const f32x16& a1, int64_t m_base, int64_t n_base,
+                              int lane, unsigned voff, bool has_bias, const u32x4& bias8) {
+    static_assert(EPI == M4D_EPI_STORE || EPI == M4D_EPI_GELU_TANH, "bf16 outputs only");
+    f32x4 b0, b1;
+    {
+        const bf16_t* bb = reinterpret_cast<const bf16_t*>(&bias8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b0[e] = (float)bb[e]; b1[e] = (float)bb[4 + e]; }
+    }
+    const int li = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const f32x16& acc = ni == 0 ? a0 : a1;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int ch = (ni * 32 + rq * 8 + hi * 4) >> 2;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[rq * 4 + e];
+            *reinterpret_cast<f32x4*>(wl + li * 256 + ((ch ^ (li & 15)) << 4)) = v;
+        }
+    }
+    const int c8 = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
+        if (has_bias) { v0 += b0; v1 += b1; }
+        if constexpr (EPI == M4D_EPI_GELU_TANH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = gelu_tanh_f(v0[e]); v1[e] = gelu_tanh_f(v1[e]); }
+        }
+        bf16x8 ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ob[e] = (bf16_t)v0[e]; ob[4 + e] = (bf16_t)v1[e]; }
+        const u32x4 ov = __builtin_bit_cast(u32x4, ob);
+        const char* sb = uniform_ptr((const char*)p.out + ((m_base + it * 8) * p.ldc + n_base) * 2);
+        // NO edge mask: a tile shifted inwards rewrites rows / columns of its neighbour with the neighbour's own values (same K order,
+        // same instruction sequence per element: bit-identical), so every tile issues exactly 4 stores per block — the phases
+        // after the epilogue count them
+        // (s_nop 1: a store of more than 8 bytes reads its data registers up to two wait states after issue and the hardware does not
+        // interlock; hipcc's hazard recognizer, which pads its own stores, does not look inside an asm statement — without the
+        // nops it re-used a data register for an LDS address in the very next instruction and the address went out as data)
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(ov), "s"(sb) : "memory");
+    }
+}
+
 // ABL: compile-time timing ablations (tool builds only; results wrong when != 0): 1 no DMA, 2 no fragment reads, 4 no barriers, 8 no MFMA,
 // 64 = correct kernel + per-workgroup timestamps written over the first output row of every tile (tools/gemm_timeline.py)
-template <int ABL, int EPI>
+// PERSIST: the workgroup walks tiles blockIdx.x, + gridDim.x, ... of the XCD-aware order and the DMA stream runs on from one tile into the
+// next: a staging group whose K-tile counter reaches K/64 wraps to K-tile 0 of the workgroup's NEXT tile (the tile origin lives in the
+// per-group VGPR offset, the scalar row bases are tile independent), so the next tile's first two K-tiles are in LDS and its first
+// fragments in registers when the epilogue of the current one ends — no prologue, no launch gap.  The epilogue runs beside the live
+// ring in 32 KiB of extra LDS (8 KiB per wave) and only ISSUES its stores (every tile issues all 32: edge tiles rewrite their
+// neighbour's identical values instead of masking).
+// Requirements (host-checked): K/64 even and >= 4, both operands below 4 GiB, bias along n, bf16 output.
+template <int ABL, int EPI, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
     typedef bf16_t T;
+    static_assert(!PERSIST || ((EPI == M4D_EPI_STORE || EPI == M4D_EPI_GELU_TANH) && ABL == 0), "persistent form: bf16 epilogues, no ablations");
     unsigned long long ts[6];
     if constexpr (ABL & 64) { ts[0] = __builtin_readcyclecounter(); ts[5] = __builtin_amdgcn_s_memrealtime(); }
     int tm, tn;
-    tile_coords(p, tm, tn);
-    const int64_t m_lo = (int64_t)tm * BM2, n_lo = (int64_t)tn * BN2;
-    const int64_t m0 = min(m_lo, p.M - BM2), n0 = min(n_lo, p.N - BN2);     // edge tiles shifted inwards (see gemm_phased.h)
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int bid = blockIdx.x;
+    tile_coords(p, tm, tn, bid);
+    int64_t m_lo = (int64_t)tm * BM2, n_lo = (int64_t)tn * BN2;
+    int64_t m0 = min(m_lo, p.M - BM2), n0 = min(n_lo, p.N - BN2);     // edge tiles shifted inwards (see gemm_phased.h)
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // scalar: everything derived from (tile, wave) stays in SGPRs
     const int li = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned lds_base = (unsigned)(uintptr_t)(LDS_AS char*)dyn_smem;
@@ -140,17 +205,38 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
 #pragma unroll
     for (int jx = 0; jx < 8; ++jx) {
         const int row = (jx >> 2) * 128 + ((jx >> 1) & 1) * 64 + (jx & 1) * 32;     // jx = unit*4 + half*2 + (i & 1)
-        ra[jx] = uniform_ptr((const char*)p.A + (m0 + row) * p.lda * 2);
-        rw[jx] = uniform_ptr((const char*)p.W + (n0 + row) * p.ldw * 2);
+        ra[jx] = uniform_ptr((const char*)p.A + ((PERSIST ? 0 : m0) + row) * p.lda * 2);
+        rw[jx] = uniform_ptr((const char*)p.W + ((PERSIST ? 0 : n0) + row) * p.ldw * 2);
     }
     const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+    if constexpr (PERSIST) { oa += (unsigned)(m0 * p.lda * 2); ow += (unsigned)(n0 * p.ldw * 2); }      // (operands below 4 GiB)
     unsigned va0 = oa, va1 = oa, vb0 = ow, vb1 = ow;        // + K offset of the NEXT staging of the group
     int ka0 = 0, ka1 = 0, kb0 = 0, kb1 = 0;                  // K-tile index of that staging (scalar; clamps the advance at nk - 1)
+    // PERSIST: what a group's offset moves by when it wraps from the last K-tile of this tile to K-tile 0 of the next one
+    unsigned d_a = 0, d_w = 0;
+    const int nwg_all = p.tiles_m * p.tiles_n;
+    auto next_deltas = [&]() {
+        const int nb_ = bid + (int)gridDim.x;
+        int64_t m0n = m0, n0n = n0;
+        if (nb_ < nwg_all) {
+            int tm2, tn2;
+            tile_coords(p, tm2, tn2, nb_);
+            m0n = min((int64_t)tm2 * BM2, p.M - BM2); n0n = min((int64_t)tn2 * BN2, p.N - BN2);
+        }
+        d_a = (unsigned)((m0n - m0) * p.lda * 2 - (int64_t)(nk - 1) * 128);
+        d_w = (unsigned)((n0n - n0) * p.ldw * 2 - (int64_t)(nk - 1) * 128);
+    };
+    if constexpr (PERSIST) next_deltas();
 #define W_GLDS(VOFF, SRC, DSTOFF)                                                                            \
     if constexpr (!(ABL & 1)) asm volatile("s_add_u32 m0, %0, %3\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsw), "v"(VOFF), "s"(SRC), "i"(DSTOFF) : "memory", "m0", "scc")
     // instruction I (0..3) of the group (operand rows R, half H, group offset G) for the K-tile buffer BUFB (0 / W_BUF)
 #define W_STG_I(R, VOFF, H, G, BUFB, I) W_GLDS(VOFF, R[((I) >> 1) * 4 + (H) * 2 + ((I) & 1)], (BUFB) + (G) + (I) * 4096)
-#define W_ADV(VOFF, KC) do { KC += 1; VOFF += (KC < nk) ? 128u : 0u; } while (0)
+#define W_ADV(VOFF, KC, DLT)                                                                                 \
+    do {                                                                                                     \
+        KC += 1;                                                                                             \
+        if constexpr (PERSIST) { const bool wrap_ = KC == nk; VOFF += wrap_ ? DLT : 128u; KC = wrap_ ? 0 : KC; }  \
+        else VOFF += (KC < nk) ? 128u : 0u;                                                                  \
+    } while (0)
     f32x16 acc[4][4];   // [ni][mi]: rows n, column m = lane (W is the MFMA's A operand, see gemm.hip)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -160,20 +246,21 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // per-lane fragment addresses (block 0 of the wave's unit; block 1 = +4096) in K-tile buffer 0 and 1
-    unsigned am0[4], an0[4], am1[4], an1[4];
+    // (ONE address set: Q1 / Q2 read the current K-tile buffer, Q3 / Q4 the next one, so the set moves by +-W_BUF after Q2 and stays
+    // there for the next K-tile's Q1 / Q2: eight v_add per K-tile in MFMA shadows instead of eight more live registers)
+    unsigned am0[4], an0[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const unsigned x = li * ROWB + (((kk * 2 + hi) ^ ((li >> 1) & 7)) << 4);
         am0[kk] = lds_base + wm * 8192 + x;
         an0[kk] = lds_base + wn * 8192 + x;
-        am1[kk] = am0[kk] + W_BUF;
-        an1[kk] = an0[kk] + W_BUF;
     }
     bf16x8 fa0[2][4], fa1[2][4], fbx[2][4], fby[2][4];
 #define W_DSR(dst, addr, OFF) if constexpr (!(ABL & 2)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
 #define W_PIN() __builtin_amdgcn_sched_barrier(0)
 #define W_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define W_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define W_VM_(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define W_VM(N) W_VM_(N)
     // read one unit (2 blocks x 4 k-steps) from group offset G of the buffer addressed by AD
 #define W_READ(F, AD, G)                                                                                   \
     do {                                                                                                   \
@@ -182,15 +269,21 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
         W_DSR(F[0][2], AD[2], G); W_DSR(F[1][2], AD[2], G + 4096);                                          \
         W_DSR(F[0][3], AD[3], G); W_DSR(F[1][3], AD[3], G + 4096);                                          \
     } while (0)
-#define W_MMA(FN, FM, NB, MB, KK, NI, MI) if constexpr (!(ABL & 8)) mma32(FN[NI][KK], FM[MI][KK], acc[(NB) + (NI)][(MB) + (MI)])
+    // (PERSIST: the MFMA builtin is a pure operation to hipcc, which in the larger function sinks whole phases of them past the asm
+    // statements that make up the schedule; an empty asm that "modifies" the accumulator block right after the MFMA ties it to its slot)
+#define W_MMA(FN, FM, NB, MB, KK, NI, MI)                                                                  \
+    do {                                                                                                   \
+        if constexpr (!(ABL & 8)) mma32(FN[NI][KK], FM[MI][KK], acc[(NB) + (NI)][(MB) + (MI)]);             \
+        if constexpr (PERSIST) asm volatile("" : "+a"(acc[(NB) + (NI)][(MB) + (MI)]));                      \
+    } while (0)
     // One phase: 16 MFMAs (FN x FM into the accumulator quadrant NB, MB); ONE other instruction in the issue shadow of each MFMA
     // (an MFMA holds the pipe for 8 passes = 32 cycles): after the first MFMA the wait for the group read in this phase and the
     // barrier, then the 8 fragment reads of the phase, then the 4 DMA instructions of the group that was read in the last phase.
-#define W_PHASE(FN, FM, NB, MB, RF, RAD, RG, SR, SV, SK, SH, SG, SB)                                        \
+#define W_PHASE(VMN, FN, FM, NB, MB, RF, RAD, RG, SR, SV, SK, SH, SG, SB, SD)                                   \
     do {                                                                                                   \
         W_LGKM0(); W_PIN();                                                                                \
         W_MMA(FN, FM, NB, MB, 0, 0, 0); W_PIN();                                                           \
-        W_VM(24);                                                                                          \
+        W_VM(VMN);                                                                                         \
         if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                               \
         W_PIN();                                                                                           \
         W_MMA(FN, FM, NB, MB, 0, 0, 1); W_PIN(); W_DSR(RF[0][0], RAD[0], RG); W_PIN();                       \
@@ -205,45 +298,130 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
         W_MMA(FN, FM, NB, MB, 2, 1, 0); W_PIN(); W_STG_I(SR, SV, SH, SG, SB, 1); W_PIN();                    \
         W_MMA(FN, FM, NB, MB, 2, 1, 1); W_PIN(); W_STG_I(SR, SV, SH, SG, SB, 2); W_PIN();                    \
         W_MMA(FN, FM, NB, MB, 3, 0, 0); W_PIN(); W_STG_I(SR, SV, SH, SG, SB, 3); W_PIN();                    \
-        W_MMA(FN, FM, NB, MB, 3, 0, 1); W_PIN(); W_ADV(SV, SK); W_PIN();                                     \
+        W_MMA(FN, FM, NB, MB, 3, 0, 1); W_PIN(); W_ADV(SV, SK, SD); W_PIN();                                     \
         W_MMA(FN, FM, NB, MB, 3, 1, 0); W_MMA(FN, FM, NB, MB, 3, 1, 1); W_PIN();                            \
     } while (0)
     // K-tile KT in buffer (AMC, ANC) = byte offset BC, next K-tile's buffer (AMN, ANN) = BN; FX holds B0(KT) on entry, FY receives
     // B1(KT) and then B0(KT + 1).  Staging issued in phase h = the group read in phase h + 7, into the slot of the group read in
     // phase h - 1: Q1 of tile k is phase 4k -> B0(k + 2) (read in phase 4(k + 2) - 1); Q2 -> B1(k + 2); Q3 -> A1(k + 2);
     // Q4 -> A0(k + 3) (read in phase 4(k + 3) - 2, next buffer).
-#define W_KTILE(FX, FY, AMC, ANC, AMN, ANN, BC, BN)                                                        \
+#define W_KTILE(V1, V2, FX, FY, BC, BN)                                                                    \
     do {                                                                                                   \
-        W_PHASE(FX, fa0, 0, 0, FY, ANC, W_B1, rw, vb0, kb0, 0, W_B0, BC);                                   \
-        W_PHASE(FY, fa0, 2, 0, fa1, AMC, W_A1, rw, vb1, kb1, 1, W_B1, BC);                                  \
-        W_PHASE(FY, fa1, 2, 2, fa0, AMN, W_A0, ra, va1, ka1, 1, W_A1, BC);                                  \
-        W_PHASE(FX, fa1, 0, 2, FY, ANN, W_B0, ra, va0, ka0, 0, W_A0, BN);                                   \
+        W_PHASE(V1, FX, fa0, 0, 0, FY, an0, W_B1, rw, vb0, kb0, 0, W_B0, BC, d_w);                          \
+        W_PHASE(V1, FY, fa0, 2, 0, fa1, am0, W_A1, rw, vb1, kb1, 1, W_B1, BC, d_w);                         \
+        {                                                                                                  \
+            const unsigned dl_ = (BN) > (BC) ? (unsigned)W_BUF : (unsigned)-W_BUF;                         \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { am0[kk] += dl_; an0[kk] += dl_; }           \
+        }                                                                                                  \
+        W_PHASE(V1, FY, fa1, 2, 2, fa0, am0, W_A0, ra, va1, ka1, 1, W_A1, BC, d_a);                         \
+        W_PHASE(V2, FX, fa1, 0, 2, FY, an0, W_B0, ra, va0, ka0, 0, W_A0, BN, d_a);                          \
     } while (0)
-#define W_STAGE(R, VOFF, KC, H, G, BUFB)                                                                   \
+#define W_STAGE(R, VOFF, KC, H, G, BUFB, DLT)                                                                   \
     do {                                                                                                   \
         W_STG_I(R, VOFF, H, G, BUFB, 0); W_STG_I(R, VOFF, H, G, BUFB, 1);                                   \
-        W_STG_I(R, VOFF, H, G, BUFB, 2); W_STG_I(R, VOFF, H, G, BUFB, 3); W_ADV(VOFF, KC);                  \
+        W_STG_I(R, VOFF, H, G, BUFB, 2); W_STG_I(R, VOFF, H, G, BUFB, 3); W_ADV(VOFF, KC, DLT);                  \
     } while (0)
 
+    const T* bias = (const T*)p.bias;
+    // PERSIST: the bias of the wave's 128 columns travels like the operands — ONE LDS-DMA instruction (4 bytes per lane) at the start of
+    // a tile into the wave's epilogue block, which nothing touches before the epilogue — so it retires in order with the stagings under
+    // the same counted waits.  (An ordinary load would make hipcc wait vmcnt(0) at its first use, i.e. drain the DMA queue in front of
+    // every epilogue; an inline-asm load into registers is unsafe: the compiler may copy "its result" before the data has arrived.)
+    // ALWAYS issued (without a bias: the first weights, unused) so that the waits do not depend on it.
+    const unsigned lds_bias = __builtin_amdgcn_readfirstlane(lds_base + 2 * W_BUF + wave * 8192);
+    auto request_bias = [&]() {
+        const char* src = uniform_ptr(bias ? (const char*)(bias + n0 + wn * 128) : (const char*)p.W);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_bias), "v"(lane * 4), "s"(src) : "memory", "m0");
+    };
+    if constexpr (PERSIST) request_bias();          // (first tile: older than every DMA of the prologue, retired by the first counted wait)
     // ---- prologue: both K-tile buffers in flight in consumption order, then A0(2) ----
-    W_STAGE(ra, va0, ka0, 0, W_A0, 0); W_STAGE(rw, vb0, kb0, 0, W_B0, 0); W_STAGE(rw, vb1, kb1, 1, W_B1, 0); W_STAGE(ra, va1, ka1, 1, W_A1, 0);
-    W_STAGE(ra, va0, ka0, 0, W_A0, W_BUF); W_STAGE(rw, vb0, kb0, 0, W_B0, W_BUF); W_STAGE(rw, vb1, kb1, 1, W_B1, W_BUF); W_STAGE(ra, va1, ka1, 1, W_A1, W_BUF);
+    W_STAGE(ra, va0, ka0, 0, W_A0, 0, d_a); W_STAGE(rw, vb0, kb0, 0, W_B0, 0, d_w); W_STAGE(rw, vb1, kb1, 1, W_B1, 0, d_w); W_STAGE(ra, va1, ka1, 1, W_A1, 0, d_a);
+    W_STAGE(ra, va0, ka0, 0, W_A0, W_BUF, d_a); W_STAGE(rw, vb0, kb0, 0, W_B0, W_BUF, d_w); W_STAGE(rw, vb1, kb1, 1, W_B1, W_BUF, d_w); W_STAGE(ra, va1, ka1, 1, W_A1, W_BUF, d_a);
     W_VM(24);                                  // A0(0), B0(0) of this wave have landed
     __builtin_amdgcn_s_barrier();
     W_READ(fa0, am0, W_A0);
     W_READ(fbx, an0, W_B0);
     W_LGKM0();
     __builtin_amdgcn_s_barrier();              // everybody has read A0(0): its slot may be re-staged
-    W_STAGE(ra, va0, ka0, 0, W_A0, 0);         // A0(2)
+    W_STAGE(ra, va0, ka0, 0, W_A0, 0, d_a);    // A0(2)
     // entering phase 0 the wait is vmcnt(24): B1(0) is followed by A1(0), A0(1), B0(1), B1(1), A1(1), A0(2) = 24 instructions
     if constexpr (ABL & 64) ts[1] = __builtin_readcyclecounter();
+    if constexpr (PERSIST) {
+        char* wl8 = dyn_smem + 2 * W_BUF + wave * 8192;
+        // first tile: nothing but DMAs in flight.  Later tiles: the 32 stores of the last epilogue and the bias request of this tile sit
+        // between the DMAs.  vmcnt is ONE counter for loads and stores, and only loads are retired in order among themselves (stores may
+        // be acknowledged before older loads: a wait that counted them — vmcnt(58) — raced), so a wait may only count the YOUNGER LOADS:
+        // 24 DMA instructions + the bias request for the seven phases whose group was staged before the epilogue.  Stores still
+        // pending make that wait stricter than needed: phase j needs all but the last 24 - 4j stores acknowledged, which they are
+        // unless the fabric is more than a microsecond behind.
+#define W_KLOOP(KT0)                                                                                       \
+        for (int kt = KT0; kt < nk; kt += 2) {                                                             \
+            W_KTILE(24, 24, fbx, fby, 0, W_BUF);                                                           \
+            W_KTILE(24, 24, fby, fbx, W_BUF, 0);                                                           \
+        }
+        W_KLOOP(0)
+        for (;;) {
+            // epilogue of this tile; the ring already holds K-tiles 0 and 1 of the next one, fa0 / fbx its first fragments.
+            // The lane id is laundered through an empty asm so that hipcc recomputes the epilogue's per-lane addresses per tile
+            // (a few dozen VALU instructions) instead of hoisting them out of the tile loop and spilling across the K loop.
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+#ifdef M4D_ABLATIONS
+            if (p.abl & 512) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (p.abl & 1024) { asm volatile("s_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127" ::: "memory"); }
+            if (p.abl & 2048) __builtin_amdgcn_s_barrier();
+            if (p.abl & 128) {      // debug: known accumulators (tile-local n, or m with bit 256) instead of the products
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[a][b][r] = (p.abl & 256) ? (float)(wm * 128 + b * 32 + (lane_e & 31))
+                                                         : (float)(wn * 128 + a * 32 + (r >> 2) * 8 + (lane_e >> 5) * 4 + (r & 3));
+            }
+#endif
+            const unsigned evoff = (unsigned)(((lane_e >> 3) * p.ldc + (lane_e & 7) * 8) * 2);     // stores: row (lane >> 3), columns (lane & 7) * 8
+            u32x4 bz[2];            // this lane's 2 x 8 bias values, out of the block before the first accumulators go in
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) bz[nh] = *reinterpret_cast<const u32x4*>(wl8 + (nh * 64 + (lane_e & 7) * 8) * 2);
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                {
+                    epilogue_block32<T, EPI>(p, wl8, acc[nh * 2][mi], acc[nh * 2 + 1][mi], m0 + wm * 128 + mi * 32, n0 + wn * 128 + nh * 64,
+                                             lane_e, evoff, bias != nullptr, bz[nh]);
+                    __builtin_amdgcn_sched_barrier(0);       // one block at a time: interleaved blocks cost registers the K loop then spills
+                }
+            bid += (int)gridDim.x;
+            if (bid >= nwg_all) break;
+            tile_coords(p, tm, tn, bid);
+            m_lo = (int64_t)tm * BM2; n_lo = (int64_t)tn * BN2;
+            m0 = min(m_lo, p.M - BM2); n0 = min(n_lo, p.N - BN2);
+            next_deltas();
+            request_bias();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            W_KTILE(25, 25, fbx, fby, 0, W_BUF);
+            W_KTILE(25, 24, fby, fbx, W_BUF, 0);
+            W_KLOOP(2)
+        }
+#undef W_KLOOP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead stagings of the last tile must not outlive the workgroup's LDS
+        return;
+    }
     {
         int kt = 0;
         for (; kt + 1 < nk; kt += 2) {
-            W_KTILE(fbx, fby, am0, an0, am1, an1, 0, W_BUF);
-            W_KTILE(fby, fbx, am1, an1, am0, an0, W_BUF, 0);
+            W_KTILE(24, 24, fbx, fby, 0, W_BUF);
+            W_KTILE(24, 24, fby, fbx, W_BUF, 0);
         }
-        if (kt < nk) W_KTILE(fbx, fby, am0, an0, am1, an1, 0, W_BUF);
+        if (kt < nk) W_KTILE(24, 24, fbx, fby, 0, W_BUF);
     }
 #undef W_KTILE
 #undef W_PHASE
@@ -324,6 +502,20 @@ int launch_gemm_wide(const GemmArgs& p, unsigned nwg, hipStream_t st) {
 #endif
     W_LAUNCH(0);
 #undef W_LAUNCH
+    return 0;
+}
+
+// persistent form (bf16 epilogues): one workgroup per CU walks its tiles; 160 KiB of LDS (two K-tile buffers + 4 x 8 KiB epilogue blocks)
+template <int EPI>
+int launch_gemm_wide_persistent(const GemmArgs& p, unsigned nwg, unsigned ncu, hipStream_t st) {
+    constexpr int LDS = 2 * W_BUF + 4 * 8192;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)gemm_bt256w_kernel<0, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        configured = true;
+    }
+    const unsigned grid = nwg < ncu ? nwg : ncu;
+    hipLaunchKernelGGL((gemm_bt256w_kernel<0, EPI, true>), dim3(grid), dim3(256), LDS, st, p);
     return 0;
 }
 

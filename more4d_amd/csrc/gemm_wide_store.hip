@@ -5,3 +5,7 @@
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_store(const void* args, unsigned nwg, hipStream_t st) {
     return launch_gemm_wide<M4D_EPI_STORE>(*(const GemmArgs*)args, nwg, st);
 }
+
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_store_persistent(const void* args, unsigned nwg, unsigned ncu, hipStream_t st) {
+    return launch_gemm_wide_persistent<M4D_EPI_STORE>(*(const GemmArgs*)args, nwg, ncu, st);
+}

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Same-box A/B of the production GEMM structures (M4D_GEMM_VARIANT is read once per process, so every variant runs in
 its own child, alternating): sustained timing at the DiT's three shapes on N(0,1) operands + bit-comparison of the results
-(all structures accumulate K in the same MFMA order).  Usage: python tools/ab_gemm.py 4 5 [--reps 2] [--n 40]"""
+(all structures accumulate K in the same MFMA order).  Usage: python tools/ab_gemm.py 4 5 5:0 [--reps 2] [--n 40]
+("5:0" = variant 5 with M4D_GEMM_PERSIST=0, i.e. the one-tile-per-workgroup form of the wide kernel)"""
 import hashlib, json, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -26,7 +27,16 @@ def child(n):
         resid = torch.zeros(M, N, device="cuda", dtype=torch.float32)
         gate = torch.randn(1, N, device="cuda", dtype=torch.float32, generator=g)
         ops.gemm_bt(a, w, b, out=resid, epilogue=ops.EPI_RESID_GATE, gate=gate, gate_stride=N, rows_per_sample=M)
+        # no-bias and tanh-GELU stores (the two forms the persistent kernel also serves); repeated: a persistent workgroup's tile
+        # hand-over races would not be deterministic
+        nb_ = ops.gemm_bt(a, w, None)
+        ge_ = ops.gemm_bt(a, w, b, epilogue=ops.EPI_GELU_TANH)
+        for _ in range(3):
+            if not (torch.equal(ops.gemm_bt(a, w, None), nb_) and torch.equal(ops.gemm_bt(a, w, b, epilogue=ops.EPI_GELU_TANH), ge_)
+                    and torch.equal(ops.gemm_bt(a, w, b), out)):
+                raise SystemExit(f"{name}: results differ between runs")
         digest = hashlib.sha1(out.view(torch.int16).cpu().numpy().tobytes() + resid.cpu().numpy().tobytes()).hexdigest()[:16]
+        digest += "/" + hashlib.sha1(nb_.view(torch.int16).cpu().numpy().tobytes() + ge_.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:8]
         for _ in range(5):
             ops.gemm_bt(a, w, b, out=out)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,7 +56,7 @@ def main():
         return child(int(sys.argv[sys.argv.index("--n") + 1]))
     variants = []
     for a in sys.argv[1:]:
-        if not a.isdigit():
+        if not a[0].isdigit():
             break
         variants.append(a)
     reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 2
@@ -54,7 +64,9 @@ def main():
     table = {}
     for rep in range(reps):
         for v in variants:
-            env = dict(os.environ, M4D_GEMM_VARIANT=v)
+            env = dict(os.environ, M4D_GEMM_VARIANT=v.split(":")[0])
+            if ":" in v:
+                env["M4D_GEMM_PERSIST"] = v.split(":")[1]
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--n", n], env=env, capture_output=True, text=True, timeout=900)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:
