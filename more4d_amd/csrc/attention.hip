@@ -558,11 +558,11 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             // 64 queries per wave: half the LDS traffic per MFMA, softmax interleaved into the MFMA stream (attention_wide.h)
             static bool configured_w = false;
             if (!configured_w) {
-                if (hipFuncSetAttribute((const void*)attn128w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
+                if (hipFuncSetAttribute((const void*)attn128w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
 #ifdef M4D_ABLATIONS
-                hipFuncSetAttribute((const void*)attn128w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-                hipFuncSetAttribute((const void*)attn128w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-                hipFuncSetAttribute((const void*)attn128w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                hipFuncSetAttribute((const void*)attn128w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
+                hipFuncSetAttribute((const void*)attn128w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
+                hipFuncSetAttribute((const void*)attn128w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
 #endif
                 configured_w = true;
             }
@@ -583,10 +583,10 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
             static bool configured = false;
             if (!configured) {
-                if (hipFuncSetAttribute((const void*)attn128p_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return -3;
-                hipFuncSetAttribute((const void*)attn128p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-                hipFuncSetAttribute((const void*)attn128p_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-                hipFuncSetAttribute((const void*)attn128p_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+                if (hipFuncSetAttribute((const void*)attn128p_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
+                hipFuncSetAttribute((const void*)attn128p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
+                hipFuncSetAttribute((const void*)attn128p_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
+                hipFuncSetAttribute((const void*)attn128p_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
                 configured = true;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
@@ -594,10 +594,10 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             M4D_ENV_ONCE(prio, "M4D_ATTN_PRIO", 1);
             const dim3 gp((unsigned)((int64_t)q.nq_tiles * p.heads * p.B));
             m4d_count_launch(M4D_KC_ATTN_PHASED);
-            if (smx == 0) hipLaunchKernelGGL((attn128p_kernel<0, 1>), gp, dim3(512), 4 * 32768, st, q);
-            else if (prio == 0) hipLaunchKernelGGL((attn128p_kernel<1, 0>), gp, dim3(512), 4 * 32768, st, q);
-            else if (prio == 2) hipLaunchKernelGGL((attn128p_kernel<1, 2>), gp, dim3(512), 4 * 32768, st, q);
-            else hipLaunchKernelGGL((attn128p_kernel<1, 1>), gp, dim3(512), 4 * 32768, st, q);
+            if (smx == 0) hipLaunchKernelGGL((attn128p_kernel<0, 1>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
+            else if (prio == 0) hipLaunchKernelGGL((attn128p_kernel<1, 0>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
+            else if (prio == 2) hipLaunchKernelGGL((attn128p_kernel<1, 2>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
+            else hipLaunchKernelGGL((attn128p_kernel<1, 1>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
         } else if (w8) {
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             m4d_count_launch(M4D_KC_ATTN_OTHER);

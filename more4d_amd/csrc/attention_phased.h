@@ -18,6 +18,19 @@
 // the pipelined loop only sees full DMA tiles.  Single K/V segment only (the multi-segment T-sharded call keeps
 // attn128_kernel<8>).
 #pragma once
+#include <type_traits>
+#ifndef M4D_ATTN_MSTREAM
+#define M4D_ATTN_MSTREAM 0      // side builds (tools/side_lib.sh): 1 = M stream without fragment reads, 2 = without MFMAs
+#endif
+#ifndef M4D_ATTN_STAMPS
+#define M4D_ATTN_STAMPS 0      // the stamp code costs ~8 % even when it is switched off at run time: its own side build
+#endif
+#ifndef M4D_ATTN_ONE_BARRIER
+#define M4D_ATTN_ONE_BARRIER 1
+#endif
+#ifndef M4D_ATTN_RING
+#define M4D_ATTN_RING 8
+#endif
 
 // ---- M-phase instruction stream: steps 0..15 = PV (c = J/4 key group, d = J%4 head-dim block), steps 16..31 = QK of the
 // next tile (kk = (J-16)/2, sub = (J-16)%2).  A ring of 8 fragment registers, step J consumes ring[J % 8] and re-fills
@@ -29,24 +42,74 @@ template <int N> M4D_DEV void lgkm_le() {
     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int J> M4D_DEV void m_read(bf16x8 (&ring)[8], const unsigned (&va)[4], const unsigned (&ka)[8]) {
-    if constexpr (J < 16) dsr128<(J & 3) * 4096>(ring[J & 7], va[J >> 2]);
-    else dsr128<((J - 16) & 1) * 8192>(ring[J & 7], ka[(J - 16) >> 1]);
+#ifndef M4D_ATTN_OACC
+#define M4D_ATTN_OACC 0
+#endif
+#if M4D_ATTN_OACC
+// EXPERIMENT (off): MFMAs by inline asm with the register FILE of every operand chosen by hand — O accumulating in AGPRs, the Q
+// fragments in AGPRs, S in arch VGPRs.  Measured slower (hipcc splits a 256-register budget 128 / 128 as soon as a kernel uses AGPRs and
+// the softmax then runs short of arch registers); the issue rate of the MFMAs does not depend on the accumulator file
+// (tools/probes/mfma_rate.hip).
+M4D_DEV void mma_o(const bf16x8& a, const bf16x8& b, f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+M4D_DEV void mma_s(const bf16x8& a, const bf16x8& q, f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(q)); }
+M4D_DEV void mma_s0(const bf16x8& a, const bf16x8& q, f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(q)); }
+M4D_DEV void mfma_settle() { asm volatile("s_nop 7\n\ts_nop 3" ::: "memory"); }
+#else
+M4D_DEV void mma_o(const bf16x8& a, const bf16x8& b, f32x16& c) { mma32(a, b, c); }
+M4D_DEV void mma_s(const bf16x8& a, const bf16x8& q, f32x16& c) { mma32(a, q, c); }
+M4D_DEV void mma_s0(const bf16x8& a, const bf16x8& q, f32x16& c) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q, zero, 0, 0, 0);      // C = 0 as an inline constant, no 32 v_mov to clear the accumulators
 }
-template <int J, int LAST> M4D_DEV void m_steps(bf16x8 (&ring)[8], const unsigned (&va)[4], const unsigned (&ka)[8],
-                                                const bf16x8 (&pf)[4], const bf16x8 (&qf)[8], f32x16 (&o)[4], f32x16 (&s)[2]) {
+M4D_DEV void mfma_settle() {}
+#endif
+// RD = ring depth (fragment reads in flight per wave) in the steady part of the stream.
+// Where the time of an M phase went (tools/attn_clock.py phase stamps, round 3): the 32 MFMAs themselves issue every 33-34 cycles
+// (tools/probes/mfma_rate.hip: 32.5-33.1 in every combination of accumulator file, chain length, neighbour wave), but the phase
+// took ~1 500 cycles because everything else sat in FRONT of the first MFMA or BEHIND the last one: the K / V^T tile request
+// (scalar address arithmetic, 4 DMA instructions), four more fragment prefetches, 12 address updates.  The stream now starts with
+// the first MFMA right after the barrier; steps 0..3 issue the four missing prefetches next to their regular read, and a `hook`
+// called once per step places the tile request (steps 3..7) and the address updates (steps 8..11, 10..24) in MFMA shadows.
+constexpr int RD = M4D_ATTN_RING;
+template <int J> struct MStep {
+    static constexpr bool pv = J < 16;
+    static constexpr int idx = J < 16 ? J : J - 16;
+};
+template <int J> M4D_DEV void m_read(bf16x8 (&ring)[RD], const unsigned (&va)[4], const unsigned (&ka)[8]) {
+    constexpr int I = MStep<J>::idx;
+    if constexpr (MStep<J>::pv) dsr128<(I & 3) * 4096>(ring[J % RD], va[I >> 2]);
+    else dsr128<(I & 1) * 8192>(ring[J % RD], ka[I >> 1]);
+}
+// issue order of the fragment reads: r0..r3 in the softmax phase, then step j issues r(j+4) (j < 4) and r(j+RD)
+constexpr int m_issued_by_step(int j, int LAST) { return (j < 4 && j + 4 < LAST ? 1 : 0) + (j + RD < LAST ? 1 : 0); }
+constexpr int m_issued_before(int J, int LAST) { int n = 4; for (int j = 0; j < J; ++j) n += m_issued_by_step(j, LAST); return n; }
+constexpr int m_pos(int r, int LAST) {      // position of read r in the issue order
+    if (r < 4) return r;
+    if (r < 8) return m_issued_before(r - 4, LAST);                                          // first read of step r-4
+    return m_issued_before(r - RD, LAST) + ((r - RD) < 4 && (r - RD) + 4 < LAST ? 1 : 0);     // after that step's late prefetch
+}
+// MODE (tool builds): 0 = the stream, 1 = MFMAs on whatever the ring holds (no fragment reads), 2 = fragment reads only
+template <int J, int LAST, int MODE = 0, typename Hook>
+M4D_DEV void m_steps(bf16x8 (&ring)[RD], const unsigned (&va)[4], const unsigned (&ka)[8], const bf16x8 (&pf)[4], const bf16x8 (&qf)[8],
+                     f32x16 (&o)[4], f32x16 (&s)[2], Hook&& hook) {
+    static_assert(RD == 8, "the late prefetch of steps 0..3 fills ring slots 4..7");
     if constexpr (J < LAST) {
-        lgkm_le<(J + 8 < LAST) ? 7 : LAST - 1 - J>();
-        if constexpr (J < 16) mma32(ring[J & 7], pf[J >> 2], o[J & 3]);
-        else if constexpr (J < 18) {   // first k-step of S: C = 0 (inline constant), no 32 v_mov to clear the accumulators
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            s[J - 16] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[J & 7], qf[0], zero, 0, 0, 0);
-        } else mma32(ring[J & 7], qf[(J - 16) >> 1], s[(J - 16) & 1]);
-        if constexpr (J + 8 < LAST) m_read<J + 8>(ring, va, ka);
-        m_steps<J + 1, LAST>(ring, va, ka, pf, qf, o, s);
+        constexpr int I = MStep<J>::idx;
+        if constexpr (MODE != 1) lgkm_le<m_issued_before(J, LAST) - m_pos(J, LAST) - 1>();      // fragment J has arrived (LDS returns in order)
+        if constexpr (MODE == 2) asm volatile("" :: "v"(ring[J % RD]));
+        else if constexpr (MStep<J>::pv) mma_o(ring[J % RD], pf[I >> 2], o[I & 3]);
+        else if constexpr (I < 2) mma_s0(ring[J % RD], qf[0], s[I]);       // first k-step of S: C = 0
+        else mma_s(ring[J % RD], qf[I >> 1], s[I & 1]);
+        if constexpr (MODE != 1) {
+            if constexpr (J < 4 && J + 4 < LAST) m_read<J + 4>(ring, va, ka);
+            if constexpr (J + RD < LAST) m_read<J + RD>(ring, va, ka);
+        }
+        hook(std::integral_constant<int, J>{});
+        __builtin_amdgcn_sched_barrier(0);
+        m_steps<J + 1, LAST, MODE>(ring, va, ka, pf, qf, o, s, hook);
     }
 }
-template <int J, int END> M4D_DEV void m_prefetch(bf16x8 (&ring)[8], const unsigned (&va)[4], const unsigned (&ka)[8]) {
+template <int J, int END> M4D_DEV void m_prefetch(bf16x8 (&ring)[RD], const unsigned (&va)[4], const unsigned (&ka)[8]) {
     if constexpr (J < END) { m_read<J>(ring, va, ka); m_prefetch<J + 1, END>(ring, va, ka); }
 }
 
@@ -88,6 +151,10 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
             }
         }
     }
+#if M4D_ATTN_OACC
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+a"(qf[kk]));      // home of the Q fragments: AGPRs (the "a" operands of mma_s then need no copies)
+#endif
     f32x16 o[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -140,9 +207,14 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (const char*)(((unsigned long long)hi2 << 32) | lo);
     };
-    auto dma_tile = [&](int stage, int64_t /*unused*/) {          // requests the NEXT tile of the list
-        const char* kp = uniform_ptr((const char*)(dkb + dk0 * kls));
-        const char* vp = uniform_ptr((const char*)(dvb + dk0));
+    // request of the NEXT tile of the list, in two parts so that the pipelined loop can place them in MFMA shadows: the scalar part
+    // (source pointers, iterator advance), then the 4 DMA instructions one at a time
+    const char* dma_kp = nullptr;
+    const char* dma_vp = nullptr;
+    unsigned dma_dst = 0;
+    auto dma_prepare = [&](int stage) {
+        dma_kp = uniform_ptr((const char*)(dkb + dk0 * kls));
+        dma_vp = uniform_ptr((const char*)(dvb + dk0));
         dk0 += KVB;
         if (dk0 + KVB > dlen) {
             dk0 = 0;
@@ -150,34 +222,42 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
             while (dseg < p.kv.nseg && p.kv.len[dseg] < KVB) ++dseg;
             if (dseg < p.kv.nseg) { dkb = seg_k(dseg); dvb = seg_v(dseg); dlen = p.kv.len[dseg]; }
         }
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 2048);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + i * 1024), "v"(offk[i]), "s"(kp) : "memory", "m0");
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + VOFF + i * 1024), "v"(offv[i]), "s"(vp) : "memory", "m0");
-        }
+        dma_dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 2048);
+    };
+    auto dma_issue = [&](int n) {          // n = 0..3 (a literal at every call site): K rows, V^T rows, K rows, V^T rows
+        const unsigned dst = dma_dst;
+        const char* const kp = dma_kp;
+        const char* const vp = dma_vp;
+        const unsigned ok0 = offk[0], ok1 = offk[1], ov0 = offv[0], ov1 = offv[1];
+        if (n == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(ok0), "s"(kp) : "memory", "m0");
+        else if (n == 1) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + VOFF), "v"(ov0), "s"(vp) : "memory", "m0");
+        else if (n == 2) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 1024), "v"(ok1), "s"(kp) : "memory", "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + VOFF + 1024), "v"(ov1), "s"(vp) : "memory", "m0");
+    };
+    auto dma_tile = [&](int stage, int64_t /*unused*/) {
+        dma_prepare(stage);
+        dma_issue(0); dma_issue(1); dma_issue(2); dma_issue(3);
     };
 
 #define M4D_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define M4D_LGKM(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-    bf16x8 ring[8];
+    bf16x8 ring[RD];
     f32x16 s[2];
     bf16x8 pf[4];
 
     // S^T = K Q^T of the tile in stage `st` (16 MFMAs, K fragments two kk ahead)
-#define M4D_QK(B, KK, SUB, OFF, W) do { M4D_LGKM(W); mma32(B, qf[KK], s[SUB]); if ((KK) + 2 < 8) M4D_DSR(B, ka[((KK) + 2) & 7], OFF); } while (0)
+#define M4D_QK(B, KK, SUB, OFF, W) do { M4D_LGKM(W); mma_s(B, qf[KK], s[SUB]); if ((KK) + 2 < 8) M4D_DSR(B, ka[((KK) + 2) & 7], OFF); } while (0)
+#define M4D_QK0(B, SUB, OFF, W) do { M4D_LGKM(W); mma_s0(B, qf[0], s[SUB]); M4D_DSR(B, ka[2], OFF); } while (0)
 #define M4D_QK_TILE(FIRSTWAIT)                                                                                        \
     do {                                                                                                             \
-        _Pragma("unroll") for (int sub = 0; sub < 2; ++sub)                                                          \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;                                          \
-        M4D_QK(ring[0], 0, 0, 0, 3); M4D_QK(ring[1], 0, 1, 8192, 3); M4D_QK(ring[2], 1, 0, 0, 3); M4D_QK(ring[3], 1, 1, 8192, 3);    \
+        M4D_QK0(ring[0], 0, 0, 3); M4D_QK0(ring[1], 1, 8192, 3); M4D_QK(ring[2], 1, 0, 0, 3); M4D_QK(ring[3], 1, 1, 8192, 3);    \
         M4D_QK(ring[0], 2, 0, 0, 3); M4D_QK(ring[1], 2, 1, 8192, 3); M4D_QK(ring[2], 3, 0, 0, 3); M4D_QK(ring[3], 3, 1, 8192, 3);    \
         M4D_QK(ring[0], 4, 0, 0, 3); M4D_QK(ring[1], 4, 1, 8192, 3); M4D_QK(ring[2], 5, 0, 0, 3); M4D_QK(ring[3], 5, 1, 8192, 3);    \
         M4D_QK(ring[0], 6, 0, 0, 3); M4D_QK(ring[1], 6, 1, 8192, 2); M4D_QK(ring[2], 7, 0, 0, 1); M4D_QK(ring[3], 7, 1, 8192, 0);    \
     } while (0)
 #define M4D_QK_PREFETCH() do { M4D_DSR(ring[0], ka[0], 0); M4D_DSR(ring[1], ka[0], 8192); M4D_DSR(ring[2], ka[1], 0); M4D_DSR(ring[3], ka[1], 8192); } while (0)
     // O^T += V^T P^T (16 MFMAs, V^T fragments four steps ahead); the last four steps start the K prefetch of the next QK
-#define M4D_PV(B, C, DD, OFF, W) do { M4D_LGKM(W); mma32(B, pf[C], o[DD]); if ((C) + 1 < 4) M4D_DSR(B, va[((C) + 1) & 3], OFF); } while (0)
+#define M4D_PV(B, C, DD, OFF, W) do { M4D_LGKM(W); mma_o(B, pf[C], o[DD]); if ((C) + 1 < 4) M4D_DSR(B, va[((C) + 1) & 3], OFF); } while (0)
 #define M4D_PV_PREFETCH() do { M4D_DSR(ring[0], va[0], 0); M4D_DSR(ring[1], va[0], 4096); M4D_DSR(ring[2], va[0], 8192); M4D_DSR(ring[3], va[0], 12288); } while (0)
 #define M4D_PV_TILE()                                                                                                 \
     do {                                                                                                             \
@@ -307,6 +387,7 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         M4D_QK_PREFETCH();
         M4D_QK_TILE(0);
         M4D_PV_PREFETCH();
+        mfma_settle();
         softmax((int)(len - tail0));
         __builtin_amdgcn_sched_barrier(0);
         M4D_PV_TILE();
@@ -326,53 +407,112 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ka[kk] += STAGE;                    // K side now points at tile 1 (stage 1)
         if constexpr (PRIO == 2) { if (grp == 1) __builtin_amdgcn_s_setprio(1); }
-        if (grp == 1) __builtin_amdgcn_s_barrier();                        // group 1 runs one barrier behind group 0
-#define M4D_V_PHASE()                                                                                                 \
+        // side build -DM4D_ATTN_STAMPS=1 (tools/side_lib.sh) with abl & 128: phase stamps of waves 0 and 4 of workgroup 1000, tiles 100..107, kept in LDS behind the stages
+        int i = 0;
+#if M4D_ATTN_STAMPS
+        const bool stamp_on = (M4D_ABL(p) & 128) && blockIdx.x == 1000 && __builtin_amdgcn_readfirstlane(wave & 3) == 0;
+#else
+        constexpr bool stamp_on = false;
+#endif
+        char* const stamp_base = psmem + NST * STAGE + __builtin_amdgcn_readfirstlane(wave >> 2) * 512;
+#define stamp(SLOT)                                                                                                   \
     do {                                                                                                             \
-        m_prefetch<0, 4>(ring, va, ka);      /* V^T(i) landed long ago; (only four: the softmax needs the registers) */ \
-        if (!(M4D_ABL(p) & 1)) softmax(KVB);                                                                              \
-        /* pin the whole softmax (exp2, row sums, bf16 packing) in front of the barrier: without these uses the      \
-           compiler sinks the 32 v_exp_f32 behind it, i.e. into the MFMA phase this schedule exists to keep clean */  \
+        if (stamp_on && i >= 100 && i < 108) {                                                                       \
+            unsigned long long tc_;                                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_) :: "memory");                            \
+            *reinterpret_cast<volatile unsigned long long*>(stamp_base + ((i - 100) * 8 + (SLOT)) * 8) = tc_;         \
+        }                                                                                                            \
+    } while (0)
+        // V(t): softmax of S(t) -> P(t); the first four fragments of the following PV are requested in front of it
+#define M4D_V_BODY()                                                                                                  \
+    do {                                                                                                             \
+        stamp(0);                                                                                                    \
+        m_prefetch<0, 4>(ring, va, ka);      /* V^T landed long ago; (only four: the softmax needs the registers) */   \
+        if (!(M4D_ABL(p) & 1)) softmax(KVB);                                                                          \
+        /* pin the whole softmax (exp2, row sums, bf16 packing) here: without these uses the compiler sinks the      \
+           32 v_exp_f32 into the MFMA stream this schedule exists to keep clean */                                   \
         asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));                                          \
         asm volatile("" : "+v"(l_run), "+v"(m_run));                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        stamp(1);                                                                                                    \
+    } while (0)
+        // M(i): one stream of 32 MFMAs (PV(i) then QK(i+1)); in its shadows: the request of tile i+3 (its stage held tile i-1, dead
+        // since the barrier that opened this interval) and the advance of the fragment addresses one stage (mod 4) as soon as the last
+        // read through them has been issued (va -> tile i+1 after step 7, ka[kk] -> tile i+2 after step 9 + 2 kk)
+#define M4D_M_BODY()                                                                                                  \
+    do {                                                                                                             \
+        stamp(2);                                                                                                    \
+        const bool do_dma = i + 3 < NT;                                                                              \
+        const unsigned dv = ((i + 1) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);                                \
+        const unsigned dk = ((i + 2) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);                                \
+        auto hook = [&](auto JJ) {                                                                                   \
+            constexpr int J = decltype(JJ)::value;                                                                   \
+            if constexpr (J == 3) { if (do_dma) dma_prepare((i + 3) & 3); }                                          \
+            if constexpr (J >= 4 && J < 8) { if (do_dma) dma_issue(J - 4); }                                         \
+            if constexpr (J >= 8 && J < 12) va[J - 8] += dv;                                                         \
+            if constexpr (J >= 10 && J <= 24 && (J & 1) == 0) ka[(J - 10) >> 1] += dk;                               \
+        };                                                                                                           \
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                      \
+        if (!(M4D_ABL(p) & 2)) m_steps<0, 32, M4D_ATTN_MSTREAM>(ring, va, ka, pf, qf, o, s, hook);                    \
+        else {                                                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+            if (do_dma) dma_tile((i + 3) & 3, 0);                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) va[c] += dv;                                               \
+            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) ka[kk] += dk;                                           \
+        }                                                                                                            \
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                      \
+        stamp(3);                                                                                                    \
+    } while (0)
+        // end of interval i: tile i+2 must have landed before anyone reads it in interval i+1; tile i+3 (just requested) may stay in flight
+#define M4D_END_INTERVAL()                                                                                            \
+    do {                                                                                                             \
+        if (i + 3 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        stamp(4);                                                                                                    \
         __builtin_amdgcn_s_barrier();                                                                                \
     } while (0)
-        int i = 0;
-        for (; i + 1 < NT; ++i) {
-            M4D_V_PHASE();
-            // ---- M(i): one stream of 32 MFMAs (PV(i) then QK(i+1)), fragments 8 steps ahead ----
-            if (i + 3 < NT) dma_tile((i + 3) & 3, (int64_t)(i + 3) * KVB);
-            __builtin_amdgcn_sched_barrier(0);
-            m_prefetch<4, 8>(ring, va, ka);
-            if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-            if (!(M4D_ABL(p) & 2)) m_steps<0, 32>(ring, va, ka, pf, qf, o, s);
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-            {   // advance the fragment addresses one stage (mod 4): va -> tile i+1, ka -> tile i+2
-                const unsigned dv = ((i + 1) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);
-                const unsigned dk = ((i + 2) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) va[c] += dv;
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) ka[kk] += dk;
-            }
-            // tile i+2 must have landed before anyone starts M(i+1); tile i+3 (just requested) may stay in flight
-            if (i + 3 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+#define M4D_LAST_PV()                                                                                                 \
+    do {                                                                                                             \
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                      \
+        m_steps<0, 16>(ring, va, ka, pf, qf, o, s, [](auto) {});                                                     \
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#if M4D_ATTN_ONE_BARRIER
+        // ONE barrier per tile.  In interval i both groups read V^T(i) and K(i+1) and nothing else; the early group runs
+        // V(i), M(i) and the late group M(i), V(i+1) (its V(0) is done here, in front of the loop), so on every SIMD one wave is in its
+        // softmax while the other streams MFMAs without a barrier between the halves: an interval costs V + M instead of
+        // 2 max(V, M) + two hand-overs (phase stamps, round 3: V 1 120, M 1 300, waits 700 cycles per tile and group).
+        if (grp == 0) {
+            for (; i + 1 < NT; ++i) { M4D_V_BODY(); M4D_M_BODY(); M4D_END_INTERVAL(); }
+            M4D_V_BODY();
+            M4D_LAST_PV();
+        } else {
+            M4D_V_BODY();
+            for (; i + 1 < NT; ++i) { M4D_M_BODY(); M4D_V_BODY(); M4D_END_INTERVAL(); }
+            M4D_LAST_PV();
         }
-        // ---- last tile: V(NT-1), then PV only ----
-        M4D_V_PHASE();
-        m_prefetch<4, 8>(ring, va, ka);
-        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        m_steps<0, 16>(ring, va, ka, pf, qf, o, s);
-        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+#else
+        // TWO barriers per tile: the late group runs exactly one barrier behind the early one
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (; i + 1 < NT; ++i) {
+            M4D_V_BODY();
+            __builtin_amdgcn_s_barrier();
+            M4D_M_BODY();
+            M4D_END_INTERVAL();
+        }
+        M4D_V_BODY();
         __builtin_amdgcn_s_barrier();
-#undef M4D_V_PHASE
+        M4D_LAST_PV();
+        __builtin_amdgcn_s_barrier();
         if (grp == 0) __builtin_amdgcn_s_barrier();                        // balance the barrier count
+#endif
+#undef M4D_V_BODY
+#undef M4D_M_BODY
+#undef M4D_END_INTERVAL
+#undef M4D_LAST_PV
+#undef stamp
         if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     }
 #undef M4D_PV_TILE
@@ -381,9 +521,11 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
 #undef M4D_QK_PREFETCH
 #undef M4D_QK_TILE
 #undef M4D_QK
+#undef M4D_QK0
 #undef M4D_LGKM
 #undef M4D_DSR
 
+    mfma_settle();
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     if (p.lse && qvalid && hi == 0) p.lse[((int64_t)b * p.heads + h) * p.Lq + qrow] = m_run + log2f(l_tot);
@@ -404,6 +546,10 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
                 }
                 store4(dst, v);
             }
+    }
+    if (M4D_ATTN_STAMPS && (M4D_ABL(p) & 128) && p.dbg && blockIdx.x == 1000) {      // phase stamps: [group][tile][slot] -> dbg + 8 Mi words
+        __syncthreads();
+        if (t < 128) p.dbg[(1 << 19) + t] = reinterpret_cast<unsigned long long*>(psmem + NST * STAGE)[t];
     }
     if ((M4D_ABL(p) & 64) && p.dbg && t == 0) {     // tool build: shader cycles and 100 MHz wall clock of this workgroup's lifetime
         unsigned long long* d = p.dbg + (size_t)blockIdx.x * 4;

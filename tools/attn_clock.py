@@ -15,18 +15,33 @@ k = torch.randn(B, L, C, device="cuda", dtype=torch.bfloat16)
 vt = torch.randn(C, B * L, device="cuda", dtype=torch.bfloat16)
 out = torch.empty_like(q)
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for i in range(8):
+N = int(os.environ.get("ATTN_ITERS", "8"))
+for i in range(N):
     if i == 3:
         s.record()
     ops.attention(q, [ops.KV(k, vt, L * C, C, L, B * L, L)], B=B, Lq=L, heads=n, head_dim=D, out=out)
 e.record()
 torch.cuda.synchronize()
-ms = s.elapsed_time(e) / 5
+ms = s.elapsed_time(e) / (N - 3)
 r = dbg.cpu().numpy().reshape(-1, 4)
 r = r[r[:, 1] > 0]
+if len(r) == 0:          # no stamps (shipping library or M4D_ATTN_ABL without bit 64): time only
+    print(f"attn128p self-attention: {ms:.3f} ms = {4.0 * B * L * L * n * D / ms / 1e9:.0f} TF")
+    sys.exit(0)
 cyc, us = r[:, 1] - r[:, 0], (r[:, 3] - r[:, 2]) / 100.0
 clk = cyc / np.maximum(us, 1e-9) / 1e3
 tf = 4.0 * B * L * L * n * D / ms / 1e9
+if int(os.environ.get("M4D_ATTN_ABL", "0")) & 128:      # phase stamps of workgroup 1000 (waves 0 and 4), tiles 100..107
+    st = dbg.cpu().numpy()[(1 << 19):(1 << 19) + 128].reshape(2, 8, 8)
+    names = ["V start", "V end (pre-barrier)", "M start (post-barrier)", "M stream issued", "M end (pre-barrier)"]
+    for g in range(2):
+        base = st[g, 0, 0]
+        print(f"group {g}: cycles relative to its V start of tile 100")
+        for ti in range(8):
+            row = st[g, ti, :5] - base
+            d = [int(row[0] - (st[g, ti - 1, 4] - base)) if ti else 0, int(row[1] - row[0]), int(row[2] - row[1]), int(row[3] - row[2]), int(row[4] - row[3])]
+            print(f"  tile {100 + ti}: " + " ".join(f"{int(x):7d}" for x in row) + f"   barrier->V {d[0]:5d}  V {d[1]:5d}  barrier {d[2]:5d}  M stream {d[3]:5d}  M tail {d[4]:5d}")
+    print("group 1 V start - group 0 V start (tile 100):", int(st[1, 0, 0] - st[0, 0, 0]))
 print(f"attn128p self-attention (abl {os.environ.get('M4D_ATTN_ABL')}): {ms:.2f} ms = {tf:.0f} TF; workgroups {len(r)}, lifetime {us.mean():.1f} us, shader clock "
       f"{np.median(clk):.3f} GHz (p10 {np.percentile(clk, 10):.3f}, p90 {np.percentile(clk, 90):.3f}); MFMA floor per workgroup "
       f"{(L / 64) * 32 * 32 * 2:.0f} cycles of {cyc.mean():.0f} = {(L / 64) * 32 * 32 * 2 / cyc.mean():.3f} busy")
