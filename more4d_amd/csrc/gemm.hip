@@ -570,7 +570,7 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
     p.epilogue = epilogue; p.bias_on_m = bias_on_m;
     p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0;
     p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
-    p.abl = 0;
+    p.abl = 0; p.sync = nullptr;
 #ifdef M4D_ABLATIONS
     { M4D_ENV_ONCE(abl_env, "M4D_GEMM_ABL", 0); p.abl = abl_env; }
 #endif
@@ -642,6 +642,16 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
             // (tool builds: the timing ablations / timeline stamps exist for the one-tile form only; 128.. = persistent epilogue debug bits)
             const bool pers_ok = persist && (p.abl & 127) == 0 && (epilogue == M4D_EPI_STORE || epilogue == M4D_EPI_GELU_TANH) && !(bias && bias_on_m) &&
                                  nkt >= 4 && (nkt & 1) == 0 && M * lda * 2 < (1ll << 32) && N * ldw * 2 < (1ll << 32) && nwg > ncu_p;
+            // XCD-wide tile rounds of the persistent kernel (M4D_GEMM_SYNC): 8 arrival counters in a library-owned buffer, zeroed in front
+            // of every launch (two persistent GEMMs running at once on different streams would only lose the hint)
+            p.sync = nullptr;
+            M4D_ENV_ONCE(psync, "M4D_GEMM_SYNC", 1);
+            if (pers_ok && psync && ncu_p % 8 == 0 && nwg > ncu_p) {
+                static unsigned* g_sync = nullptr;
+                static bool tried = false;
+                if (!tried) { tried = true; if (hipMalloc((void**)&g_sync, 1024) != hipSuccess) { g_sync = nullptr; (void)hipGetLastError(); } }
+                if (g_sync && hipMemsetAsync(g_sync, 0, 1024, st) == hipSuccess) p.sync = g_sync;
+            }
             const int rc = pers_ok ? (epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store_persistent(&p, (unsigned)nwg, (unsigned)ncu_p, st)
                                                                 : m4d_launch_gemm_wide_gelu_persistent(&p, (unsigned)nwg, (unsigned)ncu_p, st))
                          : epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store(&p, (unsigned)nwg, st)
@@ -700,7 +710,7 @@ extern "C" int m4d_gemm_bt_batched(m4d_dtype dt, const void* A, int64_t lda, int
     p.A = A; p.W = W; p.bias = nullptr; p.out = out; p.gate = nullptr;
     p.lda = lda; p.ldw = ldw; p.ldc = N; p.M = M; p.N = N; p.K = K;
     p.gate_stride = 0; p.rows_per_sample = M; p.epilogue = M4D_EPI_STORE_F32; p.bias_on_m = 0;
-    p.nb1 = nb1; p.a_bs1 = a_bs1; p.a_bs2 = a_bs2; p.w_bs1 = w_bs1; p.w_bs2 = w_bs2; p.abl = 0;
+    p.nb1 = nb1; p.a_bs1 = a_bs1; p.a_bs2 = a_bs2; p.w_bs1 = w_bs1; p.w_bs2 = w_bs2; p.abl = 0; p.sync = nullptr;
     p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(nb1 * nb2)), block(256);

@@ -23,6 +23,7 @@ struct GemmArgs {
     int tile_off;   // chunked launches (M4D_GEMM_CHUNK): this launch covers logical tiles [tile_off, tile_off + remap_n)
     float* ws;
     int abl;   // timing ablations (tools only; results wrong when != 0): 1 no DMA, 2 frags once, 4 no barriers, 8 no MFMA
+    unsigned* sync;   // persistent wide kernel: 8 arrival counters (one per XCD, 128 bytes apart, zeroed before the launch) or nullptr
 };
 
 constexpr int ROWB = 128;  // bytes of K per LDS row

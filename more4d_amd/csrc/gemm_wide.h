@@ -359,8 +359,19 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
             W_KTILE(24, 24, fbx, fby, 0, W_BUF);                                                           \
             W_KTILE(24, 24, fby, fbx, W_BUF, 0);                                                           \
         }
+        // XCD-wide tile rounds (p.sync): the 32 workgroups that share an XCD's L2 (blockIdx & 7) walk their tiles in rounds — round r is
+        // an 8 x 4 block of tiles that needs 12 A / W panels between them — but only workgroups whose K loops stay within a few
+        // K-tiles of each other find a neighbour's lines in the 4 MiB L2.  Every workgroup ARRIVES (one L2 atomic) when it enters the
+        // epilogue of a tile and, before the first phase of its next tile, wave 0 polls until all workgroups that had a tile in the
+        // finished round have arrived: drift stays below one epilogue.  A hint only — the poll gives up after ~20 us, nothing depends
+        // on it for correctness, and the other waves simply meet wave 0 at the first phase's barrier.
+        const int xcd_ = (int)blockIdx.x & 7;
+        const int q_x = (nwg_all >> 3) + (xcd_ < (nwg_all & 7) ? 1 : 0);
+        unsigned* const ctr = p.sync ? p.sync + xcd_ * 32 : nullptr;
+        int round_ = 0;
         W_KLOOP(0)
         for (;;) {
+            if (ctr && t == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // epilogue of this tile; the ring already holds K-tiles 0 and 1 of the next one, fa0 / fbx its first fragments.
             // The lane id is laundered through an empty asm so that hipcc recomputes the epilogue's per-lane addresses per tile
             // (a few dozen VALU instructions) instead of hoisting them out of the tile loop and spilling across the K loop.
@@ -407,6 +418,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            if (ctr) {
+                ++round_;
+                const unsigned target = (unsigned)min(q_x, 32 * round_);
+                if (wave == 0) {
+                    for (int k = 0; k < 64; ++k) {
+                        unsigned seen;
+                        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(ctr) : "memory");
+                        if (seen >= target) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+            }
             W_KTILE(25, 25, fbx, fby, 0, W_BUF);
             W_KTILE(25, 24, fby, fbx, W_BUF, 0);
             W_KLOOP(2)

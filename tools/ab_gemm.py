@@ -2,7 +2,7 @@
 """Same-box A/B of the production GEMM structures (M4D_GEMM_VARIANT is read once per process, so every variant runs in
 its own child, alternating): sustained timing at the DiT's three shapes on N(0,1) operands + bit-comparison of the results
 (all structures accumulate K in the same MFMA order).  Usage: python tools/ab_gemm.py 4 5 5:0 [--reps 2] [--n 40]
-("5:0" = variant 5 with M4D_GEMM_PERSIST=0, i.e. the one-tile-per-workgroup form of the wide kernel)"""
+("5:1:1" = persistent kernel with the XCD-wide tile rounds, M4D_GEMM_SYNC=1; "5:0" = variant 5 with M4D_GEMM_PERSIST=0, i.e. the one-tile-per-workgroup form of the wide kernel)"""
 import hashlib, json, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -67,6 +67,8 @@ def main():
             env = dict(os.environ, M4D_GEMM_VARIANT=v.split(":")[0])
             if ":" in v:
                 env["M4D_GEMM_PERSIST"] = v.split(":")[1]
+            if v.count(":") > 1:
+                env["M4D_GEMM_SYNC"] = v.split(":")[2]
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--n", n], env=env, capture_output=True, text=True, timeout=900)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:
