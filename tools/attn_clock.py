@@ -33,15 +33,18 @@ clk = cyc / np.maximum(us, 1e-9) / 1e3
 tf = 4.0 * B * L * L * n * D / ms / 1e9
 if int(os.environ.get("M4D_ATTN_ABL", "0")) & 128:      # phase stamps of workgroup 1000 (waves 0 and 4), tiles 100..107
     st = dbg.cpu().numpy()[(1 << 19):(1 << 19) + 128].reshape(2, 8, 8)
-    names = ["V start", "V end (pre-barrier)", "M start (post-barrier)", "M stream issued", "M end (pre-barrier)"]
+    # one barrier per tile: the early group (0) runs V(i), M(i) inside interval i, the late group (1) M(i), V(i+1); slots: 0 V start, 1 V end,
+    # 2 M start, 3 M stream issued, 4 end of interval (in front of the barrier)
+    order = {0: [0, 1, 2, 3, 4], 1: [2, 3, 0, 1, 4]}
+    label = {0: ["V start", "V end", "M start", "M issued", "interval end"], 1: ["M start", "M issued", "V start", "V end", "interval end"]}
     for g in range(2):
-        base = st[g, 0, 0]
-        print(f"group {g}: cycles relative to its V start of tile 100")
+        base = st[g, 0, order[g][0]]
+        print(f"group {g} ({'V then M' if g == 0 else 'M then V'}): cycles relative to the first stamp of tile 100; columns: " + ", ".join(label[g]))
         for ti in range(8):
-            row = st[g, ti, :5] - base
-            d = [int(row[0] - (st[g, ti - 1, 4] - base)) if ti else 0, int(row[1] - row[0]), int(row[2] - row[1]), int(row[3] - row[2]), int(row[4] - row[3])]
-            print(f"  tile {100 + ti}: " + " ".join(f"{int(x):7d}" for x in row) + f"   barrier->V {d[0]:5d}  V {d[1]:5d}  barrier {d[2]:5d}  M stream {d[3]:5d}  M tail {d[4]:5d}")
-    print("group 1 V start - group 0 V start (tile 100):", int(st[1, 0, 0] - st[0, 0, 0]))
+            row = [int(st[g, ti, k] - base) for k in order[g]]
+            d = [row[1] - row[0], row[2] - row[1], row[3] - row[2], row[4] - row[3]]
+            nxt = int(st[g, ti + 1, order[g][0]] - base) - row[4] if ti < 7 else 0
+            print(f"  tile {100 + ti}: " + " ".join(f"{x:7d}" for x in row) + f"   first phase {d[0]:5d}  gap {d[1]:5d}  second phase {d[2]:5d}  tail {d[3]:5d}  barrier -> next {nxt:5d}")
 print(f"attn128p self-attention (abl {os.environ.get('M4D_ATTN_ABL')}): {ms:.2f} ms = {tf:.0f} TF; workgroups {len(r)}, lifetime {us.mean():.1f} us, shader clock "
       f"{np.median(clk):.3f} GHz (p10 {np.percentile(clk, 10):.3f}, p90 {np.percentile(clk, 90):.3f}); MFMA floor per workgroup "
       f"{(L / 64) * 32 * 32 * 2:.0f} cycles of {cyc.mean():.0f} = {(L / 64) * 32 * 32 * 2 / cyc.mean():.3f} busy")

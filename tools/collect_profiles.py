@@ -31,6 +31,10 @@ cp(f"{src}/ab_gemm.log", "ab_gemm.log")
 cp(f"{src}/atomic_probe.log", "atomic_probe.log")
 cp(f"{src}/race_screen.log", "race_screen.log")
 cp(f"{src}/attn_clock.log", "attn_clock.log")
+cp(f"{src}/attn_phases.log", "attn_phases.log")
+cp(f"{src}/gemm_traffic_variants.log", "gemm_traffic_variants.log")
+cp(f"{src}/mfma_rate_probe.log", "mfma_rate_probe.log")
+cp(f"{src}/bw_probe.log", "bw_probe.log")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "train_4layers_kernel_stats.csv")
 subprocess.run([sys.executable, "tools/summarize_prof.py", tag], check=False)

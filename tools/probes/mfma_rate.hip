@@ -55,6 +55,60 @@ __global__ __launch_bounds__(256 * WPS, 1) void k(unsigned long long* out, float
     if (lane == 0 && wave == 0) out[blockIdx.x] = t1 - t0;
 }
 
+// The other direction: how fast does the VALU wave of a SIMD run while its neighbour streams MFMAs?  MF: 0 = neighbour parked at the
+// barrier, 1 = MFMAs with accumulators in arch VGPRs, 2 = in AGPRs.  OP: 0 = v_fma_f32 (4 independent chains), 1 = v_exp_f32.
+template <int MF, int OP>
+__global__ __launch_bounds__(512, 1) void kv(unsigned long long* out, float* sink, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (lane + j)); b[j] = (__bf16)(0.002f * (lane - j)); }
+    f32x16 c[4];
+    for (int d = 0; d < 4; ++d) for (int r = 0; r < 16; ++r) c[d][r] = 0.f;
+    float x0 = 0.5f + lane * 0.001f, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
+    unsigned long long t0 = 0, t1 = 0;
+    if (wave < 4) {
+        if (MF != 0) {
+            for (int it = 0; it < iters * 3; ++it) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    if (MF == 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c[j % 4]) : "v"(a), "v"(b));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c[j % 4]) : "v"(a), "v"(b));
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                if (OP == 0) {
+                    asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x0)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x1));
+                    asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x2)); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x3));
+                } else {
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(x0)); asm volatile("v_exp_f32 %0, %0" : "+v"(x1));
+                    asm volatile("v_exp_f32 %0, %0" : "+v"(x2)); asm volatile("v_exp_f32 %0, %0" : "+v"(x3));
+                }
+            }
+        }
+        asm volatile("s_nop 7\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float s = x0 + x1 + x2 + x3;
+    for (int d = 0; d < 4; ++d) for (int r = 0; r < 16; ++r) s += c[d][r];
+    if (s == 12345.678f) sink[0] = s;
+    if (lane == 0 && wave == 4) out[blockIdx.x] = t1 - t0;
+}
+template <int MF, int OP> void runv(const char* name, unsigned long long* d, float* sink) {
+    const int iters = 50, nb = 256;
+    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((kv<MF, OP>), dim3(nb), dim3(512), 0, 0, d, sink, iters); hipDeviceSynchronize(); }
+    unsigned long long h[256];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (int i = 0; i < nb; ++i) sum += (double)h[i];
+    printf("%-64s %6.2f cycles per VALU instruction\n", name, sum / nb / (iters * 256.0));
+}
+
 template <int WPS, int ACC, int GAP, int OTHER, int CH> void run(const char* name, unsigned long long* d, float* sink) {
     const int iters = 50, nb = 256;
     hipLaunchKernelGGL((k<WPS, ACC, GAP, OTHER, CH>), dim3(nb), dim3(256 * WPS), 0, 0, d, sink, iters);
@@ -88,5 +142,11 @@ int main() {
     run<2, 0, 2, 2, 4>("2 waves/SIMD (other: v_fma loop), VGPR acc, waitcnt + ds_read", d, sink);
     run<2, 1, 2, 1, 4>("2 waves/SIMD (other: v_exp loop), AGPR acc, waitcnt + ds_read", d, sink);
     run<2, 1, 2, 2, 4>("2 waves/SIMD (other: v_fma loop), AGPR acc, waitcnt + ds_read", d, sink);
+    runv<0, 0>("v_fma_f32 wave, neighbour parked", d, sink);
+    runv<1, 0>("v_fma_f32 wave, neighbour: MFMAs with VGPR accumulators", d, sink);
+    runv<2, 0>("v_fma_f32 wave, neighbour: MFMAs with AGPR accumulators", d, sink);
+    runv<0, 1>("v_exp_f32 wave, neighbour parked", d, sink);
+    runv<1, 1>("v_exp_f32 wave, neighbour: MFMAs with VGPR accumulators", d, sink);
+    runv<2, 1>("v_exp_f32 wave, neighbour: MFMAs with AGPR accumulators", d, sink);
     return 0;
 }
