@@ -147,3 +147,31 @@ def test_inner_model_entry_points_on_device():
     out.square().mean().backward()
     assert lat_g.grad is not None and bool(torch.isfinite(lat_g.grad).all()) and float(lat_g.grad.abs().max()) > 0
     assert m.decoder.head[2].weight.grad is not None
+
+
+@pytest.mark.parametrize("M,N,K,what", [
+    (70000, 512, 256, "548 tiles of 4 K-tiles: the shortest K loop the persistent form takes, ragged last tile row"),
+    (4100, 4104, 512, "17 x 17 tiles: both edges shifted inwards, the last round has 33 of 256 workgroups"),
+    (33000, 776, 1088, "K/64 odd: stays on the one-tile form"),
+    (8200, 2056, 768, "33 x 9 tiles, 12 K-tiles"),
+])
+def test_gemm_persistent_form_shapes(M, N, K, what):
+    """The persistent wide GEMM (default for bf16 stores when there are more tiles than CUs) against fp32 torch on sampled rows, for
+    plain / no-bias / tanh-GELU stores; repeated launches must agree bit for bit (a hand-over race between tiles would not).  The
+    bit-equality with the one-tile and phased forms is test_round2_gpu.py::test_gemm_switch_paths_in_a_subprocess."""
+    from more4d_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).bfloat16().to(DEV)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M)]).to(DEV)
+    ref = a[rows].float() @ w.float().t()
+    ops.launch_counts(reset=True)
+    for bias, epi, f in ((b, ops.EPI_STORE, lambda r: r + b.float()), (None, ops.EPI_STORE, lambda r: r),
+                         (b, ops.EPI_GELU_TANH, lambda r: torch.nn.functional.gelu(r + b.float(), approximate="tanh"))):
+        out = ops.gemm_bt(a, w, bias, epilogue=epi)
+        want = f(ref)
+        assert rel_err(out[rows].float().cpu(), want.cpu()) < 8e-3, what
+        for _ in range(2):
+            assert torch.equal(ops.gemm_bt(a, w, bias, epilogue=epi), out), what
+    assert ops.launch_counts()["gemm_wide"] == 9
