@@ -76,7 +76,7 @@ typedef enum {
  * Requirements: K*sizeof(T) % 16 == 0, N % 4 == 0, lda/ldw*sizeof(T) % 16 == 0, ldc % 4 == 0.
  * Side effects besides the launch: large bf16 STORE / GELU_TANH problems (more 256 x 256 tiles than CUs) run as a persistent kernel whose
  * workgroups pace each other per XCD through eight arrival counters in a 1 KiB device buffer the library allocates on its first such
- * call (so that first call must not sit inside a hipGraph capture) and clears with a hipMemsetAsync on `stream` in front of every such launch;
+ * call outside a stream capture and clears with a hipMemsetAsync on `stream` in front of every such launch;
  * the counters are a performance hint only (two such GEMMs running concurrently on different streams lose the hint, not the result).
  * M4D_GEMM_SYNC=0 / M4D_GEMM_PERSIST=0 in the environment switch the hint / the persistent form off. */
 int m4d_gemm_bt(m4d_dtype dt, const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,

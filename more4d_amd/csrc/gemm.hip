@@ -649,7 +649,14 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
             if (pers_ok && psync && ncu_p % 8 == 0 && nwg > ncu_p) {
                 static unsigned* g_sync = nullptr;
                 static bool tried = false;
-                if (!tried) { tried = true; if (hipMalloc((void**)&g_sync, 1024) != hipSuccess) { g_sync = nullptr; (void)hipGetLastError(); } }
+                if (!tried) {       // (never allocate inside a stream capture: the hint simply starts with the first launch outside one)
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { cs = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+                    if (cs == hipStreamCaptureStatusNone) {
+                        tried = true;
+                        if (hipMalloc((void**)&g_sync, 1024) != hipSuccess) { g_sync = nullptr; (void)hipGetLastError(); }
+                    }
+                }
                 if (g_sync && hipMemsetAsync(g_sync, 0, 1024, st) == hipSuccess) p.sync = g_sync;
             }
             const int rc = pers_ok ? (epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store_persistent(&p, (unsigned)nwg, (unsigned)ncu_p, st)
