@@ -646,7 +646,8 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
             // of every launch (two persistent GEMMs running at once on different streams would only lose the hint)
             p.sync = nullptr;
             M4D_ENV_ONCE(psync, "M4D_GEMM_SYNC", 1);
-            if (pers_ok && psync && ncu_p % 8 == 0 && nwg > ncu_p) {
+            // (only from four rounds on: at the 1.7 rounds of a rank's M = 5 460 shard the poll costs 3 % and there is hardly a panel to share)
+            if (pers_ok && psync && ncu_p % 8 == 0 && nwg >= 4 * (int64_t)ncu_p) {
                 static unsigned* g_sync = nullptr;
                 static bool tried = false;
                 if (!tried) {       // (never allocate inside a stream capture: the hint simply starts with the first launch outside one)
