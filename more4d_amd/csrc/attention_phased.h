@@ -28,9 +28,6 @@
 #ifndef M4D_ATTN_ONE_BARRIER
 #define M4D_ATTN_ONE_BARRIER 1
 #endif
-#ifndef M4D_ATTN_RING
-#define M4D_ATTN_RING 8
-#endif
 
 // ---- M-phase instruction stream: steps 0..15 = PV (c = J/4 key group, d = J%4 head-dim block), steps 16..31 = QK of the
 // next tile (kk = (J-16)/2, sub = (J-16)%2).  A ring of 8 fragment registers, step J consumes ring[J % 8] and re-fills
@@ -42,27 +39,15 @@ template <int N> M4D_DEV void lgkm_le() {
     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-#ifndef M4D_ATTN_OACC
-#define M4D_ATTN_OACC 0
-#endif
-#if M4D_ATTN_OACC
-// EXPERIMENT (off): MFMAs by inline asm with the register FILE of every operand chosen by hand — O accumulating in AGPRs, the Q
-// fragments in AGPRs, S in arch VGPRs.  Measured slower (hipcc splits a 256-register budget 128 / 128 as soon as a kernel uses AGPRs and
-// the softmax then runs short of arch registers); the issue rate of the MFMAs does not depend on the accumulator file
-// (tools/probes/mfma_rate.hip).
-M4D_DEV void mma_o(const bf16x8& a, const bf16x8& b, f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
-M4D_DEV void mma_s(const bf16x8& a, const bf16x8& q, f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(q)); }
-M4D_DEV void mma_s0(const bf16x8& a, const bf16x8& q, f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "a"(q)); }
-M4D_DEV void mfma_settle() { asm volatile("s_nop 7\n\ts_nop 3" ::: "memory"); }
-#else
+// (An inline-asm form of these three with O accumulating in AGPRs and the Q fragments in AGPRs was measured in round 3: 12 % slower —
+// hipcc splits a 256-register budget 128 / 128 as soon as a kernel uses AGPRs and the softmax runs short of arch registers — and the
+// MFMA issue rate does not depend on the accumulator file, tools/probes/mfma_rate.hip.  Removed.)
 M4D_DEV void mma_o(const bf16x8& a, const bf16x8& b, f32x16& c) { mma32(a, b, c); }
 M4D_DEV void mma_s(const bf16x8& a, const bf16x8& q, f32x16& c) { mma32(a, q, c); }
 M4D_DEV void mma_s0(const bf16x8& a, const bf16x8& q, f32x16& c) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q, zero, 0, 0, 0);      // C = 0 as an inline constant, no 32 v_mov to clear the accumulators
 }
-M4D_DEV void mfma_settle() {}
-#endif
 // RD = ring depth (fragment reads in flight per wave) in the steady part of the stream.
 // Where the time of an M phase went (tools/attn_clock.py phase stamps, round 3): the 32 MFMAs themselves issue every 33-34 cycles
 // (tools/probes/mfma_rate.hip: 32.5-33.1 in every combination of accumulator file, chain length, neighbour wave), but the phase
@@ -70,7 +55,7 @@ M4D_DEV void mfma_settle() {}
 // (scalar address arithmetic, 4 DMA instructions), four more fragment prefetches, 12 address updates.  The stream now starts with
 // the first MFMA right after the barrier; steps 0..3 issue the four missing prefetches next to their regular read, and a `hook`
 // called once per step places the tile request (steps 3..7) and the address updates (steps 8..11, 10..24) in MFMA shadows.
-constexpr int RD = M4D_ATTN_RING;
+constexpr int RD = 8;      // (12 and 14 were measured with the round-2 structure: slower)
 template <int J> struct MStep {
     static constexpr bool pv = J < 16;
     static constexpr int idx = J < 16 ? J : J - 16;
@@ -151,10 +136,6 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
             }
         }
     }
-#if M4D_ATTN_OACC
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+a"(qf[kk]));      // home of the Q fragments: AGPRs (the "a" operands of mma_s then need no copies)
-#endif
     f32x16 o[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -387,7 +368,6 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         M4D_QK_PREFETCH();
         M4D_QK_TILE(0);
         M4D_PV_PREFETCH();
-        mfma_settle();
         softmax((int)(len - tail0));
         __builtin_amdgcn_sched_barrier(0);
         M4D_PV_TILE();
@@ -525,7 +505,6 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
 #undef M4D_LGKM
 #undef M4D_DSR
 
-    mfma_settle();
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     if (p.lse && qvalid && hi == 0) p.lse[((int64_t)b * p.heads + h) * p.Lq + qrow] = m_run + log2f(l_tot);
