@@ -175,3 +175,32 @@ def test_gemm_persistent_form_shapes(M, N, K, what):
         for _ in range(2):
             assert torch.equal(ops.gemm_bt(a, w, bias, epilogue=epi), out), what
     assert ops.launch_counts()["gemm_wide"] == 9
+
+
+@pytest.mark.parametrize("C", [5120, 3072])
+@pytest.mark.parametrize("affine", [False, True], ids=["modulate", "affine"])
+def test_ln_modulate_rows_form_is_the_one_shot_kernel_bit_for_bit(C, affine):
+    """ln_modulate takes its LDS-staged persistent form from 4096 rows on (the DiT's shapes); the same rows fed in chunks of < 4096 go
+    through the one-shot kernel.  Same arithmetic in the same order: the outputs must agree bit for bit, and both match fp32 torch."""
+    from more4d_amd import ops
+    B, L = 2, 4100
+    g = torch.Generator().manual_seed(C + affine)
+    x = (torch.randn(B * L, C, generator=g) * 2 + 0.3).to(DEV)
+    sc = (torch.randn(B, 2, C, generator=g) * 0.3).to(DEV)
+    w, b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    if affine:
+        full = ops.ln_modulate(x, BF, ln_w=w, ln_b=b)
+    else:
+        full = ops.ln_modulate(x, BF, shift=sc[:, 0], scale=sc[:, 1], mod_stride=2 * C, rows_per_sample=L)
+    parts = []
+    for s_ in range(B):
+        for lo, hi in ((0, 2048), (2048, L)):
+            xs = x[s_ * L + lo:s_ * L + hi].contiguous()
+            if affine:
+                parts.append(ops.ln_modulate(xs, BF, ln_w=w, ln_b=b))
+            else:
+                parts.append(ops.ln_modulate(xs, BF, shift=sc[s_:s_ + 1, 0], scale=sc[s_:s_ + 1, 1], mod_stride=2 * C, rows_per_sample=hi - lo))
+    assert torch.equal(full, torch.cat(parts))
+    ref = torch.nn.functional.layer_norm(x.view(B, L, C), (C,), eps=1e-6)
+    ref = ref * w + b if affine else ref * (1 + sc[:, 1].reshape(B, 1, C)) + sc[:, 0].reshape(B, 1, C)
+    assert rel_err(full.float().cpu().view(B, L, C), ref.cpu()) < 8e-3
