@@ -369,6 +369,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
         const int q_x = (nwg_all >> 3) + (xcd_ < (nwg_all & 7) ? 1 : 0);
         unsigned* const ctr = p.sync ? p.sync + xcd_ * 32 : nullptr;
         int round_ = 0;
+        bool poll_ok = true;      // a poll that ran out (counters not visible: another launch shares them, or the workgroups of this
+                                  // blockIdx class do not share an L2 after all) switches the polling off for the rest of the launch
         W_KLOOP(0)
         for (;;) {
             if (ctr && t == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -421,11 +423,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
             if (ctr) {
                 ++round_;
                 const unsigned target = (unsigned)min(q_x, 32 * round_);
-                if (wave == 0) {
+                if (wave == 0 && poll_ok) {
+                    poll_ok = false;
                     for (int k = 0; k < 64; ++k) {
                         unsigned seen;
                         asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(seen) : "s"(ctr) : "memory");
-                        if (seen >= target) break;
+                        if (seen >= target) { poll_ok = true; break; }
                         __builtin_amdgcn_s_sleep(8);
                     }
                 }
