@@ -40,9 +40,37 @@ constexpr int W_A0 = 0, W_A1 = W_GRP, W_B0 = 2 * W_GRP, W_B1 = 3 * W_GRP;
 // same order, so the results are bit-identical.
 template <typename T, int EPI>
 M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, const f32x16& a01, const f32x16& a10, const f32x16& a11,
-                              int64_t m_base, int64_t n_base, int64_t m_lo, int64_t n_lo, int lane) {
+                              int64_t m_base, int64_t n_base, int64_t m_lo, int64_t n_lo, int lane,
+                              f32x4 (&r0)[8], f32x4 (&r1)[8], bool first, bool has_next, int64_t m_next, int64_t n_next) {
     // a[ni][mi2]: a00 = (ni 0, mi2 0), a01 = (ni 0, mi2 1), a10 = (ni 1, mi2 0), a11 = (ni 1, mi2 1)
     const int li = lane & 31, hi = lane >> 5;
+    const int c8 = lane & 7;
+    const int64_t nb = n_base + c8 * 8;
+    // Gated residual: written as "v += load(dst); store(dst, v)" per iteration, every load sat behind the previous iteration's store to the same
+    // array (may alias: hipcc keeps the order) and a block paid eight dependent HBM / L2 round trips — ~30 us of epilogue per 256 x 256 tile
+    // against 7 us for the bf16 store (the K = 5120 gated-residual GEMMs ran 23 % behind the q / k / v projections of the same size).
+    // Now a rolling window of eight iterations' residual values (r0 / r1, owned by the caller): the tile's first block requests all eight
+    // before its accumulators go through LDS, and every iteration re-fills its slot with the same iteration of the NEXT block right after its
+    // own store — a load has a whole block (~1.5 us) to arrive.
+    auto fetch = [&](int it, int64_t mb, int64_t nbb) {
+        const int64_t m = mb + it * 8 + (lane >> 3);
+        const float* src = (const float*)p.out + m * p.ldc + nbb;
+        r0[it] = (m >= m_lo && nbb >= n_lo) ? load4(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        r1[it] = (m >= m_lo && nbb + 4 >= n_lo) ? load4(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = {1.f, 1.f, 1.f, 1.f};
+    bool one_gate = false;
+    if constexpr (EPI == M4D_EPI_RESID_GATE) {
+        if (first) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) fetch(it, m_base, nb);
+        }
+        one_gate = p.gate && m_base / p.rows_per_sample == (m_base + 63) / p.rows_per_sample;      // (wave-uniform) the block lies in one sample
+        if (one_gate) {
+            const float* grow = p.gate + (m_base / p.rows_per_sample) * p.gate_stride + nb;
+            g0 = load4(grow); g1 = load4(grow + 4);
+        }
+    }
 #pragma unroll
     for (int mi2 = 0; mi2 < 2; ++mi2) {
         const int r = mi2 * 32 + li;
@@ -61,8 +89,6 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
     }
     // wave-private region: program order + the compiler's lgkmcnt wait order the reads after the writes
     constexpr bool F32OUT = EPI == M4D_EPI_RESID_GATE || EPI == M4D_EPI_STORE_F32;
-    const int c8 = lane & 7;
-    const int64_t nb = n_base + c8 * 8;
     const T* bias = (const T*)p.bias;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     if (bias && !p.bias_on_m) { b0 = load4(bias + nb); b1 = load4(bias + nb + 4); }
@@ -86,11 +112,15 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
             float* dst = (float*)p.out + m * p.ldc + nb;
             if constexpr (EPI == M4D_EPI_RESID_GATE) {
                 if (p.gate) {
-                    const float* grow = p.gate + (m / p.rows_per_sample) * p.gate_stride + nb;
-                    v0 = v0 * load4(grow); v1 = v1 * load4(grow + 4);
+                    if (one_gate) { v0 = v0 * g0; v1 = v1 * g1; }
+                    else {
+                        const float* grow = p.gate + (m / p.rows_per_sample) * p.gate_stride + nb;
+                        v0 = v0 * load4(grow); v1 = v1 * load4(grow + 4);
+                    }
                 }
-                if (m >= m_lo && nb >= n_lo) { v0 += load4(dst); store4(dst, v0); }
-                if (m >= m_lo && nb + 4 >= n_lo) { v1 += load4(dst + 4); store4(dst + 4, v1); }
+                if (m >= m_lo && nb >= n_lo) { v0 += r0[it]; store4(dst, v0); }
+                if (m >= m_lo && nb + 4 >= n_lo) { v1 += r1[it]; store4(dst + 4, v1); }
+                if (has_next) fetch(it, m_next, n_next + c8 * 8);
             } else {
                 if (m >= m_lo && nb >= n_lo) store4(dst, v0);
                 if (m >= m_lo && nb + 4 >= n_lo) store4(dst + 4, v1);
@@ -461,12 +491,16 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
     char* wl = dyn_smem + wave * 16384;
     // (the host sends bf16 outputs whose rows are not 16-byte aligned, and the erf-GELU / SiLU epilogues of a few small GEMMs, to
     // gemm_bt256p_kernel)
+    f32x4 res0[8], res1[8];      // rolling residual window of the gated-residual epilogue (unused by the others)
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
+        for (int mh = 0; mh < 2; ++mh) {
+            const int nxt = nh * 2 + mh + 1;        // next block in this order: (nh', mh') = (nxt >> 1, nxt & 1)
             epilogue_block64<T, EPI>(p, wl, acc[nh * 2][mh * 2], acc[nh * 2][mh * 2 + 1], acc[nh * 2 + 1][mh * 2], acc[nh * 2 + 1][mh * 2 + 1],
-                                 m0 + wm * 128 + mh * 64, n0 + wn * 128 + nh * 64, m_lo, n_lo, lane);
+                                 m0 + wm * 128 + mh * 64, n0 + wn * 128 + nh * 64, m_lo, n_lo, lane, res0, res1, nxt == 1, nxt < 4,
+                                 m0 + wm * 128 + (nxt & 1) * 64, n0 + wn * 128 + (nxt >> 1) * 64);
+        }
     if constexpr (ABL & 64) {       // timestamps (shader cycles) + 100 MHz wall clock + hardware id into the tile's first output row
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = __builtin_readcyclecounter();
