@@ -65,10 +65,14 @@ M4D_DEV float wave_max(float v) {
     return v;
 }
 
+// 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3): one v_exp_f32 and one v_rcp_f32 instead of libm's tanhf
+// (~30 instructions with range branches, 5 % of the ffn_up GEMM in its epilogue).  |error| of the two hardware ops: ~1e-7 relative, far
+// inside bf16 rounding and the fp32-mode parity budget; x -> -inf: exp -> +inf, rcp -> 0, result -0 like the tanh form.
 M4D_DEV float gelu_tanh_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    const float u = k0 * (x + k1 * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(u * -2.8853900817779268f);      // exp(-2u) = 2^(-2u log2 e)
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 M4D_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 M4D_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
