@@ -45,30 +45,35 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
     // a[ni][mi2]: a00 = (ni 0, mi2 0), a01 = (ni 0, mi2 1), a10 = (ni 1, mi2 0), a11 = (ni 1, mi2 1)
     const int li = lane & 31, hi = lane >> 5;
     const int c8 = lane & 7;
-    const int64_t nb = n_base + c8 * 8;
+    constexpr bool F32OUT = EPI == M4D_EPI_RESID_GATE || EPI == M4D_EPI_STORE_F32;
+    // the lane's two 4-column chunks of a row: bf16 outputs take 8 consecutive columns (one 16-byte store); fp32 outputs take chunk c8
+    // and chunk 8 + c8, so that the eight lanes of a row cover 128 CONTIGUOUS bytes per load / store instruction instead of 16 of every 32
+    constexpr int CA_MUL = F32OUT ? 1 : 2, CB_OFF = F32OUT ? 8 : 1;
+    const int cA = c8 * CA_MUL, cB = cA + CB_OFF;
+    const int64_t nb = n_base + cA * 4, nb2 = n_base + cB * 4;
     // Gated residual: written as "v += load(dst); store(dst, v)" per iteration, every load sat behind the previous iteration's store to the same
     // array (may alias: hipcc keeps the order) and a block paid eight dependent HBM / L2 round trips — ~30 us of epilogue per 256 x 256 tile
     // against 7 us for the bf16 store (the K = 5120 gated-residual GEMMs ran 23 % behind the q / k / v projections of the same size).
     // Now a rolling window of eight iterations' residual values (r0 / r1, owned by the caller): the tile's first block requests all eight
     // before its accumulators go through LDS, and every iteration re-fills its slot with the same iteration of the NEXT block right after its
     // own store — a load has a whole block (~1.5 us) to arrive.
-    auto fetch = [&](int it, int64_t mb, int64_t nbb) {
+    auto fetch = [&](int it, int64_t mb, int64_t nbase) {
         const int64_t m = mb + it * 8 + (lane >> 3);
-        const float* src = (const float*)p.out + m * p.ldc + nbb;
-        r0[it] = (m >= m_lo && nbb >= n_lo) ? load4(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-        r1[it] = (m >= m_lo && nbb + 4 >= n_lo) ? load4(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* src = (const float*)p.out + m * p.ldc + nbase;
+        r0[it] = (m >= m_lo && nbase + cA * 4 >= n_lo) ? load4(src + cA * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        r1[it] = (m >= m_lo && nbase + cB * 4 >= n_lo) ? load4(src + cB * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = {1.f, 1.f, 1.f, 1.f};
     bool one_gate = false;
     if constexpr (EPI == M4D_EPI_RESID_GATE) {
         if (first) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) fetch(it, m_base, nb);
+            for (int it = 0; it < 8; ++it) fetch(it, m_base, n_base);
         }
         one_gate = p.gate && m_base / p.rows_per_sample == (m_base + 63) / p.rows_per_sample;      // (wave-uniform) the block lies in one sample
         if (one_gate) {
-            const float* grow = p.gate + (m_base / p.rows_per_sample) * p.gate_stride + nb;
-            g0 = load4(grow); g1 = load4(grow + 4);
+            const float* grow = p.gate + (m_base / p.rows_per_sample) * p.gate_stride;
+            g0 = load4(grow + nb); g1 = load4(grow + nb2);
         }
     }
 #pragma unroll
@@ -88,16 +93,15 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
         }
     }
     // wave-private region: program order + the compiler's lgkmcnt wait order the reads after the writes
-    constexpr bool F32OUT = EPI == M4D_EPI_RESID_GATE || EPI == M4D_EPI_STORE_F32;
     const T* bias = (const T*)p.bias;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-    if (bias && !p.bias_on_m) { b0 = load4(bias + nb); b1 = load4(bias + nb + 4); }
+    if (bias && !p.bias_on_m) { b0 = load4(bias + nb); b1 = load4(bias + nb2); }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int r = it * 8 + (lane >> 3);
         const int64_t m = m_base + r;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((cA ^ (r & 15)) << 4));
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((cB ^ (r & 15)) << 4));
         if (bias) {
             if (p.bias_on_m) { const float bm = (float)bias[m]; v0 += bm; v1 += bm; }
             else { v0 += b0; v1 += b1; }
@@ -109,21 +113,21 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
         if constexpr (F32OUT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = round_through<T>(v0[e]); v1[e] = round_through<T>(v1[e]); }
-            float* dst = (float*)p.out + m * p.ldc + nb;
+            float* drow = (float*)p.out + m * p.ldc;
             if constexpr (EPI == M4D_EPI_RESID_GATE) {
                 if (p.gate) {
                     if (one_gate) { v0 = v0 * g0; v1 = v1 * g1; }
                     else {
-                        const float* grow = p.gate + (m / p.rows_per_sample) * p.gate_stride + nb;
-                        v0 = v0 * load4(grow); v1 = v1 * load4(grow + 4);
+                        const float* grow = p.gate + (m / p.rows_per_sample) * p.gate_stride;
+                        v0 = v0 * load4(grow + nb); v1 = v1 * load4(grow + nb2);
                     }
                 }
-                if (m >= m_lo && nb >= n_lo) { v0 += r0[it]; store4(dst, v0); }
-                if (m >= m_lo && nb + 4 >= n_lo) { v1 += r1[it]; store4(dst + 4, v1); }
-                if (has_next) fetch(it, m_next, n_next + c8 * 8);
+                if (m >= m_lo && nb >= n_lo) { v0 += r0[it]; store4(drow + nb, v0); }
+                if (m >= m_lo && nb2 >= n_lo) { v1 += r1[it]; store4(drow + nb2, v1); }
+                if (has_next) fetch(it, m_next, n_next);
             } else {
-                if (m >= m_lo && nb >= n_lo) store4(dst, v0);
-                if (m >= m_lo && nb + 4 >= n_lo) store4(dst + 4, v1);
+                if (m >= m_lo && nb >= n_lo) store4(drow + nb, v0);
+                if (m >= m_lo && nb2 >= n_lo) store4(drow + nb2, v1);
             }
         } else {
             union { uint4 u; bf16x4 h[2]; } o;
