@@ -96,6 +96,13 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
     const T* bias = (const T*)p.bias;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     if (bias && !p.bias_on_m) { b0 = load4(bias + nb); b1 = load4(bias + nb2); }
+    // bias along m (the V^T projection): the eight rows' values up front — loaded inside the iterations each one queued behind the previous
+    // iteration's store (same may-alias order as the residual above): that GEMM ran 41 % behind the q / k projections of the same FLOPs
+    float bm8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias && p.bias_on_m) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) bm8[it] = (float)bias[m_base + it * 8 + (lane >> 3)];
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int r = it * 8 + (lane >> 3);
@@ -103,7 +110,7 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
         f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((cA ^ (r & 15)) << 4));
         f32x4 v1 = *reinterpret_cast<const f32x4*>(wl + r * 256 + ((cB ^ (r & 15)) << 4));
         if (bias) {
-            if (p.bias_on_m) { const float bm = (float)bias[m]; v0 += bm; v1 += bm; }
+            if (p.bias_on_m) { const float bm = bm8[it]; v0 += bm; v1 += bm; }
             else { v0 += b0; v1 += b1; }
         }
         if constexpr (EPI == M4D_EPI_GELU_TANH) {
