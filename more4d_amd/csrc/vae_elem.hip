@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float y = (u.h[h][e] - m[h]) * r[h] * w[h][e] + bb[h][e];
-                if (p.silu) { y = round_through<T>(y); y = y / (1.f + __expf(-y)); }
+                if (p.silu) y = silu_f(round_through<T>(y));
                 u.h[h][e] = y;
             }
     };
