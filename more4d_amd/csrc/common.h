@@ -78,6 +78,10 @@ M4D_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067
 // (v_rcp_f32 instead of the IEEE division sequence, ~10 instructions: eight SiLUs per read-back iteration sit in the latency-bound fused-norm
 // epilogue of the VAE conv; 1 ulp, far inside the bf16 rounding that follows — every SiLU of the library goes through this one function)
 M4D_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// root_c / max(|x|, 1e-12) of the VAE's RMS_norm (F.normalize): v_sqrt_f32 + v_rcp_f32 (1 ulp each) instead of the correctly rounded
+// sqrtf and IEEE division sequences (~25 instructions per pixel in the fused-norm conv epilogue); ONE function for the fused epilogue and
+// the separate kernel, whose results must agree bit for bit
+M4D_DEV float rms_scale_f(float root_c, float ss) { return root_c * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f)); }
 
 // ---- A/B switches and timing ablations ----
 // Environment switches are read ONCE per process (M4D_ENV_ONCE).  Timing ablations (M4D_*_ABL: kernels that skip work,

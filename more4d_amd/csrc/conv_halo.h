@@ -392,7 +392,7 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
                     if constexpr (!GAMMA_ONCE) {
                         if (act) { pg0 = load4(p.post_gamma + ch * 8); pg1 = load4(p.post_gamma + ch * 8 + 4); }
                     }
-                    const float sc = root_c / fmaxf(sqrtf(ss[jj]), 1e-12f);
+                    const float sc = rms_scale_f(root_c, ss[jj]);
                     const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw[jj]);
                     bf16x8 y;
 #pragma unroll

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(RmsClArgs p) {
 #pragma unroll
     for (int o = SW / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     // F.normalize: x / max(||x||, 1e-12), then * sqrt(C) * gamma   (wan_vae.py :55-58)
-    const float sc = sqrtf((float)p.C) / fmaxf(sqrtf(s), 1e-12f);
+    const float sc = rms_scale_f(sqrtf((float)p.C), s);
     if (!active) return;
     T* orow = (T*)p.out + pix * p.out_ld;
 #pragma unroll
