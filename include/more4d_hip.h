@@ -122,7 +122,7 @@ int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, void* out, 
 
 /* In-place WanRMSNorm over the full channel dim (:386-394) followed by 3-axis RoPE on adjacent pairs
  * (:340-369) for up to two tensors (q and k) in one launch.
- *   x0/x1: T [rows, C] row stride ld (x1 may be NULL); w0/w1: float [C];
+ *   x0/x1: T [rows, C] row stride ld (x1 may be NULL); w0/w1: float [C], both NULL => RoPE only (qk_norm=False, :431-432);
  *   cos/sin: float [table_rows, head_dim/2], per-token tables built by the host for the (f,h,w) grid
  *   (NULL => no RoPE, cross-attention q/k); token l = row % rows_per_sample gets table row
  *   pos_offset + l when l < rope_len, rows past rope_len are normalised but not rotated (:365). */

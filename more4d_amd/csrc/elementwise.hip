@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs p) {
     }
     const float inv = rsqrtf(wave_sum(s) / C + p.eps);
     if (!active) return;
+    const bool norm = w != nullptr;           // NULL weight: RoPE only (qk_norm=False, reference :431-432: norm_q / norm_k = nn.Identity)
     const int64_t l = row % p.rows_per_sample;
     const bool rot = p.cos_t && l < p.rope_len;
     const int half = p.head_dim >> 1;
@@ -220,9 +221,14 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs p) {
             // reference: (x * rsqrt(..)).to(x.dtype) * weight  (wan_transformer4d.py:391-394)
 #pragma unroll
             for (int e = 0; e < EPV; e += 4) {
-                const f32x4 wv = load4(w + c + e);
+                if (norm) {
+                    const f32x4 wv = load4(w + c + e);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[e + j] = round_through<T>(v[i][e + j] * inv) * wv[j];
+                    for (int j = 0; j < 4; ++j) y[e + j] = round_through<T>(v[i][e + j] * inv) * wv[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[e + j] = v[i][e + j];
+                }
             }
             if (rot) {
                 const int pi = (c % p.head_dim) >> 1;  // first pair index inside the head; pairs are (c+2j, c+2j+1)
@@ -487,8 +493,9 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
 extern "C" int m4d_rmsnorm_rope(m4d_dtype dt, void* x0, void* x1, int64_t ld, const float* w0, const float* w1,
                                 int64_t rows, int C, int head_dim, float eps, const float* cos_t, const float* sin_t,
                                 int64_t rows_per_sample, int64_t rope_len, int64_t pos_offset, m4d_stream stream) {
-    M4D_CHECK_ARG(x0 && w0 && rows > 0, "rmsnorm_rope: null/empty");
-    M4D_CHECK_ARG(x1 == nullptr || w1 != nullptr, "rmsnorm_rope: x1 without w1");
+    M4D_CHECK_ARG(x0 && rows > 0, "rmsnorm_rope: null/empty");
+    M4D_CHECK_ARG(w0 || cos_t, "rmsnorm_rope: neither a norm weight nor rope tables: nothing to do");
+    M4D_CHECK_ARG(x1 == nullptr || (w1 != nullptr) == (w0 != nullptr), "rmsnorm_rope: x1 must be normalised like x0 (both weights or neither)");
     M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 8192, "rmsnorm_rope: C=%d must be a multiple of 4 and <= 8192", C);
     M4D_CHECK_ARG(head_dim > 0 && head_dim % 8 == 0 && C % head_dim == 0, "rmsnorm_rope: head_dim=%d must divide C and be a multiple of 8", head_dim);
     M4D_CHECK_ARG(dt != M4D_BF16 || (ld % 8 == 0 && ((uintptr_t)x0 % 16) == 0 && (x1 == nullptr || ((uintptr_t)x1 % 16) == 0)), "rmsnorm_rope: bf16 rows must be 16-byte aligned");

@@ -123,13 +123,15 @@ class WanSelfAttention(nn.Module):
     def _ones(self, ref):
         return torch.ones(self.dim, device=ref.device, dtype=torch.float32)
 
-    def run(self, xn, xres, gate, gate_stride, c: _Ctx):
-        """xn: T [B, Lp, C] modulated input; accumulates o-proj * gate into xres (float32) in place."""
+    def run(self, xn, xres, gate, gate_stride, c: _Ctx, gate_rows=None):
+        """xn: T [B, Lp, C] modulated input; accumulates o-proj * gate into xres (float32) in place.  gate_rows: rows that share
+        one gate vector (default: a sample's Lp rows; 1 = per-token gates)."""
         B, Lp, C = xn.shape
         n, d = self.num_heads, self.head_dim
-        if not self.qk_norm:  # rope without norm is not a reference configuration for Wan checkpoints
-            raise NotImplementedError("qk_norm=False is not supported by the fused rmsnorm+rope kernel")
-        wq, wk = _f32(self.norm_q.weight, c.f32cache), _f32(self.norm_k.weight, c.f32cache)
+        if self.qk_norm:
+            wq, wk = _f32(self.norm_q.weight, c.f32cache), _f32(self.norm_k.weight, c.f32cache)
+        else:       # norm_q / norm_k are nn.Identity (:431-432): the same kernel with NULL weights rotates only
+            wq = wk = None
         rope = dict(head_dim=d, eps=self.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
                     pos_offset=c.pos_offset)
         if c.sp is None or c.sp.world_size == 1:
@@ -173,7 +175,7 @@ class WanSelfAttention(nn.Module):
         if segs is not None:
             o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
         ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=gate,
-                    gate_stride=gate_stride, rows_per_sample=Lp)
+                    gate_stride=gate_stride, rows_per_sample=gate_rows or Lp)
         return xres
 
 
@@ -321,6 +323,20 @@ class SpatialGuidanceModule(nn.Module):
         return ops.gemm_bt(feats_silu.reshape(B * P, D), lin.weight, lin.bias, epilogue=EPI_STORE_F32).view(B, P, -1)
 
 
+def _fold_guidance(e, i_scale, i_shift, g, B, Lp, C):
+    """Per-token table e [B*Lp, 6, C] (in place): scale <- (1 + scale)(1 + gs gate) - 1, shift <- shift (1 + gs gate) + gh gate for
+    the guided tokens l < g_len, gs | gh = row (l % period) of the guidance table (SpatialGuidanceModule, reference :769-781)."""
+    period, glen = int(g["g_period"]), int(g["g_len"])
+    if glen <= 0:
+        return
+    idx = torch.arange(glen, device=e.device) % period
+    tab = g["g_ss"].view(B, -1, 2 * C)[:, idx] * g["g_gate"].repeat(2)                    # [B, glen, 2C]
+    ev = e.view(B, Lp, 6, C)
+    m = 1.0 + tab[..., :C]
+    ev[:, :glen, i_shift] = ev[:, :glen, i_shift] * m + tab[..., C:]
+    ev[:, :glen, i_scale] = (1.0 + ev[:, :glen, i_scale]) * m - 1.0
+
+
 class WanAttentionBlock(nn.Module):
     def __init__(self, cross_attn_type, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True,
                  cross_attn_norm=False, eps=1e-6, use_spatial_guidance=True):
@@ -343,12 +359,16 @@ class WanAttentionBlock(nn.Module):
             self.spatial_guidance_ffn = None
 
     def run(self, xres, e0, c: _Ctx, cc: ContextCache, layer, guid=None):
-        """xres: float32 [B, Lp, C] residual stream (updated in place); e0: float32 [B, 6, C]."""
+        """xres: float32 [B, Lp, C] residual stream (updated in place); e0: float32 [B, 6, C], or [B, Lp, 6, C] for per-token
+        timesteps (reference :655-657: `e.dim() > 3`) — the kernels index their modulation / gate vectors by
+        `row / rows_per_sample`, so one vector per token is the same call with rows_per_sample = 1."""
         B, Lp, C = xres.shape
         T = self.ffn[0].weight.dtype
+        per_token = e0.dim() == 4
         # e = modulation + e0 (:659): a [B,6,C] table, rows = shift1, scale1, gate1, shift2, scale2, gate2
-        e = ops.add_bcast(e0, _f32(self.modulation, c.f32cache))
+        e = ops.add_bcast(e0, _f32(self.modulation, c.f32cache)).view(-1, 6, C)
         st = 6 * C
+        rps = 1 if per_token else Lp
         g1 = dict(g_ss=None)
         g2 = dict(g_ss=None)
         if guid is not None and self.spatial_guidance_self is not None:
@@ -357,10 +377,18 @@ class WanAttentionBlock(nn.Module):
                       g_gate=_f32(self.spatial_guidance_self.gate, c.f32cache), g_period=period, g_len=glen)
             g2 = dict(g_ss=self.spatial_guidance_ffn.table(feats_silu, c.f32cache),
                       g_gate=_f32(self.spatial_guidance_ffn.gate, c.f32cache), g_period=period, g_len=glen)
+            if per_token:
+                # guidance on top of a per-token modulation: the guided result (LN (1 + sc) + sh) (1 + gs g) + gh g (:781) is
+                # again ONE scale / shift pair per token — fold it into the table (the kernel's guidance index is
+                # row % rows_per_sample, which per-token calls use for the modulation)
+                e = e.clone()
+                _fold_guidance(e, 1, 0, g1, B, Lp, C)
+                _fold_guidance(e, 4, 3, g2, B, Lp, C)
+                g1, g2 = dict(g_ss=None), dict(g_ss=None)
         # self-attention (:662-669)
-        xn = ops.ln_modulate(xres, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=Lp, eps=self.eps,
+        xn = ops.ln_modulate(xres, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=rps, eps=self.eps,
                              **g1)
-        self.self_attn.run(xn, xres, e[:, 2], st, c)
+        self.self_attn.run(xn, xres, e[:, 2], st, c, gate_rows=rps)
         # cross-attention (:674)
         if self.cross_attn_norm:
             xn = ops.ln_modulate(xres, T, ln_w=_f32(self.norm3.weight, c.f32cache),
@@ -369,11 +397,11 @@ class WanAttentionBlock(nn.Module):
             xn = ops.unary(xres, T, out=xn)
         self.cross_attn.run(xn, xres, c, cc, layer)
         # ffn (:677-684)
-        xn = ops.ln_modulate(xres, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=Lp, eps=self.eps,
+        xn = ops.ln_modulate(xres, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=rps, eps=self.eps,
                              out=xn, **g2)
         h = ops.gemm_bt(xn, self.ffn[0].weight, self.ffn[0].bias, epilogue=EPI_GELU_TANH)
         ops.gemm_bt(h, self.ffn[2].weight, self.ffn[2].bias, out=xres, epilogue=EPI_RESID_GATE, gate=e[:, 5],
-                    gate_stride=st, rows_per_sample=Lp)
+                    gate_stride=st, rows_per_sample=rps)
         return xres
 
 
@@ -411,7 +439,12 @@ class WanAttentionBlock(nn.Module):
             src = cls.expand(-1, feats.shape[1], -1) if (use_cls_token and cls is not None) else feats
             # the reference applies guidance per token over feats.shape[1] tokens (zero beyond, :772-776)
             guid = (ops.unary(src.to(dev).contiguous(), T, act=1), feats.shape[1], feats.shape[1])
-        self.run(xres, e.to(device=dev, dtype=torch.float32).contiguous(), c, cc, 0, guid)
+        e = e.to(device=dev, dtype=torch.float32).contiguous()
+        if e.dim() > 3:                              # per-token modulation [B, L, 6, C] (:655-657)
+            ep = torch.zeros((B, Lp, 6, C), device=dev, dtype=torch.float32)
+            ep[:, :L] = e
+            e = ep
+        self.run(xres, e, c, cc, 0, guid)
         return xres[:, :L]
 
 
@@ -425,11 +458,14 @@ class Head(nn.Module):
         self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
 
     def run(self, xres, e, f32cache):
-        """xres float32 [B, Lp, C], e float32 [B, C] -> float32 [B, Lp, prod(patch)*out_dim] (:708-721)."""
+        """xres float32 [B, Lp, C], e float32 [B, C] (or [B, Lp, C]: per-token timesteps, :713-715) -> float32
+        [B, Lp, prod(patch)*out_dim] (:708-721)."""
         B, Lp, C = xres.shape
         T = self.head.weight.dtype
-        m = ops.add_bcast(e.view(B, 1, C).expand(B, 2, C).contiguous(), _f32(self.modulation, f32cache))
-        xn = ops.ln_modulate(xres, T, shift=m[:, 0], scale=m[:, 1], mod_stride=2 * C, rows_per_sample=Lp, eps=self.eps)
+        per_token = e.dim() == 3
+        m = ops.add_bcast(e.reshape(-1, 1, C).expand(-1, 2, C).contiguous(), _f32(self.modulation, f32cache))
+        xn = ops.ln_modulate(xres, T, shift=m[:, 0], scale=m[:, 1], mod_stride=2 * C, rows_per_sample=1 if per_token else Lp,
+                             eps=self.eps)
         out = ops.gemm_bt(xn, self.head.weight, self.head.bias, epilogue=EPI_STORE_F32)
         return out.view(B, Lp, -1)
 
@@ -655,7 +691,8 @@ class WanTransformer4DModel(nn.Module):
         return cc
 
     def _time_embed(self, t):
-        """e [B, C], e0 [B, 6, C] float32 (:1160-1171): fp32 GEMMs regardless of T."""
+        """e [B, C], e0 [B, 6, C] float32 (:1160-1171): fp32 GEMMs regardless of T.  t may hold any number of timesteps (per-token
+        calls pass the flattened [B * seq_len] vector, :1161-1167)."""
         dev = self.device
         s = sinusoidal_embedding_1d(self.freq_dim, t.to(dev)).float().contiguous()
         fc = self._f32cache
@@ -679,8 +716,6 @@ class WanTransformer4DModel(nn.Module):
         """
         if y_camera is not None or subject_ref is not None:
             raise NotImplementedError("y_camera / subject_ref are not part of the 4D-STraG path")
-        if t.dim() != 1:
-            raise NotImplementedError("per-token timesteps (ti2v) are not part of the 4D-STraG path")
         if first_frame is not None and self.use_omnimae_guidance and first_frame_features is None:
             first_frame_features = self.omnimae_extractor.trunk.forward_patch_features(first_frame, None, normalize=True)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -706,6 +741,7 @@ class WanTransformer4DModel(nn.Module):
         key_len = L if self.mask_padding_keys else seq_len
         if sp is not None:
             seq_len = int(math.ceil(seq_len / self.sp_world_size)) * self.sp_world_size
+        seq_len_tok = seq_len                     # what a per-token t is unflattened to (:1166, after the SP round-up of :1100)
         assert L <= seq_len, f"sequence of {L} tokens exceeds seq_len={seq_len}"
         # ---- tokens: patch gather + GEMM straight into the fp32 residual stream
         Lp = _round8(seq_len) if sp is None else _round8(seq_len // self.sp_world_size) * self.sp_world_size
@@ -720,7 +756,18 @@ class WanTransformer4DModel(nn.Module):
             for b in range(B):
                 ops.gemm_bt(rt[b], wr, self.ref_conv.bias, out=xres[b, :n_ref], epilogue=EPI_STORE_F32)
         # ---- conditioning
-        e, e0 = self._time_embed(t)
+        if t.dim() != 1:
+            # per-token timesteps (:1161-1167): t [B, seq_len] (seq_len AFTER the ref row was added, :1088) -> e [B, Lp, C],
+            # e0 [B, Lp, 6, C]; rows beyond seq_len exist only as padding and get a zero modulation
+            if t.shape[0] != B or t.shape[1] != seq_len_tok:
+                raise ValueError(f"per-token t must be [B, seq_len] = [{B}, {seq_len_tok}], got {tuple(t.shape)}")
+            ef, e0f = self._time_embed(t.reshape(-1))
+            e = torch.zeros((B, Lp, self.dim), device=dev, dtype=torch.float32)
+            e0 = torch.zeros((B, Lp, 6, self.dim), device=dev, dtype=torch.float32)
+            e[:, :seq_len_tok] = ef.view(B, seq_len_tok, self.dim)
+            e0[:, :seq_len_tok] = e0f.view(B, seq_len_tok, 6, self.dim)
+        else:
+            e, e0 = self._time_embed(t)
         cc = context if isinstance(context, ContextCache) else self.prepare_context(context, clip_fea)
         cos, sin = self._rope_tables(grid, dev)
         guid = None
@@ -732,6 +779,9 @@ class WanTransformer4DModel(nn.Module):
             Ls = Lp // self.sp_world_size
             pos_offset = self.sp_world_rank * Ls
             xres = xres[:, pos_offset:pos_offset + Ls].contiguous()
+            if t.dim() != 1:                      # :1190-1192: the per-token tables are chunked like the tokens
+                e = e[:, pos_offset:pos_offset + Ls].contiguous()
+                e0 = e0[:, pos_offset:pos_offset + Ls].contiguous()
             c = _Ctx(B, L, Ls, grid, cos, sin, max(0, min(Ls, L - pos_offset)), self._f32cache, key_len, sp, pos_offset)
         else:
             c = _Ctx(B, L, Lp, grid, cos, sin, L, self._f32cache, key_len)

@@ -43,10 +43,17 @@ def denoise_latents(transformer, scheduler, latents, timesteps, guidance_scale, 
     # two velocities are exchanged once per step; x stays replicated and identical on every rank
     from ..dist import cfg_exchange, get_cfg_parallel_rank
     branch = get_cfg_parallel_rank() if do_cfg else None
+    skip_ratio = None
     if branch is not None:
-        if transformer.teacache is not None or getattr(transformer, "cfg_skip_ratio", None):
-            raise NotImplementedError("TeaCache / cfg-skip together with CFG-parallel ranks")
         rep = 1
+        # TeaCache under CFG-parallel ranks needs no communication: its compute / skip decision is a function of the timestep
+        # embedding e0 alone (cache_utils.py:19-74, hooks wan_transformer4d.py:1201-1270) — identical on every rank — and each
+        # rank caches the residual of its own branch (every call is a `cond_flag=True` call of that rank's TeaCache).
+        # cfg-skip (cfg_optimization.py:5-37: the last cfg_skip_ratio of the schedule runs the conditional branch only and uses its
+        # output for both) becomes: the unconditional ranks sit those steps out.  The model's own decorator slices a CFG BATCH, which
+        # does not exist on a CFG-parallel rank, so it is switched off for the duration of the loop.
+        skip_ratio = getattr(transformer, "cfg_skip_ratio", None)
+        transformer.cfg_skip_ratio = None
 
     def dup(t):
         if t is None:
@@ -69,20 +76,33 @@ def denoise_latents(transformer, scheduler, latents, timesteps, guidance_scale, 
     ffeat = None
     if first_frame_features is not None:
         ffeat = tuple(torch.cat([u] * rep) for u in first_frame_features)
-    for i, t in enumerate(timesteps):
-        transformer.current_steps = i
-        xin = torch.cat([x] * rep) if rep > 1 else x
-        tt = t.to(dev).expand(xin.shape[0])
-        v = transformer(x=xin.to(T) if T != torch.float32 else xin, t=tt, context=cc, seq_len=seq_len, y=y2,
-                        full_ref=ref2, first_frame_features=ffeat)
+    try:
+        for i, t in enumerate(timesteps):
+            transformer.current_steps = i
+            xin = torch.cat([x] * rep) if rep > 1 else x
+            tt = t.to(dev).expand(xin.shape[0])
+            skip = skip_ratio is not None and i >= len(timesteps) * (1 - skip_ratio)
+            if skip and branch == 0:      # unconditional rank in a cfg-skip step: no forward, its slot of the exchange is ignored
+                v = torch.zeros(x.shape, device=dev, dtype=T)
+            else:
+                v = transformer(x=xin.to(T) if T != torch.float32 else xin, t=tt, context=cc, seq_len=seq_len, y=y2,
+                                full_ref=ref2, first_frame_features=ffeat)
+            if branch is not None:
+                v = cfg_exchange(v)
+                if skip:
+                    v = torch.cat([v[B:], v[B:]])
+            if do_cfg:
+                scheduler.step_cfg_(x, v.contiguous(), guidance_scale, i, round_dtype=T)
+            else:
+                scheduler.step_cfg_(x, torch.cat([v, v]).contiguous(), 1.0, i, round_dtype=T)
+            if callback is not None:
+                callback(i, t, x)
+    finally:
         if branch is not None:
-            v = cfg_exchange(v)
-        if do_cfg:
-            scheduler.step_cfg_(x, v.contiguous(), guidance_scale, i, round_dtype=T)
-        else:
-            scheduler.step_cfg_(x, torch.cat([v, v]).contiguous(), 1.0, i, round_dtype=T)
-        if callback is not None:
-            callback(i, t, x)
+            transformer.cfg_skip_ratio = skip_ratio
+            tc = transformer.teacache
+            if tc is not None and tc.cnt != 0:      # a rank that sat out steps never reached num_steps: start the next sample clean
+                tc.reset()
     return x
 
 
@@ -156,9 +176,18 @@ class WanFunControlPipeline:
     def _preprocess(video, height, width):
         """`self.image_processor.preprocess(...)` of the reference (:637-639, :681-683, :704-706) for float tensors: diffusers'
         VaeImageProcessor (third-party, restated — parity unpinned) resizes to (height, width) and maps [0, 1] -> [-1, 1]; a
-        tensor that already holds negative values is taken to be normalised and passed through."""
-        if tuple(video.shape[-2:]) != (height, width):
-            raise NotImplementedError(f"control / reference frames must already be {height}x{width} (got {tuple(video.shape[-2:])})")
+        tensor that already holds negative values is taken to be normalised and passed through.
+        Resize, as published: the target is rounded DOWN to a multiple of the VAE's spatial factor (`get_default_height_width`)
+        and tensors go through `torch.nn.functional.interpolate(image, size=(h, w))` with its default mode, i.e. legacy NEAREST
+        (source index = floor(dst * in / out)) — a pure row / column gather, done on whatever device the frames live on."""
+        height, width = height - height % 8, width - width % 8
+        hin, win = video.shape[-2:]
+        if (hin, win) != (height, width):
+            dev = video.device
+            # F.interpolate's legacy nearest computes floor(dst * scale) with scale = in / out in float32
+            ih = (torch.arange(height, device=dev, dtype=torch.float32) * (hin / height)).floor().long().clamp_(max=hin - 1)
+            iw = (torch.arange(width, device=dev, dtype=torch.float32) * (win / width)).floor().long().clamp_(max=win - 1)
+            video = video.index_select(-2, ih).index_select(-1, iw)
         video = video.float()
         return video if float(video.min()) < 0 else video * 2.0 - 1.0
 

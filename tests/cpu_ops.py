@@ -105,7 +105,10 @@ def rmsnorm_rope(x0, w0, x1=None, w1=None, *, head_dim, eps=1e-6, cos=None, sin=
         rows = x.numel() // C
         rps = rows_per_sample or rows
         xf = x.reshape(rows, C).float()
-        y = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype).float() * w
+        if w is None:      # RoPE only (qk_norm=False)
+            y = xf.clone()
+        else:
+            y = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype).float() * w
         if cos is not None:
             y = y.view(rows // rps, rps, C // head_dim, head_dim // 2, 2)
             n = min(rope_len, rps)
@@ -214,7 +217,8 @@ def unary(x, out_dtype, act=0, out=None):
 
 
 def add_bcast(a, bias):
-    return a + bias.reshape(a.shape[1:])
+    n = bias.numel()      # like the kernel: `bias` broadcast over every leading group of bias.numel() elements
+    return (a.reshape(-1, n) + bias.reshape(1, n)).reshape(a.shape)
 
 
 # ------------------------------------------------------------------ VAE ops (channels-last)

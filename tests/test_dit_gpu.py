@@ -85,8 +85,13 @@ def test_tiny_dit_bf16_budget():
         out = m(x=z["x"].to(DEV, torch.bfloat16), t=z["t"].to(DEV), context=ctx, seq_len=int(z["seq_len_pad"]),
                 clip_fea=z["clip"].to(DEV), y=z["y"].to(DEV, torch.bfloat16), full_ref=z["full_ref"].to(DEV, torch.bfloat16))
     assert out.dtype == torch.bfloat16
-    assert rms_rel_err(out.float().cpu(), z["out_ref"]) < 2e-2
-    assert rel_err(out.float().cpu(), z["out_ref"]) < 6e-2
+    # budget: the reference's own bf16-autocast run of this call sits 4.3e-3 rms / 4.2e-3 max from its fp32 run
+    # (bf16_calibration.json); ours additionally rounds the OUTPUT to bf16 (2^-9 relative per element)
+    from util import bf16_budget
+    e_rms, e_max = rms_rel_err(out.float().cpu(), z["out_ref"]), rel_err(out.float().cpu(), z["out_ref"])
+    print("tiny dit bf16", e_rms, e_max)
+    assert e_rms <= bf16_budget("dit_tiny", "rms") + 2e-3
+    assert e_max <= bf16_budget("dit_tiny", "max", factor=2.0) + 4e-3
 
 
 def test_loop_50_steps_fp32():

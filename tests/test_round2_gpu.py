@@ -13,7 +13,7 @@ import os
 import pytest
 import torch
 
-from util import load_keys, load_npz, rel_err, rms_rel_err
+from util import bf16_budget, load_keys, load_npz, rel_err, rms_rel_err
 from weights import block_shapes, fill, randn_named
 
 pytestmark = pytest.mark.gpu
@@ -91,12 +91,15 @@ def test_block_14b_width_long_sequence_vs_reference(dtype):
         assert rel_err(out[rows], z["out_rows"]) < 1e-3
         assert rel_err(out.norm(dim=-1), z["row_norm"]) < 1e-3
     else:
+        # budgets: 1.5 x the error of the reference's OWN bf16-autocast run of this block against its fp32 run (bf16_calibration.json)
         delta = out - x[0]
         scale = float(z["delta_rows"].abs().max())
-        assert float((delta[rows] - z["delta_rows"]).abs().max()) / scale < 4e-2
-        assert rms_rel_err(delta[rows], z["delta_rows"]) < 1e-2
-        assert rel_err(delta.norm(dim=-1), z["delta_norm"]) < 1e-2       # every row's update, not just the sampled ones
-        assert rms_rel_err(out[rows], z["out_rows"]) < 3e-3
+        got = dict(delta_max=float((delta[rows] - z["delta_rows"]).abs().max()) / scale, delta_rms=rms_rel_err(delta[rows], z["delta_rows"]),
+                   delta_norm=rel_err(delta.norm(dim=-1), z["delta_norm"]),       # every row's update, not just the sampled ones
+                   out_rms=rms_rel_err(out[rows], z["out_rows"]))
+        print("block_14b_long bf16", got)
+        for k_, v_ in got.items():
+            assert v_ <= bf16_budget("block_14b_long", k_), (k_, v_, bf16_budget("block_14b_long", k_))
 
 
 def test_full_model_forward_configs1():

@@ -4,7 +4,7 @@ which kernels a case ran."""
 import pytest
 import torch
 
-from util import load_keys, load_npz, rel_err, rms_rel_err
+from util import bf16_budget, load_keys, load_npz, rel_err, rms_rel_err
 from weights import fill
 
 pytestmark = pytest.mark.gpu
@@ -23,14 +23,14 @@ def _chain_modules(dtype):
     return vae.to(DEV, dtype), ea.to(DEV, dtype), da.to(DEV, dtype)
 
 
-def _check(name, got, samples, norms, tol_max, tol_rms, report):
-    """got [1, C, T, H, W] against the reference's every-11th element and per-(channel, frame) L2 norms"""
+def _check(name, got, samples, norms, tol, report):
+    """got [1, C, T, H, W] against the reference's every-11th element and per-(channel, frame) L2 norms; tol = (max, rms, norm)"""
     g = got.float().cpu()
     e_max = rel_err(g.reshape(-1)[::11], samples)
     e_rms = rms_rel_err(g.reshape(-1)[::11], samples)
     e_nrm = rel_err(g[0].flatten(2).norm(dim=-1), norms)
     report[name] = (e_max, e_rms, e_nrm)
-    assert e_max < tol_max and e_rms < tol_rms and e_nrm < tol_rms, (name, e_max, e_rms, e_nrm)
+    assert e_max <= tol[0] and e_rms <= tol[1] and e_nrm <= tol[2], (name, (e_max, e_rms, e_nrm), tol)
 
 
 @pytest.mark.parametrize("size", ["120x208", "96x128"])
@@ -49,24 +49,33 @@ def test_vae_chain_vs_reference_production_tiles(size, dtype):
     traj = torch.rand(1, 3, T, H, W, generator=torch.Generator().manual_seed(int(z["seed"])))
     vae, ea, da = _chain_modules(dtype)
     fp32 = dtype == torch.float32
-    tmax, trms = (1e-3, 1e-3) if fp32 else (8e-2, 2.5e-2)      # first run: <= 3.7e-2 max, <= 1.7e-2 rms per stage in bf16, <= 1e-5 in fp32
+
+    def tol(stage):
+        """fp32: north_star's 1e-3.  bf16: 1.5 x what the REFERENCE'S OWN bf16-autocast run of this stage loses against its fp32 run
+        on the same stored inputs (bf16_calibration.json; 2 x for the max-type metrics, which are extreme values of ~1e6 samples
+        and move by tens of percent between two equally good bf16 implementations)."""
+        if fp32:
+            return (1e-3, 1e-3, 1e-3)
+        key = f"vae_probe_{size}"
+        nrm = bf16_budget(key, stage, "nrm", factor=2.0) if stage != "encode" else 0.0
+        return (bf16_budget(key, stage, "max", factor=2.0), bf16_budget(key, stage, "rms"), max(nrm, 2e-3))
     rep = {}
     ops.launch_counts(reset=True)
     with torch.no_grad():
         pseudo = ea(traj.to(DEV, dtype)) * 2 - 1
-        _check("enc-adaptor", pseudo, z["pseudo_s"], z["pseudo_n"], tmax, trms, rep)
+        _check("enc-adaptor", pseudo, z["pseudo_s"], z["pseudo_n"], tol("enc-adaptor"), rep)
         enc = vae._encode(z["pv16"].float().to(DEV, dtype))
         e_enc = (rel_err(enc.float().cpu(), z["enc"]), rms_rel_err(enc.float().cpu(), z["enc"]))
         rep["encode"] = e_enc
-        assert e_enc[0] < tmax and e_enc[1] < trms, e_enc
+        assert e_enc[0] <= tol("encode")[0] and e_enc[1] <= tol("encode")[1], (e_enc, tol("encode"))
         dec = vae.decode(z["enc"][:, :16].half().float().to(DEV, dtype)).sample
-        _check("decode", dec, z["dec_s"], z["dec_n"], tmax, 3e-2 if not fp32 else trms, rep)
+        _check("decode", dec, z["dec_s"], z["dec_n"], tol("decode"), rep)
         rec = da(z["dec16"].float().to(DEV, dtype))
-        _check("dec-adaptor", rec, z["rec_s"], z["rec_n"], tmax, trms, rep)
+        _check("dec-adaptor", rec, z["rec_s"], z["rec_n"], tol("dec-adaptor"), rep)
         counts = ops.launch_counts()
         # end to end on our own hand-offs (the reference's hand-offs were rounded to fp16: noise of 5e-4 per stage on its side)
         chain = da(vae.decode(vae._encode(pseudo)[:, :16].contiguous()).sample)
-        _check("chain", chain, z["rec_s"], z["rec_n"], 5e-3 if fp32 else 1e-1, 3e-3 if fp32 else 6e-2, rep)
+        _check("chain", chain, z["rec_s"], z["rec_n"], (5e-3, 3e-3, 3e-3) if fp32 else tol("chain"), rep)
     print(size, dtype, {k: tuple(f"{x:.2e}" for x in v) for k, v in rep.items()}, {k: v for k, v in counts.items() if v})
     if fp32:
         assert counts["conv_generic"] > 0 and counts["conv_halo"] + counts["conv_halo_mt3_12x32"] + counts["conv_halo_mt3_24x16"] == 0

@@ -18,6 +18,23 @@ def load_keys(name):
         return {k: tuple(v) for k, v in json.load(fh).items()}
 
 
+_CALIB = None
+
+
+def bf16_budget(*path, factor=1.5):
+    """Budget of a bf16 GPU test = `factor` x the error of the REFERENCE'S OWN bf16-autocast run against its fp32 run in the same
+    metric (tests/golden/bf16_calibration.json, made by tests/golden/make_golden_r4.py by running the reference under
+    torch.autocast("cpu", bfloat16)).  path: keys into that file, e.g. ("vae_probe_120x208", "decode", "rms")."""
+    global _CALIB
+    if _CALIB is None:
+        with open(os.path.join(GOLDEN, "bf16_calibration.json")) as fh:
+            _CALIB = json.load(fh)
+    v = _CALIB
+    for k in path:
+        v = v[k]
+    return factor * float(v)
+
+
 def rel_err(a, b):
     """max |a-b| / max |b|  (the '1e-3 relative fp32' metric of BASELINE.json)."""
     a = a.double()
