@@ -304,27 +304,63 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def launch_check(world, rank, local_rank):
+def launch_check(world, rank, local_rank, parallelism="auto"):
     """Bring the ranks up exactly as a measurement would (RCCL when GPUs are present, gloo otherwise), count them with an
-    all-reduce and print one JSON line on rank 0.  Runs in the GPU-less CPU suite at world 2."""
+    all-reduce, then build the process groups of BOTH layouts a measurement may use — the one --parallelism selects first, the
+    other one the way the second pass of a measurement re-initialises it — and push one K-shaped all-gather, the head all-gather
+    and (cfg-sp) one velocity exchange through each, checked against what every rank must receive; the stand-in group of the
+    exposed-collective pass is checked for shape compatibility with the real one.  One JSON line on rank 0.  Runs in the
+    GPU-less CPU suite at world 2 and 8."""
     import torch.distributed as dist
     gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    layouts = {}
     if world > 1:
         if gpu:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-        ones = torch.ones(1, device=torch.device("cuda", local_rank) if gpu else "cpu")
+        dev = torch.device("cuda", local_rank) if gpu else torch.device("cpu")
+        ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         n = int(ones.item())
+        from more4d_amd.dist import cfg_exchange, get_cfg_parallel_rank, init_sequence_parallel
+        first = parallelism == "cfg-sp" or (parallelism == "auto" and world % 2 == 0)
+        for cfgp in ([first, not first] if world % 2 == 0 else [False]):
+            name = "cfg-sp" if cfgp else "sp"
+            try:
+                sp = init_sequence_parallel(cfg_parallel=cfgp)
+                br = get_cfg_parallel_rank()
+                W = sp.world_size
+                k = torch.full((2, 8), float(rank), device=dev)                      # a K shard: every peer's rows must arrive
+                if W > 1:
+                    buf, work, _ = sp.gather_start(k)
+                    if work is not None:
+                        work.wait()
+                    base = rank - sp.rank                                            # first global rank of this group
+                    ok = all(float(buf[r].mean()) == base + r for r in range(W))
+                    ok = ok and tuple(sp.all_gather(k, dim=0).shape) == (2 * W, 8)
+                    sb, _, _ = standin_group(W).gather_start(k)                      # the stand-in pass must hand over the same shapes
+                    ok = ok and sb.shape == buf.shape
+                else:
+                    ok = True
+                if br is not None:
+                    v = cfg_exchange(torch.full((1, 4), float(br), device=dev))
+                    ok = ok and v.shape == (2, 4) and float(v[0].mean()) == 0.0 and float(v[1].mean()) == 1.0
+                layouts[name] = {"sp_world": W, "cfg_branch_of_rank0": br, "ok": bool(ok)}
+            except Exception as ex:
+                layouts[name] = {"ok": False, "error": repr(ex)[:300]}
+        okt = torch.tensor([1.0 if all(v["ok"] for v in layouts.values()) else 0.0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        layouts["all_ranks_ok"] = bool(okt.item() == 1.0)
         dist.barrier()
         dist.destroy_process_group()
     else:
         n = 1
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": n, "backend": "nccl(RCCL)" if gpu else "gloo"}))
-    return 0
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": n, "backend": "nccl(RCCL)" if gpu else "gloo",
+                          "layouts": layouts}))
+    return 0 if (world == 1 or layouts.get("all_ranks_ok")) else 4
 
 
 def train_mode(args, world, rank, local_rank, dev, rccl_ranks, overrides):
@@ -391,6 +427,8 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring up the N ranks (RCCL on GPUs, gloo without), all-reduce a one per rank, print the count")
+    ap.add_argument("--no-other-layout", action="store_true",
+                    help="N>1 even: skip the second pass that times the other layout (sp-N <-> cfg2 x sp(N/2)) for secondary.*_layout")
     ap.add_argument("--parallelism", choices=["auto", "sp", "cfg-sp"], default="auto",
                     help="N>1: 'sp' = all ranks shard the tokens of the CFG pair; 'cfg-sp' = the two CFG branches on the two "
                          "halves of the world, tokens sharded inside each half (auto: cfg-sp when N is even)")
@@ -406,7 +444,7 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if args.launch_check:
-        return launch_check(world, rank, local_rank)
+        return launch_check(world, rank, local_rank, args.parallelism)
     overrides = m4d_overrides()
     from more4d_amd import _lib
     if _lib.ABLATION_BUILD:
@@ -455,9 +493,11 @@ def main():
     dtype = torch.bfloat16
     model = build_model(cfg, dev, dtype)
     branch = None
-    if world > 1:
+
+    def set_layout(cfgp):
+        """(re)build the process groups of one layout: plain sp-N (every rank shards the tokens of the CFG pair: the layout
+        north_star names) or cfg2 x sp(N/2); returns this rank's CFG branch (None = CFG batched on every rank)"""
         from more4d_amd.dist import get_cfg_parallel_rank, init_sequence_parallel
-        cfgp = args.parallelism == "cfg-sp" or (args.parallelism == "auto" and world % 2 == 0)
         try:
             init_sequence_parallel(cfg_parallel=cfgp)
         except Exception as ex:     # sub-group creation failed identically on every rank: plain T-sharding over WORLD
@@ -465,7 +505,12 @@ def main():
                 print(f"[bench] cfg-parallel groups unavailable ({ex!r}); falling back to sp{world}", file=sys.stderr)
             init_sequence_parallel(cfg_parallel=False)
         model.enable_multi_gpus_inference()
-        branch = get_cfg_parallel_rank()
+        return get_cfg_parallel_rank()
+
+    cfgp = False
+    if world > 1:
+        cfgp = args.parallelism == "cfg-sp" or (args.parallelism == "auto" and world % 2 == 0)
+        branch = set_layout(cfgp)
 
     # synthetic 49x480x832 trajectory latents: [1,16,13,60,104] (+48 control channels, ref row, context)
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -550,6 +595,42 @@ def main():
         finally:
             model._sp, model.sp_world_rank, mdist.cfg_exchange = real_sp, real_rank, real_exchange
 
+    def layout_name(br):
+        return (f"sp{world} (token/T-sharded, RCCL all-gather K,V^T)" if br is None else
+                f"cfg2 x sp{world // 2} (CFG branches on the two halves; tokens T-sharded inside a half, RCCL "
+                "all-gather K,V^T; one velocity exchange per step)")
+
+    # N > 1, even: the OTHER layout in the same run, so that one SCALE pass answers both questions — the plain sp-N layout
+    # north_star names and the cfg2 x sp(N/2) layout this build prefers.  Same inputs, same steps, its own
+    # context cache; the headline `value` stays the layout chosen by --parallelism.
+    other = None
+    if world > 1 and world % 2 == 0 and not args.no_other_layout:
+        try:
+            br2 = set_layout(not cfgp)
+            with torch.no_grad():
+                cc2 = model.prepare_context(ctx, torch.cat([clip, clip])) if br2 is None else model.prepare_context([ctx[br2]], clip)
+
+                def run2(i0, n, x_):
+                    class _S:
+                        @staticmethod
+                        def step_cfg_(lat_, v, gs, i, round_dtype=torch.float32):
+                            return sch.step_cfg_(lat_, v, gs, i0 + i, round_dtype)
+                    return denoise_latents(model, _S, x_, ts[i0:i0 + n], 6.0, cc2, y=y, full_ref=full_ref, seq_len=Lv,
+                                           first_frame_features=ffeat)
+                x2 = run2(0, max(1, args.warmup), lat)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                x2 = run2(max(1, args.warmup), args.steps, x2)
+                dist.barrier()
+                torch.cuda.synchronize()
+                d2 = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+            dist.all_reduce(d2, op=dist.ReduceOp.MAX)
+            other = {"parallelism": layout_name(br2), "ms_per_step": float(d2) / args.steps * 1e3, "value": args.steps / float(d2),
+                     "unit": "denoise-steps/s", "finite": bool(torch.isfinite(x2).all()), "steps": args.steps}
+        except Exception as ex:
+            other = {"error": repr(ex)[:400]}
+
     if rank == 0:
         gemm_fl, attn_fl = flops_per_forward(cfg, L, 2)
         step_flops = gemm_fl + attn_fl
@@ -563,10 +644,7 @@ def main():
                                    f"{'' if args.no_ref else ' incl. 1560 ref-row tokens'}, CFG batch 2, "
                                    "guidance + Euler fused; random-init weights",
                        "layers": args.layers, "tokens": L, "cfg_batch": 2, "spatial_guidance": bool(args.guidance),
-                       "parallelism": "single GPU" if world == 1 else (
-                           f"sp{world} (token/T-sharded, RCCL all-gather K,V^T)" if branch is None else
-                           f"cfg2 x sp{world // 2} (CFG branches on the two halves; tokens T-sharded inside a half, RCCL "
-                           "all-gather K,V^T; one velocity exchange per step)")},
+                       "parallelism": "single GPU" if world == 1 else layout_name(branch)},
             "finite": ok, "valid": args.layers == 40 and ok and not overrides, "env_overrides": overrides,
             "rccl_ranks": rccl_ranks, "collectives": exposed,
             "step_tflop": step_flops / 1e12,
@@ -598,6 +676,8 @@ def main():
             }
         if world == 1 and not args.no_secondary and args.layers == 40:
             out["secondary"] = secondary_figures(model, cfg, dev)
+        if other is not None:
+            out.setdefault("secondary", {})["sp_layout" if cfgp else "cfg_sp_layout"] = other
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, L)

@@ -49,7 +49,9 @@ typedef enum {
     M4D_KC_CONV_FUSED_NORM = 9,    /* a conv launch that wrote the next layer's RMS_norm(+SiLU) from its epilogue */
     M4D_KC_CONV_FUSED_NORM_RESID = 10, /* ... of a residual block's conv2 (shortcut added, norm of the NEXT block / head) */
     M4D_KC_CONV_GNSTATS = 11,      /* a conv launch that emitted GroupNorm partial statistics from its epilogue */
-    M4D_KC_COUNT = 12
+    M4D_KC_ATTN_BWD128 = 12,       /* one pass of the production attention backward (attn_bwd128_kernel: dQ / dK / dV, bf16, head_dim 128) */
+    M4D_KC_ATTN_BWD_GENERIC = 13,  /* one pass of the generic two-pass backward (fp32 / other head dims) */
+    M4D_KC_COUNT = 14
 } m4d_kernel_class;
 /* launches of `kernel_class` since process start (or the last reset); reset != 0 clears that counter after reading it;
  * kernel_class < 0 with reset != 0 clears all counters and returns 0. */

@@ -358,6 +358,7 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         p.LX = p.LXs = a->Lq; p.LY = a->Lk; p.nx_tiles = (int)((a->Lq + 255) / 256); p.accumulate = a->accumulate_dq;
         if (launch_bwd128<BWD_DQ>(p, st, 1)) { m4d_set_error("attention_bwd: cannot configure the dq kernel"); return -3; }
         M4D_CHECK_LAUNCH("attention_bwd(dq128)");
+        m4d_count_launch(M4D_KC_ATTN_BWD128);
         // dK: X = (K, V), Y = (Q, dO, Q^T)
         p.xa = a->k; p.xa_bs = a->k_bs; p.xa_ls = a->k_ls; p.xb = a->v; p.xb_bs = a->v_bs; p.xb_ls = a->v_ls;
         p.ya = a->q; p.ya_bs = a->q_bs; p.ya_ls = a->q_ls; p.yb = a->d_o; p.yb_bs = a->do_bs; p.yb_ls = a->do_ls;
@@ -386,6 +387,7 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
             const int rc2 = pass == 0 ? launch_bwd128<BWD_DK>(p, st, nsplit) : launch_bwd128<BWD_DV>(p, st, nsplit);
             if (rc2) { m4d_set_error("attention_bwd: cannot configure the dk/dv kernel"); return -3; }
             M4D_CHECK_LAUNCH("attention_bwd(dkv128)");
+            m4d_count_launch(M4D_KC_ATTN_BWD128);
             if (nsplit > 1) {
                 WsArgs w{a->ws, p.out_a, p.oa_bs, p.oa_ls, a->Lk_rows, a->heads * 128, a->B, p.accumulate};
                 const int64_t n4 = ws_need / 4;
@@ -408,6 +410,7 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
     int rc = bf ? launch_bwd<bf16_t, false>(p, a->head_dim, st) : launch_bwd<float, false>(p, a->head_dim, st);
     if (rc) { m4d_set_error("attention_bwd: unsupported configuration"); return rc; }
     M4D_CHECK_LAUNCH("attention_bwd(dq)");
+    m4d_count_launch(M4D_KC_ATTN_BWD_GENERIC);
     // ---- pass KV: X = keys ----
     p.xa = a->k; p.xa_bs = a->k_bs; p.xa_ls = a->k_ls;
     p.xb = a->v; p.xb_bs = a->v_bs; p.xb_ls = a->v_ls;
@@ -421,5 +424,6 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
     rc = bf ? launch_bwd<bf16_t, true>(p, a->head_dim, st) : launch_bwd<float, true>(p, a->head_dim, st);
     if (rc) { m4d_set_error("attention_bwd: unsupported configuration"); return rc; }
     M4D_CHECK_LAUNCH("attention_bwd(dkv)");
+    m4d_count_launch(M4D_KC_ATTN_BWD_GENERIC);
     return 0;
 }

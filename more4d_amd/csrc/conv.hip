@@ -498,10 +498,12 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     // descriptor (just under 2 GiB), the DMA-gather implicit GEMM (1x1 shortcut convs, M4D_CONV_VARIANT=2) signed 31-bit element
     // arithmetic on 2-byte elements (1 GiB)
     const int64_t xlimit = halo_shape ? (1ll << 31) - (1ll << 20) : (1ll << 30);
-    if (v2_shape && xbytes >= xlimit && kt == 1 && pad_t == 0 && To == Tin) {
+    const int64_t frame_bytes = (int64_t)Hin * Win * x_pixel_stride * 2;
+    // (Tin > 1 and one frame below the limit: a single oversized frame must NOT re-enter this branch — it falls through to the
+    // register-staged kernel, which addresses 64 bits — ADVICE r3)
+    if (v2_shape && xbytes >= xlimit && kt == 1 && pad_t == 0 && To == Tin && Tin > 1 && frame_bytes < xlimit) {
         // 2-D convolution over many frames (the adaptors: 49 x 480 x 832 x 128): frames are independent, so launch groups of
         // frames whose input fits the target kernel's offsets (otherwise the group would fall through to the register-staged kernel)
-        const int64_t frame_bytes = (int64_t)Hin * Win * x_pixel_stride * 2;
         const int per = (int)std::max<int64_t>(1, (xlimit - 1) / frame_bytes);
         for (int f0 = 0; f0 < Tin; f0 += per) {
             const int nf = std::min(per, Tin - f0);

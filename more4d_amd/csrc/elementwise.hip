@@ -459,8 +459,14 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
     const bool rows_form = ln_rows && !g_ss && ((scale != nullptr) != (ln_w != nullptr)) && (ln_w || p.rows_per_sample % 4 == 0) &&
                            rows >= 4096 && C > 2048 && C <= 5120;
     if (rows_form) {
-        static int ncu = 0;
-        if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+        static int ncu_dev[64] = {0};       // per device: a process may drive several GPUs
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+        if (!ncu_dev[dev]) {
+            int v = 0;
+            ncu_dev[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        }
+        const int ncu = ncu_dev[dev];
         const size_t lds = (size_t)C * 8;
         const int per_cu = 3;          // 168 VGPRs: three waves per SIMD
         grid = dim3((unsigned)std::min<int64_t>((rows + 3) / 4, (int64_t)ncu * per_cu));

@@ -526,14 +526,22 @@ inline int tail_split(int64_t nwg, int64_t nk, int ncu) {
 }  // namespace
 
 // compute units of the current device (the tile-round arithmetic of the split-K tail); 256 on an MI355X
+// (a process may drive several GPUs — one per emulated rank or per stream owner: everything device-bound is kept per device)
+constexpr int M4D_MAX_DEVICES = 64;
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev >= 0 && dev < M4D_MAX_DEVICES ? dev : 0;
+}
 static int device_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
+    static int n[M4D_MAX_DEVICES] = {0};
+    const int dev = current_device();
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n[dev] = v;
+        else n[dev] = 256;
     }
-    return n;
+    return n[dev];
 }
 // production structure for big bf16 problems: 5 (default) = 4-wave 128 x 128-per-wave kernel (gemm_wide.h), 4 = phased two-group
 // kernel (gemm_phased.h); 1 two-stage, 2 ping-pong, 3 staggered rings (older A/B structures)
@@ -648,17 +656,20 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
             M4D_ENV_ONCE(psync, "M4D_GEMM_SYNC", 1);
             // (only from four rounds on: at the 1.7 rounds of a rank's M = 5 460 shard the poll costs 3 % and there is hardly a panel to share)
             if (pers_ok && psync && ncu_p % 8 == 0 && nwg >= 4 * (int64_t)ncu_p) {
-                static unsigned* g_sync = nullptr;
-                static bool tried = false;
-                if (!tried) {       // (never allocate inside a stream capture: the hint simply starts with the first launch outside one)
+                // one counter buffer PER DEVICE, allocated on the device that is current at its first qualifying launch (a
+                // process-wide buffer made launches on a second GPU poll and memset device-0 memory)
+                static unsigned* g_sync[M4D_MAX_DEVICES] = {nullptr};
+                static bool tried[M4D_MAX_DEVICES] = {false};
+                const int dev = current_device();
+                if (!tried[dev]) {       // (never allocate inside a stream capture: the hint simply starts with the first launch outside one)
                     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { cs = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
                     if (cs == hipStreamCaptureStatusNone) {
-                        tried = true;
-                        if (hipMalloc((void**)&g_sync, 1024) != hipSuccess) { g_sync = nullptr; (void)hipGetLastError(); }
+                        tried[dev] = true;
+                        if (hipMalloc((void**)&g_sync[dev], 1024) != hipSuccess) { g_sync[dev] = nullptr; (void)hipGetLastError(); }
                     }
                 }
-                if (g_sync && hipMemsetAsync(g_sync, 0, 1024, st) == hipSuccess) p.sync = g_sync;
+                if (g_sync[dev] && hipMemsetAsync(g_sync[dev], 0, 1024, st) == hipSuccess) p.sync = g_sync[dev];
             }
             const int rc = pers_ok ? (epilogue == M4D_EPI_STORE ? m4d_launch_gemm_wide_store_persistent(&p, (unsigned)nwg, (unsigned)ncu_p, st)
                                                                 : m4d_launch_gemm_wide_gelu_persistent(&p, (unsigned)nwg, (unsigned)ncu_p, st))

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
                                   // blockIdx class do not share an L2 after all) switches the polling off for the rest of the launch
         W_KLOOP(0)
         for (;;) {
-            if (ctr && t == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (agent scope: other workgroups read the counter; on gfx950 the same L2 atomic as the workgroup-scope form)
+            if (ctr && t == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // epilogue of this tile; the ring already holds K-tiles 0 and 1 of the next one, fa0 / fbx its first fragments.
             // The lane id is laundered through an empty asm so that hipcc recomputes the epilogue's per-lane addresses per tile
             // (a few dozen VALU instructions) instead of hoisting them out of the tile loop and spilling across the K loop.

@@ -109,6 +109,9 @@ class ShardedDataParallel:
             if p.grad is not None:
                 view.add_(p.grad.to(view.dtype))
             p.grad = view
+        if b.ready and self.world == 1:
+            # nothing was reduced at world 1: a second backward simply accumulates, like a plain model (and torch DDP at world 1)
+            b.ready, b.pending = False, len(b.params)
         if b.ready:
             # the bucket's reduce-scatter is already on the wire (or done): this rank's slice holds GLOBAL sums, a second
             # backward would add local gradients on top of them and never reduce those
@@ -135,7 +138,10 @@ class ShardedDataParallel:
     def no_sync(self):
         """Context manager for gradient accumulation (`accelerator.accumulate` / --gradient_accumulation_steps,
         train_wan.py:1916): backward() inside it only accumulates into the local buckets; the first backward outside it
-        issues the reduce-scatters.  Mirrors torch DDP's no_sync()."""
+        issues the reduce-scatters.  Mirrors torch DDP's no_sync() — which, like this one, SUMS the micro-batch gradients:
+        `accelerator.backward` divides the loss by gradient_accumulation_steps before it calls backward, so a port of the
+        reference loop either does the same (`(loss / steps).backward()`) or passes `accumulation_steps=steps` to
+        reduce_gradients() / step(), which folds 1 / steps into the norm and into the fused update scale."""
         dp = self
 
         class _NoSync:
@@ -160,27 +166,29 @@ class ShardedDataParallel:
                 b.work.wait()
                 b.work = None
 
-    def reduce_gradients(self):
+    def reduce_gradients(self, accumulation_steps=1):
         """Issue the reduce-scatter of every bucket backward did not complete (unused parameters keep zero gradients), wait for
         all of them (the current stream waits, not the host) and return the global L2 norm of the AVERAGED gradients as a 0-d
-        device tensor (`torch.norm(stack(norm(g)))` of train_wan.py:1991-1993 on what DDP would have left in .grad)."""
+        device tensor (`torch.norm(stack(norm(g)))` of train_wan.py:1991-1993 on what DDP would have left in .grad).
+        accumulation_steps: micro-batches summed under no_sync() whose losses were NOT pre-divided (see no_sync)."""
         self._wait_all()
         acc = torch.zeros((), device=self.device, dtype=torch.float32)
         for b in self.buckets:
             ops.sumsq(self._slice(b, b.flat_g), acc)
         if self.world > 1:
             dist.all_reduce(acc, group=self.group)
-        return acc.sqrt() / self.world
+        return acc.sqrt() / (self.world * accumulation_steps)
 
     # ------------------------------------------------------------------ optimizer side
     @torch.no_grad()
-    def step(self, max_norm=None, total_norm=None):
+    def step(self, max_norm=None, total_norm=None, accumulation_steps=1):
         """Clip (coefficient fused into the update: no pass over the gradients) + AdamW on this rank's slice of every bucket +
-        all-gather of the updated parameters.  `total_norm`: what reduce_gradients() returned (required with max_norm)."""
+        all-gather of the updated parameters.  `total_norm`: what reduce_gradients() returned (required with max_norm; pass the
+        same accumulation_steps to both)."""
         # "ready" only means the reduce-scatter was LAUNCHED (asynchronously, from the backward hooks): the update below reads
         # the gradient slice on the compute stream, so every outstanding collective is waited for here, unconditionally
         self._wait_all()
-        scale = torch.full((), 1.0 / self.world, device=self.device, dtype=torch.float32)       # sum -> mean
+        scale = torch.full((), 1.0 / (self.world * accumulation_steps), device=self.device, dtype=torch.float32)       # sum -> mean
         if max_norm is not None:
             if total_norm is None:
                 raise ValueError("step(max_norm=...) needs the total_norm returned by reduce_gradients()")

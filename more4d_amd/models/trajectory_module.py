@@ -185,16 +185,19 @@ class VAEEncoderadaptor(_AdaptorBase):
         self._setup()
 
     def _forward_one(self, x):
-        """x [3, F, H, W] -> sigmoid(net(x) + x)."""
+        """x [3, F, H, W] -> sigmoid(net(x) + x).  The skip and the sigmoid run in promote(x.dtype, T), like the reference's
+        `h + x` under autocast (trajectory_module.py:194-196: the conv stack computes in T, the fp32 coordinates join at full
+        precision and the result is fp32); a caller that hands in T-typed coordinates (whole-model cast, infer.py) gets T back."""
         C, F, H, W = x.shape
         T, dev = self.dtype, self.device
-        xb = x.to(device=dev, dtype=T).contiguous()
-        h = ops.ncthw_to_cl(xb, T, Cp=CIN_PAD).view(F * H * W, CIN_PAD)
+        odt = torch.promote_types(x.dtype, T) if x.dtype.is_floating_point else T
+        xs = x.to(device=dev, dtype=odt).contiguous()
+        h = ops.ncthw_to_cl(xs, T, Cp=CIN_PAD).view(F * H * W, CIN_PAD)
         h, st = self._conv_first(h, self.conv_in, F, H, W)
         for blk in self.down[0].block:
             h, st = self._resnet(h, blk, F, H, W, st)
         h, cop, _ = self._norm_conv(h, self.norm_out, self.conv_out, F, H, W, self.ch, stats_in=st)
-        return ops.cl_to_ncthw(h, T, C=C, T=F, H=H, W=W, pixel_stride=cop, act=2, aux=xb)
+        return ops.cl_to_ncthw(h, odt, C=C, T=F, H=H, W=W, pixel_stride=cop, act=2, aux=xs)
 
     def forward(self, x):
         """x [B, 3, F, H, W] -> sigmoid(net(x) + x), same shape (reference :177-196)."""

@@ -68,6 +68,8 @@ def build_rope_tables(freqs, grid, head_dim, device):
 
 
 _XATTN_FUSED = os.environ.get("M4D_XATTN_FUSED", "1") != "0"      # A/B switch: 0 = text and image branches as two launches
+# fused q+k projection of the self-attention (one N = 2C GEMM launch); M4D_FUSE_QK=0 = two launches (A/B)
+_FUSE_QK = os.environ.get("M4D_FUSE_QK", "1") != "0"
 
 
 def _f32(p, cache):
@@ -123,6 +125,18 @@ class WanSelfAttention(nn.Module):
     def _ones(self, ref):
         return torch.ones(self.dim, device=ref.device, dtype=torch.float32)
 
+    def _qk_weights(self):
+        """[Wq; Wk] [2C, C] and [bq; bk] for the fused q+k projection, rebuilt when either parameter changes (version / storage)."""
+        key = (self.q.weight._version, self.q.weight.data_ptr(), self.k.weight._version, self.k.weight.data_ptr(),
+               self.q.bias._version, self.k.bias._version, self.q.weight.dtype)
+        hit = self.__dict__.get("_qk_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, torch.cat([self.q.weight.detach(), self.k.weight.detach()]).contiguous(),
+                       torch.cat([self.q.bias.detach(), self.k.bias.detach()]).contiguous())
+            self.__dict__["_qk_cache"] = hit
+        return hit[1], hit[2]
+
     def run(self, xn, xres, gate, gate_stride, c: _Ctx, gate_rows=None):
         """xn: T [B, Lp, C] modulated input; accumulates o-proj * gate into xres (float32) in place.  gate_rows: rows that share
         one gate vector (default: a sample's Lp rows; 1 = per-token gates)."""
@@ -134,12 +148,22 @@ class WanSelfAttention(nn.Module):
             wq = wk = None
         rope = dict(head_dim=d, eps=self.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
                     pos_offset=c.pos_offset)
+        q_ls = C                         # row stride of q (2C when q and k share one [rows, 2C] projection buffer)
         if c.sp is None or c.sp.world_size == 1:
-            q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
-            k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
+            if _FUSE_QK:
+                # ONE projection launch for q and k (N = 2C = 10 240: twice the tiles per launch for the persistent GEMM, one
+                # partial tile round and one launch less per layer); q / k are the two column halves of the [rows, 2C] result —
+                # the norm+rope kernel and the attention kernel take row strides
+                wqk, bqk = self._qk_weights()
+                qk = ops.gemm_bt(xn, wqk, bqk).view(B * Lp, 2 * C)
+                q, k = qk[:, :C], qk[:, C:]
+                q_ls = 2 * C
+            else:
+                q = ops.gemm_bt(xn, self.q.weight, self.q.bias)
+                k = ops.gemm_bt(xn, self.k.weight, self.k.bias)
             vt = ops.gemm_bt(self.v.weight, xn, self.v.bias, bias_on_m=True)          # V^T [C, B*Lp]
             ops.rmsnorm_rope(q, wq, k, wk, **rope)
-            segs = [KV(k, vt, Lp * C, C, Lp, B * Lp, c.key_len)]
+            segs = [KV(k, vt, Lp * q_ls, q_ls, Lp, B * Lp, c.key_len)]
         elif c.sp.mode == "ulysses":
             o = self._ulysses(xn, wq, wk, rope, c)
             segs = None
@@ -173,7 +197,7 @@ class WanSelfAttention(nn.Module):
             else:
                 segs = c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)
         if segs is not None:
-            o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
+            o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * q_ls, q_ls=q_ls)
         ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=gate,
                     gate_stride=gate_stride, rows_per_sample=gate_rows or Lp)
         return xres

