@@ -410,6 +410,37 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
 //   * ONE workgroup barrier per tile (stage hand-over); the tile request is 8 x (s_mov m0 + global_load_lds) with scalar bases and
 //     per-lane 32-bit offsets computed once (no 64-bit VALU address arithmetic in the loop).
 // 128 key rows per workgroup (4 pairs x 32), 64-query Y tiles of (Q, dO, Q^T, dO^T) in two 64.5 KiB stages.
+// ---- transposed operands without transposed copies: ds_read_b64_tr_b16 (round 4) ----
+// The accumulate products need the Y tile transposed (dV^T += dO^T P^T, dK^T += Q^T dS^T, dQ^T += K^T dS^T): A fragment = 32 d rows x 16 y,
+// lane (i = d, hi) holding 8 y values of column d of the row-major tile.  gfx950's transposing LDS read does exactly that gather.
+// Semantics (probed, tools/probes/ds_read_tr.hip): within each group of 16 lanes, lane s supplies the address of one 8-byte piece =
+// row (s >> 2), column quad (s & 3) of a [4 rows][16 columns] block of 16-bit elements, and lane t receives column t of the block
+// (4 elements, rows 0..3).  The four rows of a block may be any four rows (each lane has its own address); here they are rows
+// y0, y0 + 4, y0 + 8, y0 + 12 of a 16-row chunk, because with the tile's XOR swizzle (16-byte chunk ^ (row & 15), applied on the DMA source
+// address) rows that differ in bits 2..3 and agree in bits 0..1 put their four chunks on 16 different bank slots: the 32 lanes serviced
+// per LDS cycle cover all 64 banks exactly once.  Two reads (jj = 0, 1) fill one fragment, so fragment slot (hi, e) of chunk c is
+//     y = 16 c + 2 hi + (e >> 2) + 4 (e & 3)
+// — and the S / G accumulators must deliver P / dS in that order: the row-major fragment reads take tile row bwd_tr_row(i) for MFMA row i
+// (C layout: register r of lane-half hi is row (r & 3) + 8 (r >> 2) + 4 hi), which makes registers 8 c' + e of a 32-row half exactly
+// slot e of chunk c'.  Conflict-free for ds_read_b128 as well: the 16 lanes of a service group read rows that are distinct mod 16.
+M4D_DEV int bwd_tr_row(int i) { return (i & 16) | ((i & 3) << 2) | ((i >> 1) & 2) | ((i >> 3) & 1); }
+// byte offset (inside a row-major [64][128] bf16 tile, chunk c = 0) of the piece lane (li, hi) supplies for read jj of d-block dd
+M4D_DEV unsigned bwd_tr_addr(int li, int hi, int jj, int dd) {
+    const int g = li >> 4, s = li & 15;
+    const int row = 2 * hi + jj + 4 * (s >> 2);
+    const int chunk = (4 * dd + 2 * g + ((s >> 1) & 1)) ^ row;
+    return (unsigned)(row * 256 + chunk * 16 + (s & 1) * 8);
+}
+// statistics (lse / delta of a tile's 64 y) sit in LDS in accumulator-register order: position 32 half + 16 c + 8 hi + e holds y =
+M4D_DEV int bwd_tr_stat(int pos) { return (pos & 48) | (((pos >> 3) & 1) << 1) | ((pos >> 2) & 1) | ((pos & 3) << 2); }
+template <int OFF> M4D_DEV void bwd_tr_read(bf16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+M4D_DEV bf16x8 bwd_tr_join(const bf16x4& lo, const bf16x4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+#ifndef BKV_NST
+#define BKV_NST 4      // Y-tile stages of the fused dK / dV pass (tile i + NST - 1 is requested while tile i is computed)
+#endif
 #ifndef BKV_ABL
 #define BKV_ABL 0      // side builds (tools/side_lib.sh): 1 no elementwise arithmetic, 2 no S / G MFMAs, 4 no accumulate MFMAs, 8 no mailbox /
 #endif                 // flags, 16 no tile DMA, 32 no fragment reads — timing only, results wrong
@@ -425,8 +456,8 @@ template <int N> M4D_DEV void bkv_lgkm() {
 __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
     typedef bf16_t T;
     constexpr int D = 128, YB = 64, XB = 128;
-    constexpr int TQ = 0, TDO = 16384, TQT = 32768, TDOT = 49152, STAT_OFF = 65536, STAGE = STAT_OFF + 512, MAIL = 2 * STAGE, FLAGS = MAIL + 16384;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE + 4 pairs x 4 KiB mailbox + flags
+    constexpr int TQ = 0, TDO = 16384, STAT_OFF = 32768, STAGE = STAT_OFF + 512, NST = BKV_NST, MAIL = NST * STAGE, FLAGS = MAIL + 16384;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST * STAGE + 4 pairs x 4 KiB mailbox + flags
 
     const int HB = p.heads * p.B;
     int xt, hb;
@@ -467,15 +498,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
 
     // per-lane fragment addresses in the CURRENT stage, the role's tiles folded in: row-major tile = Q (P-wave) / dO (dS-wave),
     // transposed tile = dO^T (P-wave) / Q^T (dS-wave)
-    unsigned ka[8], va[4];
+    // The transposed operand of the accumulate product (dO^T for dV, Q^T for dK) is read out of the SAME row-major tile with
+    // ds_read_b64_tr_b16 (bwd_tr_row / bwd_tr_addr above): no transposed copies in HBM, half the tile bytes through the DMA path.
+    unsigned ka[8], ta[2][4];
     const unsigned lds0 = (unsigned)(uintptr_t)(LDS_AS char*)smem;
     {
-        const unsigned rbase = lds0 + (ds_role ? TDO : TQ), tbase = lds0 + (ds_role ? TQT : TDOT);
-        const int kr = perm23(li);
+        const unsigned rbase = lds0 + (ds_role ? TDO : TQ), tbase = lds0 + (ds_role ? TQ : TDO);
+        const int kr = bwd_tr_row(li);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ka[kk] = rbase + kr * 256 + (((kk * 2 + hi) ^ (kr & 15)) << 4);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) va[c] = tbase + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) ta[jj][dd] = tbase + bwd_tr_addr(li, hi, jj, dd);
     }
     const unsigned mail = lds0 + MAIL + pair * 4096 + lane * 16;
     const unsigned flag = lds0 + FLAGS + pair * 8;           // two counters per pair: P of half 0 / half 1 posted up to tile n
@@ -486,23 +521,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
 
     // ---- tile request: scalar bases + per-lane 32-bit offsets (row-major tiles: 4 rows x 256 B per instruction; transposed: 8 rows x 128 B)
     const int k_r = lane >> 4, k_lc0 = lane & 15;
-    const int v_r = lane >> 3, v_pc = lane & 7;
     const T* gq = (const T*)p.ya + b * p.ya_bs + (int64_t)h * D;
     const T* gdo = (const T*)p.yb + b * p.yb_bs + (int64_t)h * D;
-    const T* gqt = (const T*)p.yat + b * p.yat_bs + (int64_t)h * D * p.yat_ls;
-    const T* gdot = (const T*)p.ybt + b * p.ybt_bs + (int64_t)h * D * p.ybt_ls;
     const float* glse = p.lse + ((int64_t)b * p.heads + h) * p.Lq;
     const float* gdel = p.delta + ((int64_t)b * p.heads + h) * p.Lq;
-    unsigned oq[2], odo[2], oqt[2], odot[2];
+    unsigned oq[2], odo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int blk = wave * 2 + i;
-        const int row = blk * 4 + k_r, trow = blk * 8 + v_r;
+        const int row = blk * 4 + k_r;
         oq[i] = (unsigned)((row * p.ya_ls + (k_lc0 ^ (row & 15)) * 8) * 2);
         odo[i] = (unsigned)((row * p.yb_ls + (k_lc0 ^ (row & 15)) * 8) * 2);
-        oqt[i] = (unsigned)((trow * p.yat_ls + (v_pc ^ ((trow >> 1) & 7)) * 8) * 2);
-        odot[i] = (unsigned)((trow * p.ybt_ls + (v_pc ^ ((trow >> 1) & 7)) * 8) * 2);
     }
+    const unsigned ostat = (unsigned)bwd_tr_stat(lane) * 4u;      // LDS position `lane` of a tile's statistics holds query bwd_tr_stat(lane)
     auto uniform_ptr = [](const char* q) {
         const unsigned long long v = (unsigned long long)q;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -511,33 +542,28 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
 #define BKV_GLDS(DST, VOFF, SRC) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(DST), "v"(VOFF), "s"(SRC) : "memory", "m0")
     // the tile request in two parts so that the loop can spread its instructions over the first MFMAs of a tile (issued back to back
     // at the top of the tile, the 8 waves' 68 requests queue on the CU's one texture-address unit with every wave stuck behind its own)
-    const char *dq_b = nullptr, *ddo_b = nullptr, *dqt_b = nullptr, *ddot_b = nullptr, *dst_b = nullptr;
+    const char *dq_b = nullptr, *ddo_b = nullptr, *dst_b = nullptr;
     unsigned d_dst = 0, d_sdst = 0;
     auto dma_prepare = [&](int stage, int64_t y0) {
         dq_b = uniform_ptr((const char*)(gq + y0 * p.ya_ls));
         ddo_b = uniform_ptr((const char*)(gdo + y0 * p.yb_ls));
-        dqt_b = uniform_ptr((const char*)(gqt + y0));
-        ddot_b = uniform_ptr((const char*)(gdot + y0));
         dst_b = uniform_ptr((const char*)((wave & 1 ? gdel : glse) + y0));
         d_dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 2048);
         d_sdst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + STAT_OFF + (wave & 1) * 256);
     };
-    auto dma_one = [&](int n) {          // n = 0..8, a literal at every call site
+    auto dma_one = [&](int n) {          // n = 0..4, a literal at every call site: FIVE instructions per wave and tile (the counted waits rely on it)
         if constexpr (BKV_ABL & 16) return;
         if (n == 0) BKV_GLDS(d_dst + TQ, oq[0], dq_b);
         else if (n == 1) BKV_GLDS(d_dst + TDO, odo[0], ddo_b);
-        else if (n == 2) BKV_GLDS(d_dst + TQT, oqt[0], dqt_b);
-        else if (n == 3) BKV_GLDS(d_dst + TDOT, odot[0], ddot_b);
-        else if (n == 4) BKV_GLDS(d_dst + TQ + 1024, oq[1], dq_b);
-        else if (n == 5) BKV_GLDS(d_dst + TDO + 1024, odo[1], ddo_b);
-        else if (n == 6) BKV_GLDS(d_dst + TQT + 1024, oqt[1], dqt_b);
-        else if (n == 7) BKV_GLDS(d_dst + TDOT + 1024, odot[1], ddot_b);
-        else if (wave < 2)      // the tile's statistics travel the same way (waves 0 / 1: lse / delta of the 64 queries, 4 bytes per lane)
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(d_sdst), "v"(lane * 4), "s"(dst_b) : "memory", "m0");
+        else if (n == 2) BKV_GLDS(d_dst + TQ + 1024, oq[1], dq_b);
+        else if (n == 3) BKV_GLDS(d_dst + TDO + 1024, odo[1], ddo_b);
+        else      // the tile's statistics travel the same way (even waves: lse, odd waves: delta of the 64 queries, 4 bytes per lane, in the
+                  // register order of the S / G accumulators; waves 2..7 repeat the copy of waves 0 / 1 so that every wave counts the same)
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(d_sdst), "v"(ostat), "s"(dst_b) : "memory", "m0");
     };
     auto dma_tile = [&](int stage, int64_t y0) {
         dma_prepare(stage, y0);
-        dma_one(0); dma_one(1); dma_one(2); dma_one(3); dma_one(4); dma_one(5); dma_one(6); dma_one(7); dma_one(8);
+        dma_one(0); dma_one(1); dma_one(2); dma_one(3); dma_one(4);
     };
     auto reg_tile = [&](int stage, int64_t y0) {      // ragged last tile: zero filled, synchronous
         char* base = smem + stage * STAGE;
@@ -553,27 +579,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
                 *reinterpret_cast<uint4*>(base + TDO + swz_off<256>(row, ch)) =
                     ok ? *reinterpret_cast<const uint4*>(gdo + y * p.yb_ls + ch * 8) : make_uint4(0, 0, 0, 0);
             }
-            {
-                const int row = c >> 3, ch = c & 7;
-                const int64_t y = y0 + ch * 8;
-#pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    const T* src = (which ? gdot + row * p.ybt_ls : gqt + row * p.yat_ls) + y;
-                    union { uint4 u; T e[8]; } tmp;
-                    tmp.u = make_uint4(0, 0, 0, 0);
-                    if (y + 8 <= p.LY) tmp.u = *reinterpret_cast<const uint4*>(src);
-                    else if (y < p.LY) {
-                        for (int j = 0; j < 8; ++j)
-                            if (y + j < p.LY) tmp.e[j] = src[j];
-                    }
-                    *reinterpret_cast<uint4*>(base + (which ? TDOT : TQT) + swz_off<128>(row, ch)) = tmp.u;
-                }
-            }
         }
     };
     auto reg_stat = [&](int stage, int64_t y0) {      // ragged last tile: threads 0..63 lse, 64..127 delta of row y0 + (t & 63)
         if (t >= 128) return;
-        const int64_t y = y0 + (t & 63);
+        const int64_t y = y0 + bwd_tr_stat(t & 63);
         float v = t < 64 ? INFINITY : 0.f;               // lse = +inf => probability exactly 0
         if (y < p.LY) v = t < 64 ? glse[y] : gdel[y];
         reinterpret_cast<float*>(smem + stage * STAGE + STAT_OFF)[t] = v;
@@ -592,21 +602,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
         }
     };
 
-    bool cur_dma = YB <= p.LY;
+    // NST stages: tile it + NST - 1 is requested while tile it is computed, so a request has NST - 2 whole tiles to land (round 4, first
+    // version: two stages and vmcnt(0) in front of every tile — the DMA round trip was exposed once per tile, 5 ms of a 25 ms pass in the
+    // timing ablations).  Full tiles travel by DMA (five instructions per wave and tile: the counted waits below); a ragged last tile is
+    // staged synchronously through registers.
+    const int NT = (int)((p.LY + YB - 1) / YB), NF = (int)(p.LY / YB);      // tiles, full (DMA) tiles
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (cur_dma) dma_tile(0, 0);
-    unsigned it = 0;
-    for (int64_t y0 = 0; y0 < p.LY; y0 += YB, ++it) {
-        const int stage = it & 1;
-        if (cur_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else { reg_tile(stage, y0); reg_stat(stage, y0); }
-        __syncthreads();                                                       // stage landed; the other stage and the mailbox are free
-        const int64_t ny0 = y0 + YB;
-        bool next_dma = false;
-        if (ny0 < p.LY) {
-            next_dma = ny0 + YB <= p.LY;
-            if (next_dma) dma_prepare(stage ^ 1, ny0);
-        }
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j)
+        if (j < NF) dma_tile(j, (int64_t)j * YB);
+    int stage = 0;
+    for (int it = 0; it < NT; ++it) {
+        const int64_t y0 = (int64_t)it * YB;
+        if (it < NF) {
+            const int younger = NF - 1 - it;          // requested tiles behind this one: min(younger, NST - 2) x 5 instructions may stay in flight
+            if (younger >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (NST - 2)) : "memory");
+            else if (younger == 1 && NST > 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else { reg_tile(stage, y0); reg_stat(stage, y0); }
+        __syncthreads();                                                       // stage landed; stage it - 1 and the mailbox are free
+        const bool next_dma = it + NST - 1 < NF;
+        if (next_dma) dma_prepare(stage == 0 ? NST - 1 : stage - 1, y0 + (int64_t)(NST - 1) * YB);
         const float* st = reinterpret_cast<const float*>(smem + stage * STAGE + STAT_OFF) + (ds_role ? 64 : 0);
         bf16x8 fb0, fb1, fb2, fb3;
         bf16x8 pf[4];
@@ -622,20 +638,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
         bkv_lgkm<3>(); BKV_MMA(fb1, 1, ACC); bkv_dsr<OFF>(fb1, ka[5]); BKV_DMA(1, ON);                                  \
         bkv_lgkm<3>(); BKV_MMA(fb2, 2, ACC); bkv_dsr<OFF>(fb2, ka[6]); BKV_DMA(2, ON);                                  \
         bkv_lgkm<3>(); BKV_MMA(fb3, 3, ACC); bkv_dsr<OFF>(fb3, ka[7]); BKV_DMA(3, ON);                                  \
-        bkv_lgkm<3>(); BKV_MMA(fb0, 4, ACC); BKV_DMA(4, ON); bkv_lgkm<2>(); BKV_MMA(fb1, 5, ACC); BKV_DMA(5, ON);       \
-        bkv_lgkm<1>(); BKV_MMA(fb2, 6, ACC); BKV_DMA(6, ON); bkv_lgkm<0>(); BKV_MMA(fb3, 7, ACC); BKV_DMA(7, ON);       \
-        if (ON) { if (next_dma) dma_one(8); }                                                                          \
+        bkv_lgkm<3>(); BKV_MMA(fb0, 4, ACC); BKV_DMA(4, ON); bkv_lgkm<2>(); BKV_MMA(fb1, 5, ACC);                       \
+        bkv_lgkm<1>(); BKV_MMA(fb2, 6, ACC); bkv_lgkm<0>(); BKV_MMA(fb3, 7, ACC);                                       \
     } while (0)
-        // acc^T += (transposed Y tile) . pf for the two 16-query chunks C0, C0 + 1 of one half (8 MFMAs, fragments four steps ahead)
-#define BKV_PV(Bf, C, DD, W) do { bkv_lgkm<W>(); if constexpr (!(BKV_ABL & 4)) mma32(Bf, pf[C], acc[DD]); } while (0)
+        // acc^T += (Y tile)^T . pf for the two 16-query chunks C0, C0 + 1 of one half: 8 MFMAs, each fragment = two transposing reads
+        // (bwd_tr_addr: read jj of d-block DD; the chunk is the immediate offset), four fragments = eight reads ahead
+        bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;
+#define BKV_TR(F, C, DD) do { if constexpr (!(BKV_ABL & 32)) { bwd_tr_read<(C) * 4096>(F##l, ta[0][DD]); bwd_tr_read<(C) * 4096>(F##h, ta[1][DD]); } } while (0)
+#define BKV_PV(F, C, DD, W) do { bkv_lgkm<W>(); if constexpr (!(BKV_ABL & 4)) mma32(bwd_tr_join(F##l, F##h), pf[C], acc[DD]); } while (0)
 #define BKV_ACC_HALF(C0)                                                                                               \
     do {                                                                                                               \
-        bkv_dsr<0>(fb0, va[C0]); bkv_dsr<4096>(fb1, va[C0]); bkv_dsr<8192>(fb2, va[C0]); bkv_dsr<12288>(fb3, va[C0]);   \
-        BKV_PV(fb0, C0, 0, 3); bkv_dsr<0>(fb0, va[C0 + 1]);                                                             \
-        BKV_PV(fb1, C0, 1, 3); bkv_dsr<4096>(fb1, va[C0 + 1]);                                                          \
-        BKV_PV(fb2, C0, 2, 3); bkv_dsr<8192>(fb2, va[C0 + 1]);                                                          \
-        BKV_PV(fb3, C0, 3, 3); bkv_dsr<12288>(fb3, va[C0 + 1]);                                                         \
-        BKV_PV(fb0, C0 + 1, 0, 3); BKV_PV(fb1, C0 + 1, 1, 2); BKV_PV(fb2, C0 + 1, 2, 1); BKV_PV(fb3, C0 + 1, 3, 0);     \
+        BKV_TR(t0, C0, 0); BKV_TR(t1, C0, 1); BKV_TR(t2, C0, 2); BKV_TR(t3, C0, 3);                                     \
+        BKV_PV(t0, C0, 0, 6); BKV_TR(t0, C0 + 1, 0);                                                                    \
+        BKV_PV(t1, C0, 1, 6); BKV_TR(t1, C0 + 1, 1);                                                                    \
+        BKV_PV(t2, C0, 2, 6); BKV_TR(t2, C0 + 1, 2);                                                                    \
+        BKV_PV(t3, C0, 3, 6); BKV_TR(t3, C0 + 1, 3);                                                                    \
+        BKV_PV(t0, C0 + 1, 0, 6); BKV_PV(t1, C0 + 1, 1, 4); BKV_PV(t2, C0 + 1, 2, 2); BKV_PV(t3, C0 + 1, 3, 0);         \
     } while (0)
         if (!ds_role) {
             // ================= P-wave: S(half) -> P(half) -> mailbox + flag, twice; then dV^T += dO^T P^T =================
@@ -678,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
                         asm volatile("ds_write_b128 %0, %1 offset:3072" :: "v"(mail), "v"(pf[3]) : "memory");
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const unsigned seq = it + 1;
+                    const unsigned seq = (unsigned)it + 1u;
                     if (half == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(flag), "v"(seq) : "memory");
                     else asm volatile("ds_write_b32 %0, %1 offset:4" :: "v"(flag), "v"(seq) : "memory");
                 }
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
             for (int half = 0; half < 2; ++half) {
                 const f32x16& gv = half == 0 ? g0 : g1;
                 bf16x8 pm[2];
-                wait_flag(half, it + 1);
+                wait_flag(half, (unsigned)it + 1u);
                 if constexpr (!(BKV_ABL & 8)) {
                     if (half == 0) { bkv_dsr<0>(pm[0], mail); bkv_dsr<1024>(pm[1], mail); }
                     else { bkv_dsr<2048>(pm[0], mail); bkv_dsr<3072>(pm[1], mail); }
@@ -731,16 +749,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
         }
 #undef BKV_ACC_HALF
 #undef BKV_PV
+#undef BKV_TR
 #undef BKV_HALF
 #undef BKV_DMA
 #undef BKV_MMA
 #undef BKV_MMA0
-        cur_dma = next_dma;
-        const unsigned dl = stage ? (unsigned)-STAGE : (unsigned)STAGE;
+        const unsigned dl = stage == NST - 1 ? (unsigned)(-(NST - 1) * STAGE) : (unsigned)STAGE;
+        stage = stage == NST - 1 ? 0 : stage + 1;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ka[kk] += dl;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) va[c] += dl;
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) ta[jj][dd] += dl;
     }
 #undef BKV_GLDS
 
@@ -766,381 +787,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Wide form of the fused dK / dV pass: FOUR waves, one per SIMD (512 registers each), 64 key rows per wave.  Timing ablations of the
-// 8-wave kernel above (tools/abl_bkv.sh, profiles/r04_abl_bkv*.log) showed every component exposed one after the other — MFMAs 7 ms,
-// tile requests 7, elementwise 4, fragment reads 3.5 of a 25 ms pass — over a floor set by LDS traffic: with 32-row fragments every MFMA
-// needs its own 1 KiB fragment read (8 waves x 32 reads + the 64 KiB tile = 2 700 LDS cycles per tile against 2 048 MFMA cycles).  With
-// 64 rows per wave every fragment feeds TWO MFMAs (half the LDS reads), half as many waves contend for the LDS and the texture unit, and
-// the accumulators (64 rows x 128 = 128 registers) move to AGPRs.  Same role split (P-wave / dS-wave, here on different SIMDs), mailbox,
-// flags and tile layout; 128 key rows per workgroup as before.
-__global__ __launch_bounds__(256, 1) void attn_bwd_kvw128_kernel(BwdArgs p) {
-    typedef bf16_t T;
-    constexpr int D = 128, YB = 64, XB = 128;
-    constexpr int TQ = 0, TDO = 16384, TQT = 32768, TDOT = 49152, STAT_OFF = 65536, STAGE = STAT_OFF + 512, MAIL = 2 * STAGE, FLAGS = MAIL + 16384;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE + 2 pairs x 8 KiB mailbox + flags
-
-    const int HB = p.heads * p.B;
-    int xt, hb;
-    if ((HB & 7) == 0) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        hb = xcd * (HB >> 3) + idx / p.nx_tiles;
-        xt = idx % p.nx_tiles;
-    } else {
-        hb = blockIdx.x / p.nx_tiles;
-        xt = blockIdx.x % p.nx_tiles;
-    }
-    const int b = hb / p.heads, h = hb % p.heads;
-    const int t = threadIdx.x, lane = t & 63, li = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int pair = wave & 1;
-    const bool ds_role = wave >= 2;                 // wave-uniform
-    const int64_t xrow0 = (int64_t)xt * XB + pair * 64 + li;      // row block 0; block 1 = + 32
-
-    bf16x8 xf[2][8];                                // K rows (P-wave) or V rows (dS-wave), two 32-row blocks
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int64_t xr = xrow0 + rb * 32;
-        const T* px = ds_role ? (const T*)p.xb + b * p.xb_bs + xr * p.xb_ls : (const T*)p.xa + b * p.xa_bs + xr * p.xa_ls;
-        px += (int64_t)h * D + hi * 8;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (xr < p.LX) xf[rb][kk] = *reinterpret_cast<const bf16x8*>(px + kk * 16);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xf[rb][kk][j] = (T)0.f;
-            }
-        }
-    }
-    const bool xv0 = xrow0 < p.LX, xv1 = xrow0 + 32 < p.LX;
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][d][r] = 0.f;
-
-    unsigned ka[8], va[4];
-    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_AS char*)smem;
-    {
-        const unsigned rbase = lds0 + (ds_role ? TDO : TQ), tbase = lds0 + (ds_role ? TQT : TDOT);
-        const int kr = perm23(li);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) ka[kk] = rbase + kr * 256 + (((kk * 2 + hi) ^ (kr & 15)) << 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) va[c] = tbase + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
-    }
-    const unsigned mail = lds0 + MAIL + pair * 8192 + lane * 16;      // [chunk c][row block rb][lane] x 16 B: offset (c * 2 + rb) * 1024
-    const unsigned flag = lds0 + FLAGS + pair * 8;
-    if (!ds_role && lane == 0) {
-        volatile unsigned* fz = reinterpret_cast<volatile unsigned*>(smem + FLAGS + pair * 8);
-        fz[0] = 0u; fz[1] = 0u;
-    }
-
-    const int k_r = lane >> 4, k_lc0 = lane & 15;
-    const int v_r = lane >> 3, v_pc = lane & 7;
-    const T* gq = (const T*)p.ya + b * p.ya_bs + (int64_t)h * D;
-    const T* gdo = (const T*)p.yb + b * p.yb_bs + (int64_t)h * D;
-    const T* gqt = (const T*)p.yat + b * p.yat_bs + (int64_t)h * D * p.yat_ls;
-    const T* gdot = (const T*)p.ybt + b * p.ybt_bs + (int64_t)h * D * p.ybt_ls;
-    const float* glse = p.lse + ((int64_t)b * p.heads + h) * p.Lq;
-    const float* gdel = p.delta + ((int64_t)b * p.heads + h) * p.Lq;
-    unsigned oq[4], odo[4], oqt[4], odot[4];        // 256 threads: four instructions per tile kind and thread
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int blk = wave * 4 + i;
-        const int row = blk * 4 + k_r, trow = blk * 8 + v_r;
-        oq[i] = (unsigned)((row * p.ya_ls + (k_lc0 ^ (row & 15)) * 8) * 2);
-        odo[i] = (unsigned)((row * p.yb_ls + (k_lc0 ^ (row & 15)) * 8) * 2);
-        oqt[i] = (unsigned)((trow * p.yat_ls + (v_pc ^ ((trow >> 1) & 7)) * 8) * 2);
-        odot[i] = (unsigned)((trow * p.ybt_ls + (v_pc ^ ((trow >> 1) & 7)) * 8) * 2);
-    }
-    auto uniform_ptr = [](const char* q) {
-        const unsigned long long v = (unsigned long long)q;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return (const char*)(((unsigned long long)hi2 << 32) | lo);
-    };
-#define BKW_GLDS(DST, VOFF, SRC) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(DST), "v"(VOFF), "s"(SRC) : "memory", "m0")
-    const char *dq_b = nullptr, *ddo_b = nullptr, *dqt_b = nullptr, *ddot_b = nullptr, *dst_b = nullptr;
-    unsigned d_dst = 0, d_sdst = 0;
-    auto dma_prepare = [&](int stage, int64_t y0) {
-        dq_b = uniform_ptr((const char*)(gq + y0 * p.ya_ls));
-        ddo_b = uniform_ptr((const char*)(gdo + y0 * p.yb_ls));
-        dqt_b = uniform_ptr((const char*)(gqt + y0));
-        ddot_b = uniform_ptr((const char*)(gdot + y0));
-        dst_b = uniform_ptr((const char*)((wave & 1 ? gdel : glse) + y0));
-        d_dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 4096);
-        d_sdst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + STAT_OFF + (wave & 1) * 256);
-    };
-    auto dma_one = [&](int n) {          // n = 0..16, a literal at every call site: (kind n & 3, instruction n >> 2), 16 = statistics
-        if constexpr (BKV_ABL & 16) return;
-        const int i = n >> 2;
-        if (n == 16) {
-            if (wave < 2)
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(d_sdst), "v"(lane * 4), "s"(dst_b) : "memory", "m0");
-        } else if ((n & 3) == 0) BKW_GLDS(d_dst + TQ + i * 1024, oq[i], dq_b);
-        else if ((n & 3) == 1) BKW_GLDS(d_dst + TDO + i * 1024, odo[i], ddo_b);
-        else if ((n & 3) == 2) BKW_GLDS(d_dst + TQT + i * 1024, oqt[i], dqt_b);
-        else BKW_GLDS(d_dst + TDOT + i * 1024, odot[i], ddot_b);
-    };
-    auto reg_tile = [&](int stage, int64_t y0) {      // ragged last tile: zero filled, synchronous
-        char* base = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = t + 256 * i;
-            {
-                const int row = c >> 4, ch = c & 15;
-                const int64_t y = y0 + row;
-                const bool ok = y < p.LY;
-                *reinterpret_cast<uint4*>(base + TQ + swz_off<256>(row, ch)) =
-                    ok ? *reinterpret_cast<const uint4*>(gq + y * p.ya_ls + ch * 8) : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(base + TDO + swz_off<256>(row, ch)) =
-                    ok ? *reinterpret_cast<const uint4*>(gdo + y * p.yb_ls + ch * 8) : make_uint4(0, 0, 0, 0);
-            }
-            {
-                const int row = c >> 3, ch = c & 7;
-                const int64_t y = y0 + ch * 8;
-#pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    const T* src = (which ? gdot + row * p.ybt_ls : gqt + row * p.yat_ls) + y;
-                    union { uint4 u; T e[8]; } tmp;
-                    tmp.u = make_uint4(0, 0, 0, 0);
-                    if (y + 8 <= p.LY) tmp.u = *reinterpret_cast<const uint4*>(src);
-                    else if (y < p.LY) {
-                        for (int j = 0; j < 8; ++j)
-                            if (y + j < p.LY) tmp.e[j] = src[j];
-                    }
-                    *reinterpret_cast<uint4*>(base + (which ? TDOT : TQT) + swz_off<128>(row, ch)) = tmp.u;
-                }
-            }
-        }
-        if (t < 128) {
-            const int64_t y = y0 + (t & 63);
-            float v = t < 64 ? INFINITY : 0.f;               // lse = +inf => probability exactly 0
-            if (y < p.LY) v = t < 64 ? glse[y] : gdel[y];
-            reinterpret_cast<float*>(base + STAT_OFF)[t] = v;
-        }
-    };
-    auto wait_flag = [&](int half, unsigned seq) {
-        if constexpr (BKV_ABL & 8) return;
-        for (int spin = 0; spin < (1 << 22); ++spin) {      // (bounded: a lost flag must end in wrong numbers the tests catch, never in a hung GPU)
-            unsigned v;
-            if (half) asm volatile("ds_read_b32 %0, %1 offset:4\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag) : "memory");
-            else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag) : "memory");
-            if (__builtin_amdgcn_readfirstlane(v) >= seq) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-
-    bool cur_dma = YB <= p.LY;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (cur_dma) {
-        dma_prepare(0, 0);
-        dma_one(0); dma_one(1); dma_one(2); dma_one(3); dma_one(4); dma_one(5); dma_one(6); dma_one(7); dma_one(8);
-        dma_one(9); dma_one(10); dma_one(11); dma_one(12); dma_one(13); dma_one(14); dma_one(15); dma_one(16);
-    }
-    unsigned it = 0;
-    for (int64_t y0 = 0; y0 < p.LY; y0 += YB, ++it) {
-        const int stage = it & 1;
-        if (cur_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else reg_tile(stage, y0);
-        __syncthreads();                                                       // stage landed; the other stage and the mailbox are free
-        const int64_t ny0 = y0 + YB;
-        bool next_dma = false;
-        if (ny0 < p.LY) {
-            next_dma = ny0 + YB <= p.LY;
-            if (next_dma) dma_prepare(stage ^ 1, ny0);
-        }
-        const float* st = reinterpret_cast<const float*>(smem + stage * STAGE + STAT_OFF) + (ds_role ? 64 : 0);
-        bf16x8 fb0, fb1, fb2, fb3;
-        bf16x8 pf[2][4];                                                       // [row block][16-query chunk]
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // one fragment, both row blocks
-#define BKW_MMA0(Bf, A0, A1) do { if constexpr (!(BKV_ABL & 2)) { A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf, xf[0][0], zero, 0, 0, 0); \
-                                                                 A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Bf, xf[1][0], zero, 0, 0, 0); } else { A0 = zero; A1 = zero; } } while (0)
-#define BKW_MMA(Bf, KK, A0, A1) do { if constexpr (!(BKV_ABL & 2)) { mma32(Bf, xf[0][KK], A0); mma32(Bf, xf[1][KK], A1); } } while (0)
-#define BKW_DMA(N, ON) do { if (ON) { if (next_dma) dma_one(N); __builtin_amdgcn_sched_barrier(0); } } while (0)
-        // 16 MFMAs of one 32-query half for both row blocks (8 fragment reads, four k-steps ahead); D0: first tile-request instruction placed here
-#define BKW_HALF(A0, A1, OFF, ON, D0)                                                                                  \
-    do {                                                                                                               \
-        bkv_dsr<OFF>(fb0, ka[0]); bkv_dsr<OFF>(fb1, ka[1]); bkv_dsr<OFF>(fb2, ka[2]); bkv_dsr<OFF>(fb3, ka[3]);         \
-        bkv_lgkm<3>(); BKW_MMA0(fb0, A0, A1); bkv_dsr<OFF>(fb0, ka[4]); BKW_DMA(D0 + 0, ON);                            \
-        bkv_lgkm<3>(); BKW_MMA(fb1, 1, A0, A1); bkv_dsr<OFF>(fb1, ka[5]); BKW_DMA(D0 + 1, ON);                          \
-        bkv_lgkm<3>(); BKW_MMA(fb2, 2, A0, A1); bkv_dsr<OFF>(fb2, ka[6]); BKW_DMA(D0 + 2, ON);                          \
-        bkv_lgkm<3>(); BKW_MMA(fb3, 3, A0, A1); bkv_dsr<OFF>(fb3, ka[7]); BKW_DMA(D0 + 3, ON);                          \
-        bkv_lgkm<3>(); BKW_MMA(fb0, 4, A0, A1); BKW_DMA(D0 + 4, ON); bkv_lgkm<2>(); BKW_MMA(fb1, 5, A0, A1); BKW_DMA(D0 + 5, ON); \
-        bkv_lgkm<1>(); BKW_MMA(fb2, 6, A0, A1); BKW_DMA(D0 + 6, ON); bkv_lgkm<0>(); BKW_MMA(fb3, 7, A0, A1); BKW_DMA(D0 + 7, ON); \
-    } while (0)
-        // accumulate one half: chunks C0, C0 + 1; every transposed-tile fragment feeds both row blocks
-#define BKW_PV(Bf, C, DD, W) do { bkv_lgkm<W>(); if constexpr (!(BKV_ABL & 4)) { mma32(Bf, pf[0][C], acc[0][DD]); mma32(Bf, pf[1][C], acc[1][DD]); } } while (0)
-#define BKW_ACC_HALF(C0)                                                                                               \
-    do {                                                                                                               \
-        bkv_dsr<0>(fb0, va[C0]); bkv_dsr<4096>(fb1, va[C0]); bkv_dsr<8192>(fb2, va[C0]); bkv_dsr<12288>(fb3, va[C0]);   \
-        BKW_PV(fb0, C0, 0, 3); bkv_dsr<0>(fb0, va[C0 + 1]);                                                             \
-        BKW_PV(fb1, C0, 1, 3); bkv_dsr<4096>(fb1, va[C0 + 1]);                                                          \
-        BKW_PV(fb2, C0, 2, 3); bkv_dsr<8192>(fb2, va[C0 + 1]);                                                          \
-        BKW_PV(fb3, C0, 3, 3); bkv_dsr<12288>(fb3, va[C0 + 1]);                                                         \
-        BKW_PV(fb0, C0 + 1, 0, 3); BKW_PV(fb1, C0 + 1, 1, 2); BKW_PV(fb2, C0 + 1, 2, 1); BKW_PV(fb3, C0 + 1, 3, 0);     \
-    } while (0)
-        if (!ds_role) {
-            // ================= P-wave =================
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f32x16 s0, s1;
-                if (half == 0) BKW_HALF(s0, s1, 0, true, 0); else BKW_HALF(s0, s1, 8192, true, 8);
-                if (half == 1) { if (next_dma) dma_one(16); }
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 15\n\ts_nop 3");
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const f32x16& sv = rb == 0 ? s0 : s1;
-                    const bool xv = rb == 0 ? xv0 : xv1;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int c = half * 2 + q, r0 = q * 8, yb = half * 32 + q * 16 + 8 * hi;
-                        if constexpr (BKV_ABL & 1) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) pf[rb][c][j] = (T)sv[r0 + j];
-                        } else {
-                            const f32x4 l0 = *reinterpret_cast<const f32x4*>(st + yb), l1 = *reinterpret_cast<const f32x4*>(st + yb + 4);
-                            float lv[8], x[8];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { lv[j] = l0[j]; lv[4 + j] = l1[j]; }
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(x[j]) : "v"(sv[r0 + j]), "s"(p.sc), "v"(lv[j]));
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) asm volatile("v_exp_f32 %0, %1" : "=v"(x[j]) : "v"(x[j]));
-                            asm volatile("s_nop 1");
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) pf[rb][c][j] = (T)(xv ? x[j] : 0.f);
-                        }
-                    }
-                }
-                if constexpr (!(BKV_ABL & 8)) {
-                    if (half == 0) {
-                        asm volatile("ds_write_b128 %0, %1" :: "v"(mail), "v"(pf[0][0]) : "memory");
-                        asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(mail), "v"(pf[1][0]) : "memory");
-                        asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(mail), "v"(pf[0][1]) : "memory");
-                        asm volatile("ds_write_b128 %0, %1 offset:3072" :: "v"(mail), "v"(pf[1][1]) : "memory");
-                    } else {
-                        asm volatile("ds_write_b128 %0, %1 offset:4096" :: "v"(mail), "v"(pf[0][2]) : "memory");
-                        asm volatile("ds_write_b128 %0, %1 offset:5120" :: "v"(mail), "v"(pf[1][2]) : "memory");
-                        asm volatile("ds_write_b128 %0, %1 offset:6144" :: "v"(mail), "v"(pf[0][3]) : "memory");
-                        asm volatile("ds_write_b128 %0, %1 offset:7168" :: "v"(mail), "v"(pf[1][3]) : "memory");
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    const unsigned seq = it + 1;
-                    if (half == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(flag), "v"(seq) : "memory");
-                    else asm volatile("ds_write_b32 %0, %1 offset:4" :: "v"(flag), "v"(seq) : "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            BKW_ACC_HALF(0);
-            BKW_ACC_HALF(2);
-        } else {
-            // ================= dS-wave =================
-            f32x16 g00, g01, g10, g11;       // [half][row block]
-            BKW_HALF(g00, g01, 0, true, 0);
-            BKW_HALF(g10, g11, 8192, true, 8);
-            if (next_dma) dma_one(16);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15\n\ts_nop 3");
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                bf16x8 pm[2][2];             // [q][row block]
-                wait_flag(half, it + 1);
-                if constexpr (!(BKV_ABL & 8)) {
-                    if (half == 0) { bkv_dsr<0>(pm[0][0], mail); bkv_dsr<1024>(pm[0][1], mail); bkv_dsr<2048>(pm[1][0], mail); bkv_dsr<3072>(pm[1][1], mail); }
-                    else { bkv_dsr<4096>(pm[0][0], mail); bkv_dsr<5120>(pm[0][1], mail); bkv_dsr<6144>(pm[1][0], mail); bkv_dsr<7168>(pm[1][1], mail); }
-                } else { pm[0][0] = xf[0][0]; pm[0][1] = xf[0][1]; pm[1][0] = xf[0][2]; pm[1][1] = xf[0][3]; }
-                bkv_lgkm<0>();
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    const f32x16& gv = half == 0 ? (rb == 0 ? g00 : g01) : (rb == 0 ? g10 : g11);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int c = half * 2 + q, r0 = q * 8, yb = half * 32 + q * 16 + 8 * hi;
-                        if constexpr (BKV_ABL & 1) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) pf[rb][c][j] = (T)gv[r0 + j];
-                        } else {
-                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(st + yb), d1 = *reinterpret_cast<const f32x4*>(st + yb + 4);
-                            float dv[8], tt[8], x[8];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { dv[j] = d0[j]; dv[4 + j] = d1[j]; }
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(tt[j]) : "v"(gv[r0 + j]), "v"(dv[j]));
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float pj = (float)pm[q][rb][j];
-                                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x[j]) : "v"(pj), "v"(tt[j]));
-                            }
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) pf[rb][c][j] = (T)x[j];
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (half == 0) BKW_ACC_HALF(0); else BKW_ACC_HALF(2);
-            }
-        }
-#undef BKW_ACC_HALF
-#undef BKW_PV
-#undef BKW_HALF
-#undef BKW_DMA
-#undef BKW_MMA
-#undef BKW_MMA0
-        cur_dma = next_dma;
-        const unsigned dl = stage ? (unsigned)-STAGE : (unsigned)STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) ka[kk] += dl;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) va[c] += dl;
-    }
-#undef BKW_GLDS
-
-    const float osc = ds_role ? p.scale : 1.f;       // dK = scale * sum (P (G - delta))^T Q
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int64_t xr = xrow0 + rb * 32;
-        if (xr >= p.LXs) continue;
-        T* oa = ds_role ? (T*)p.out_a + b * p.oa_bs + xr * p.oa_ls : (T*)p.out_b + b * p.ob_bs + xr * p.ob_ls;
-        oa += (int64_t)h * D + hi * 4;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[rb][d][rq * 4 + e] * osc;
-                T* dst = oa + d * 32 + rq * 8;
-                if (p.accumulate) {
-                    f32x4 prev = load4(dst);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += prev[e];
-                }
-                store4(dst, v);
-            }
-    }
-}
-
+// (A wide form — four 64-row waves, one per SIMD, accumulators in AGPRs, every fragment feeding two MFMAs — was built and measured in
+// round 4: 43.6 ms for the whole backward against 38.5 ms with eight 32-row waves, profiles/r04_ab_attn_bwd.log; a lone wave per SIMD runs
+// its fragment waits, MFMAs and elementwise stream strictly one after the other.  Removed.)
 inline int launch_bwd_kv128(const BwdArgs& p, hipStream_t st) {
-    constexpr int LDS = 2 * (65536 + 512) + 16384 + 64;
-    // 0 = eight 32-row waves (default), 1 = four 64-row waves.  Measured (tools/ab_attn_bwd.py, same box, L = 21 840, 40 heads): whole backward
-    // 38.7 ms with separate dK / dV passes, 38.5 ms fused with eight waves, 43.6 ms fused with four wide waves — the wide form halves the LDS
-    // reads per MFMA but a lone wave per SIMD runs its fragment waits, MFMAs and elementwise stream strictly one after the other; it needs
-    // the elementwise stream hand-interleaved into the MFMA shadows (the GEMM's recipe) before it can pay.
-    M4D_ENV_ONCE(wide, "M4D_ATTN_BWD_WIDE", 0);
+    constexpr int LDS = BKV_NST * (32768 + 512) + 16384 + 64;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute((const void*)attn_bwd_kv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        if (hipFuncSetAttribute((const void*)attn_bwd_kvw128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         configured = true;
     }
     dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B));
-    if (wide) hipLaunchKernelGGL(attn_bwd_kvw128_kernel, grid, dim3(256), LDS, st, p);
-    else hipLaunchKernelGGL(attn_bwd_kv128_kernel, grid, dim3(512), LDS, st, p);
+    hipLaunchKernelGGL(attn_bwd_kv128_kernel, grid, dim3(512), LDS, st, p);
     return 0;
 }
 
