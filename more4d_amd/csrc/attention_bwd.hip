@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(BwdArgs p) {
 }
 
 #include "attention_bwd128.h"
+#include "attention_bwd_kvp.h"
 
 // float workspace [B, rows, C] -> T output rows (b, l) at out + b*bs + l*ls (+= when accumulate)
 struct WsArgs { const float* ws; void* out; int64_t bs, ls, rows; int C, B, accumulate; };
@@ -377,12 +378,12 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         const int64_t chunk = nsplit > 1 ? ((ytiles + nsplit - 1) / nsplit) * 64 : 0;
         // fused dK / dV pass (attention_bwd128.h: role-split wave pairs, S and P computed once): the self-attention shape; the split-Y
         // cross-attention case (few keys, many queries, float workspace) keeps the two separate passes.  M4D_ATTN_BWD_FUSED=0: A/B.
-        M4D_ENV_ONCE(bwd_fused, "M4D_ATTN_BWD_FUSED", 1);
+        // 2 (default) = attn_bwd_kvp_kernel (attention_bwd_kvp.h: the forward kernel's phased schedule), 1 = the first fused kernel.
+        M4D_ENV_ONCE(bwd_fused, "M4D_ATTN_BWD_FUSED", 2);
         if (bwd_fused && nsplit == 1) {
-            p.ybt = a->dot; p.ybt_bs = a->dot_bs; p.ybt_ls = a->dot_ls;
             p.out_b = a->dv; p.ob_bs = a->dv_bs; p.ob_ls = a->dv_ls;
             p.nx_tiles = (int)((a->Lk_rows + 127) / 128);
-            if (launch_bwd_kv128(p, st)) { m4d_set_error("attention_bwd: cannot configure the fused dk/dv kernel"); return -3; }
+            if (bwd_fused == 2 ? launch_bwd_kvp(p, st) : launch_bwd_kv128(p, st)) { m4d_set_error("attention_bwd: cannot configure the fused dk/dv kernel"); return -3; }
             M4D_CHECK_LAUNCH("attention_bwd(dkv128 fused)");
             m4d_count_launch(M4D_KC_ATTN_BWD128);
             return 0;
