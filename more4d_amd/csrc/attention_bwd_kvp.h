@@ -20,15 +20,25 @@
 #pragma once
 #include <type_traits>
 
-namespace kvp {
 #ifndef KVP_RD
-#define KVP_RD 6
+#define KVP_RD 6        // fragments in flight per wave (4, 5, 7 measured: within 0.5 %)
 #endif
-constexpr int RD = KVP_RD;                 // fragments in flight per wave (accumulate steps: two reads each -> lgkmcnt <= 12)
+#ifndef KVP_PRIO
+#define KVP_PRIO 1      // 0 no s_setprio, 1 raised priority around every M stream, 2 static: the dS-waves (younger half) at priority 1 (all within 1 %)
+#endif
+#ifndef KVP_ABL
+#define KVP_ABL 0       // side builds (tools/side_lib.sh, tools/abl_kvp.sh), timing only, results wrong: 1 no elementwise arithmetic, 2 no MFMAs,
+#endif                  // 4 no fragment reads, 8 no mailbox / flag, 16 no tile requests
+#ifndef KVP_STAMPS
+#define KVP_STAMPS 0    // side build: s_memtime stamps of waves 0 / 4 of workgroup 1000 (intervals 100..115), printed by the kernel (tools/kvp_stamps.py)
+#endif
+namespace kvp {
+constexpr int RD = KVP_RD;            // fragments in flight per wave (accumulate steps: two reads each -> lgkmcnt <= 12)
 constexpr int NQ = 5, ND = 3;         // ring slots
 constexpr int TILE = 16384;
 constexpr int Q_OFF = 0, DO_OFF = NQ * TILE, ST_OFF = DO_OFF + ND * TILE, MAIL_OFF = ST_OFF + ND * 512, FLAG_OFF = MAIL_OFF + 16384;
-constexpr int LDS_BYTES = FLAG_OFF + 64;
+constexpr int STAMP_OFF = FLAG_OFF + 64;
+constexpr int LDS_BYTES = STAMP_OFF + (KVP_STAMPS ? 2048 : 0);
 // fragment J of an M stream: J < 16 accumulate step (chunk J >> 2, d-block J & 3), two transposing reads; J >= 16 S / G step
 // (32-row half (J - 16) >> 3, k-step (J - 16) & 7), one 16-byte read
 constexpr int nreads(int J) { return J < 16 ? 2 : 1; }
@@ -41,6 +51,7 @@ constexpr int behind(int J, int J1) {
 struct Ring { bf16x4 tl[RD], th[RD]; bf16x8 rb[RD]; };
 
 template <int J> M4D_DEV void read(Ring& r, const unsigned (&ta)[2][4], const unsigned (&ra)[8]) {
+    if constexpr (KVP_ABL & 4) return;
     if constexpr (J < 16) {
         bwd_tr_read<(J >> 2) * 4096>(r.tl[J % RD], ta[0][J & 3]);
         bwd_tr_read<(J >> 2) * 4096>(r.th[J % RD], ta[1][J & 3]);
@@ -58,7 +69,8 @@ M4D_DEV void steps(Ring& r, const unsigned (&ta)[2][4], const unsigned (&ra)[8],
                    f32x16 (&acc)[4], f32x16 (&sg)[2], Hook&& hook) {
     if constexpr (J < J1) {
         bkv_lgkm<behind(J, J1)>();
-        if constexpr (J < 16) mma32(bwd_tr_join(r.tl[J % RD], r.th[J % RD]), pf[J >> 2], acc[J & 3]);
+        if constexpr (KVP_ABL & 2) {}
+        else if constexpr (J < 16) mma32(bwd_tr_join(r.tl[J % RD], r.th[J % RD]), pf[J >> 2], acc[J & 3]);
         else {
             constexpr int I = J - 16;
             if constexpr ((I & 7) == 0) {
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (const char*)(((unsigned long long)hi2 << 32) | lo);
     };
-#define KVP_GLDS(DST, VOFF, SRC) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(DST), "v"(VOFF), "s"(SRC) : "memory", "m0")
+#define KVP_GLDS(DST, VOFF, SRC) if constexpr (!(KVP_ABL & 16)) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(DST), "v"(VOFF), "s"(SRC) : "memory", "m0")
     const char *rq_b = nullptr, *rdo_b = nullptr, *rst_b = nullptr;
     unsigned rq_dst = 0, rdo_dst = 0, rst_dst = 0;
     bool rq_last = false, rdo_last = false;
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
     };
     auto req_st = [&]() {
         const unsigned off = rdo_last ? ostat_l : ostat;
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(rst_dst), "v"(off), "s"(rst_b) : "memory", "m0");
+        if constexpr (!(KVP_ABL & 16)) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(rst_dst), "v"(off), "s"(rst_b) : "memory", "m0");
     };
 
     Ring ring;
@@ -255,36 +267,46 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
             }
             // single-issue v_fma_f32 / v_exp_f32 as one volatile stream (packed fp32 VALU costs more than its two halves beside the partner
             // wave's MFMAs); a VALU consuming a v_exp_f32 result sits eight instructions behind it
+            if constexpr (KVP_ABL & 1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(x[e]) : "v"(sg[half][rb + e]), "s"(p.sc), "v"(lv[e]));
+                for (int e = 0; e < 8; ++e) x[e] = sg[half][rb + e] + lv[e & 1];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("v_exp_f32 %0, %1" : "=v"(x[e]) : "v"(x[e]));
-            asm volatile("s_nop 1");
+                for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(x[e]) : "v"(sg[half][rb + e]), "s"(p.sc), "v"(lv[e]));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("v_exp_f32 %0, %1" : "=v"(x[e]) : "v"(x[e]));
+                asm volatile("s_nop 1");
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[c][e] = (T)x[e];
         }
-        asm volatile("ds_write_b128 %0, %1" :: "v"(mail), "v"(pf[0]) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(mail), "v"(pf[1]) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(mail), "v"(pf[2]) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:3072" :: "v"(mail), "v"(pf[3]) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned seq = (unsigned)j + 1u;
-        asm volatile("ds_write_b32 %0, %1" :: "v"(flag), "v"(seq) : "memory");
+        if constexpr (!(KVP_ABL & 8)) {
+            asm volatile("ds_write_b128 %0, %1" :: "v"(mail), "v"(pf[0]) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(mail), "v"(pf[1]) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(mail), "v"(pf[2]) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:3072" :: "v"(mail), "v"(pf[3]) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned seq = (unsigned)j + 1u;
+            asm volatile("ds_write_b32 %0, %1" :: "v"(flag), "v"(seq) : "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     // ---- dS-wave elementwise step: dS(j) = P(j) (G - delta) (the softmax scale is applied to dK once, at the end) ----
     auto v_ds = [&](int j) {
         const float* st = reinterpret_cast<const float*>(smem + ST_OFF + (j % ND) * 512) + 64;
         const unsigned seq = (unsigned)j + 1u;
-        for (int spin = 0; spin < (1 << 22); ++spin) {      // (bounded: a lost flag must end in wrong numbers the tests catch, never in a hung GPU)
-            unsigned v;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag) : "memory");
-            if (__builtin_amdgcn_readfirstlane(v) >= seq) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
         bf16x8 pm[4];
-        bkv_dsr<0>(pm[0], mail); bkv_dsr<1024>(pm[1], mail); bkv_dsr<2048>(pm[2], mail); bkv_dsr<3072>(pm[3], mail);
-        bkv_lgkm<0>();
+        if constexpr (KVP_ABL & 8) { pm[0] = xf[0]; pm[1] = xf[1]; pm[2] = xf[2]; pm[3] = xf[3]; }
+        else {
+            for (int spin = 0; spin < (1 << 22); ++spin) {      // (bounded: a lost flag must end in wrong numbers the tests catch, never in a hung GPU)
+                unsigned v;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag) : "memory");
+                if (__builtin_amdgcn_readfirstlane(v) >= seq) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            bkv_dsr<0>(pm[0], mail); bkv_dsr<1024>(pm[1], mail); bkv_dsr<2048>(pm[2], mail); bkv_dsr<3072>(pm[3], mail);
+            bkv_lgkm<0>();
+        }
         asm volatile("s_nop 15\n\ts_nop 3");
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -293,12 +315,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
             float dv[8], tt[8], x[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { dv[e] = d0[e]; dv[4 + e] = d1[e]; }
+            if constexpr (KVP_ABL & 1) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(tt[e]) : "v"(sg[half][rb + e]), "v"(dv[e]));
+                for (int e = 0; e < 8; ++e) { tt[e] = dv[e & 1]; x[e] = sg[half][rb + e] + tt[e] + (float)pm[c][e & 1]; }
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pe = (float)pm[c][e];
-                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x[e]) : "v"(pe), "v"(tt[e]));
+                for (int e = 0; e < 8; ++e) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(tt[e]) : "v"(sg[half][rb + e]), "v"(dv[e]));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pe = (float)pm[c][e];
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x[e]) : "v"(pe), "v"(tt[e]));
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[c][e] = (T)x[e];
@@ -323,19 +350,37 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
     // ONE stream shape everywhere (accumulators that flow through differently shaped branches cost hipcc copies of all 64 registers and
     // spills): where half of a stream has nothing to do it runs on harmless operands — P = dS = 0 against a landed tile (accumulators
     // unchanged), or S / G of a stale slot that nobody reads afterwards.
+    int iv = -1;                                               // interval counter of the stamps
+    const bool stamp_on = KVP_STAMPS && blockIdx.x == (gridDim.x > 1000 ? 1000 : 0) && pair == 0;
+    // stamps (side build): slot 0 interval start, 1 between the wave's two phases, 2 before / 3 after the wait for the tile requests
+#define KVP_STAMP(SLOT)                                                                                                \
+    do {                                                                                                               \
+        if constexpr (KVP_STAMPS) {                                                                                    \
+            if (stamp_on && iv >= 100 && iv < 116) {                                                                   \
+                unsigned long long tc_;                                                                                \
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc_) :: "memory");                          \
+                if (lane == 0) *(volatile LDS_AS unsigned long long*)((LDS_AS char*)smem + STAMP_OFF + (ds_role ? 1024 : 0) + ((iv - 100) * 4 + (SLOT)) * 8) = tc_; \
+            }                                                                                                          \
+        }                                                                                                              \
+    } while (0)
 #define KVP_END_INTERVAL()                                                                                             \
     do {                                                                                                               \
+        KVP_STAMP(2);                                                                                                  \
         if (do_req) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      /* everything but this interval's own request has landed */ \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
+        KVP_STAMP(3);                                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                                  \
+        ++iv;                                                                                                          \
+        KVP_STAMP(0);                                                                                                  \
     } while (0)
 #define KVP_M_STREAM()                                                                                                 \
     do {                                                                                                               \
-        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        if constexpr (KVP_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                    \
         steps<0, 0, 32>(ring, ta, ra, pf, xf, acc, sg, hook);                                                          \
-        __builtin_amdgcn_s_setprio(0);                                                                                 \
+        if constexpr (KVP_PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                    \
     } while (0)
+    if constexpr (KVP_PRIO == 2) { if (ds_role) __builtin_amdgcn_s_setprio(1); }
     if (!ds_role) {
         // in front of interval 0: S(0) = Q(0) K^T (the accumulate half runs on P = 0 against dO(0))
         do_req = false;
@@ -349,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
             req_tq = j + 3; req_td = j + 2;
             prefetch<0, RD>(ring, ta, ra);                     // dO(j)^T fragments land under the elementwise step
             if (ragged && j == NT - 1) v_p(j, std::true_type{}); else v_p(j, std::false_type{});
+            KVP_STAMP(1);
             advance_deltas(true, true);
             KVP_M_STREAM();                                    // dV += dO(j)^T P(j); S(j + 1) (of a stale slot after the last tile)
             KVP_END_INTERVAL();
@@ -364,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
             req_tq = j + 3; req_td = j + 2;
             advance_deltas(j > 0, true);                       // ta: Q(j - 1) -> Q(j) (stays on Q(0) in interval 0); ra: dO(j) -> dO(j + 1)
             KVP_M_STREAM();                                    // dK += Q(j - 1)^T dS(j - 1); G(j) = dO(j) V^T
+            KVP_STAMP(1);
             v_ds(j);
             prefetch<0, RD>(ring, ta, ra);                     // Q(j)^T fragments of the next interval's dK steps (the tile landed long ago)
             KVP_END_INTERVAL();
@@ -375,6 +422,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
     }
 #undef KVP_M_STREAM
 #undef KVP_END_INTERVAL
+    if constexpr (KVP_STAMPS) {
+        __syncthreads();
+        if (stamp_on && t == 0) {
+            const LDS_AS unsigned long long* sp = (const LDS_AS unsigned long long*)((LDS_AS char*)smem + STAMP_OFF);
+            for (int k = 0; k < 16; ++k)
+                printf("KVPSTAMP %d  P: %llu %llu %llu %llu   dS: %llu %llu %llu %llu\n", k, sp[k * 4], sp[k * 4 + 1], sp[k * 4 + 2], sp[k * 4 + 3],
+                       sp[128 + k * 4], sp[128 + k * 4 + 1], sp[128 + k * 4 + 2], sp[128 + k * 4 + 3]);
+        }
+    }
 #undef KVP_GLDS
 
     if (xrow < p.LXs) {
