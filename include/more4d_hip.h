@@ -324,7 +324,9 @@ int m4d_attention_lse(m4d_dtype dt, const void* q, int64_t q_bs, int64_t q_ls, c
  * Row-major operands: element (b, l, h, d) at ptr + b*bs + l*ls + h*head_dim + d.  Transposed operands (qt, kt, dot =
  * q^T, k^T, dO^T): element (b, h, d, l) at ptr + b*bs + (h*head_dim + d)*ls + l (what m4d_transpose of the [B*L, C]
  * matrix produces with bs = L, ls = B*L).  Only the first Lk of the Lk_rows key rows are real keys; dk / dv rows in
- * [Lk, Lk_rows) are written as zero.  delta: float workspace [B, heads, Lq]; lse from m4d_attention_lse. */
+ * [Lk, Lk_rows) are written as zero.  delta: float workspace [B, heads, Lq]; lse from m4d_attention_lse.
+ * qt / kt / dot may be NULL for bf16 with head_dim 128: those passes take the transposed fragments out of the row-major
+ * tiles (ds_read_b64_tr_b16); the generic kernels (float, other head dims) require them. */
 typedef struct {
     const void *q, *k, *v, *o, *d_o, *qt, *kt, *dot;
     const float* lse;

@@ -317,8 +317,7 @@ int launch_bwd(const BwdArgs& p, int D, hipStream_t st) {
 extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "attention_bwd: bad dtype %d", (int)dt);
     M4D_CHECK_ARG(a, "attention_bwd: null args");
-    M4D_CHECK_ARG(a->q && a->k && a->v && a->o && a->d_o && a->qt && a->kt && a->dot && a->lse && a->delta && a->dq && a->dk && a->dv,
-                  "attention_bwd: null pointer");
+    M4D_CHECK_ARG(a->q && a->k && a->v && a->o && a->d_o && a->lse && a->delta && a->dq && a->dk && a->dv, "attention_bwd: null pointer");
     M4D_CHECK_ARG(a->B > 0 && a->Lq > 0 && a->Lk > 0 && a->heads > 0 && a->Lk_rows >= a->Lk, "attention_bwd: bad sizes");
     if (!(a->head_dim == 32 || a->head_dim == 64 || a->head_dim == 128)) {
         m4d_set_error("attention_bwd: unsupported head_dim %d (32, 64, 128)", a->head_dim);
@@ -328,7 +327,7 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
                                a->qt_bs, a->qt_ls, a->kt_bs, a->kt_ls, a->dot_bs, a->dot_ls, a->dq_bs, a->dq_ls,
                                a->dk_bs, a->dk_ls, a->dv_bs, a->dv_ls};
     for (int64_t s : strides) M4D_CHECK_ARG(s % 8 == 0, "attention_bwd: strides must be multiples of 8 elements");
-    const void* ptrs[] = {a->q, a->k, a->v, a->o, a->d_o, a->qt, a->kt, a->dot, a->dq, a->dk, a->dv};
+    const void* ptrs[] = {a->q, a->k, a->v, a->o, a->d_o, a->qt, a->kt, a->dot, a->dq, a->dk, a->dv};      // (null qt / kt / dot pass)
     for (const void* q : ptrs) M4D_CHECK_ARG(((uintptr_t)q % 16) == 0, "attention_bwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const bool bf = dt == M4D_BF16;
@@ -350,20 +349,18 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
     M4D_ENV_ONCE(bwd_generic, "M4D_ATTN_BWD_GENERIC", 0);
     if (bf && a->head_dim == 128 && !bwd_generic) {
         // production path: three forward-shaped passes (attention_bwd128.h)
-        p.ybt = nullptr; p.ybt_bs = p.ybt_ls = 0; p.out_b = nullptr; p.ob_bs = p.ob_ls = 0;
-        // dQ: X = (Q, dO), Y = (K, V, K^T)
+        p.yat = p.ybt = nullptr; p.yat_bs = p.yat_ls = p.ybt_bs = p.ybt_ls = 0; p.out_b = nullptr; p.ob_bs = p.ob_ls = 0;
+        // dQ: X = (Q, dO), Y = (K, V)
         p.xa = a->q; p.xa_bs = a->q_bs; p.xa_ls = a->q_ls; p.xb = a->d_o; p.xb_bs = a->do_bs; p.xb_ls = a->do_ls;
         p.ya = a->k; p.ya_bs = a->k_bs; p.ya_ls = a->k_ls; p.yb = a->v; p.yb_bs = a->v_bs; p.yb_ls = a->v_ls;
-        p.yat = a->kt; p.yat_bs = a->kt_bs; p.yat_ls = a->kt_ls;
         p.out_a = a->dq; p.oa_bs = a->dq_bs; p.oa_ls = a->dq_ls;
         p.LX = p.LXs = a->Lq; p.LY = a->Lk; p.nx_tiles = (int)((a->Lq + 255) / 256); p.accumulate = a->accumulate_dq;
         if (launch_bwd128<BWD_DQ>(p, st, 1)) { m4d_set_error("attention_bwd: cannot configure the dq kernel"); return -3; }
         M4D_CHECK_LAUNCH("attention_bwd(dq128)");
         m4d_count_launch(M4D_KC_ATTN_BWD128);
-        // dK: X = (K, V), Y = (Q, dO, Q^T)
+        // dK: X = (K, V), Y = (Q, dO)
         p.xa = a->k; p.xa_bs = a->k_bs; p.xa_ls = a->k_ls; p.xb = a->v; p.xb_bs = a->v_bs; p.xb_ls = a->v_ls;
         p.ya = a->q; p.ya_bs = a->q_bs; p.ya_ls = a->q_ls; p.yb = a->d_o; p.yb_bs = a->do_bs; p.yb_ls = a->do_ls;
-        p.yat = a->qt; p.yat_bs = a->qt_bs; p.yat_ls = a->qt_ls;
         p.out_a = a->dk; p.oa_bs = a->dk_bs; p.oa_ls = a->dk_ls;
         p.LX = a->Lk; p.LXs = a->Lk_rows; p.LY = a->Lq; p.nx_tiles = (int)((a->Lk_rows + 255) / 256); p.accumulate = a->accumulate_dkv;
         // few key tiles against many queries (cross-attention): split the query loop over blockIdx.y
@@ -389,8 +386,7 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
             return 0;
         }
         for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) {   // dV: X = (K), Y = (Q, dO^T)
-                p.yat = a->dot; p.yat_bs = a->dot_bs; p.yat_ls = a->dot_ls;
+            if (pass == 1) {   // dV: X = (K), Y = (Q, dO)
                 p.out_a = a->dv; p.oa_bs = a->dv_bs; p.oa_ls = a->dv_ls;
             }
             if (nsplit > 1) {
@@ -410,6 +406,8 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         }
         return 0;
     }
+    // the generic kernels read transposed copies of Q, K, dO (the bf16 / head_dim 128 passes above take them out of the row-major tiles)
+    M4D_CHECK_ARG(a->qt && a->kt && a->dot, "attention_bwd: qt / kt / dot are required for this dtype / head_dim");
     // ---- pass Q: X = queries ----
     p.xa = a->q; p.xa_bs = a->q_bs; p.xa_ls = a->q_ls;
     p.xb = a->d_o; p.xb_bs = a->do_bs; p.xb_ls = a->do_ls;

@@ -2,11 +2,13 @@
 // Same math as attn_bwd_kernel (attention_bwd.hip) split into THREE single-accumulator passes so that every pass has
 // the forward kernel's shape (attention.hip: attn128_kernel) and inherits its measured structure:
 //   * 8 waves x 32 X-rows per workgroup share each Y tile (two waves per SIMD, <= 256 VGPRs each);
-//   * Y tiles arrive by global->LDS DMA into two stages, ONE barrier per tile, swizzle applied on the source address;
+//   * Y tiles arrive by global->LDS DMA into FOUR stages (tile i + 3 requested while tile i is computed, counted vmcnt), ONE barrier per
+//     tile, swizzle applied on the source address; ROW-MAJOR tiles only: the transposed operand of the accumulate product is read out of
+//     the same tile with ds_read_b64_tr_b16 (bwd_tr_* below), so no transposed copies of Q / K / dO travel (round 4);
 //   * LDS fragment reads are hand-pipelined (inline asm ds_read_b128 + counted lgkmcnt), exp2 is the raw v_exp_f32.
-//   DQ:  X = (Q, dO)  Y = (K, V, K^T)     dS = P (G - delta_x) scale        dQ^T += K^T  dS^T      3 matmuls
-//   DK:  X = (K, V)   Y = (Q, dO, Q^T)    dS = P (G - delta_y) scale        dK^T += Q^T  dS^T      3 matmuls
-//   DV:  X = (K)      Y = (Q, dO^T)       P  = exp2(S sc - lse_y)           dV^T += dO^T P^T       2 matmuls
+//   DQ:  X = (Q, dO)  Y = (K, V)      dS = P (G - delta_x) scale        dQ^T += K^T  dS^T      3 matmuls
+//   DK:  X = (K, V)   Y = (Q, dO)     dS = P (G - delta_y) scale        dK^T += Q^T  dS^T      3 matmuls
+//   DV:  X = (K)      Y = (Q, dO)     P  = exp2(S sc - lse_y)           dV^T += dO^T P^T       2 matmuls
 // (8 matmul units instead of the fused two-pass kernel's 7, for twice the occupancy and no 512-VGPR waves.)
 #pragma once
 
@@ -15,17 +17,46 @@
 
 enum { BWD_DQ = 0, BWD_DK = 1, BWD_DV = 2 };
 
+// ---- transposed operands without transposed copies: ds_read_b64_tr_b16 (round 4) ----
+// The accumulate products need the Y tile transposed (dV^T += dO^T P^T, dK^T += Q^T dS^T, dQ^T += K^T dS^T): A fragment = 32 d rows x 16 y,
+// lane (i = d, hi) holding 8 y values of column d of the row-major tile.  gfx950's transposing LDS read does exactly that gather.
+// Semantics (probed, tools/probes/ds_read_tr.hip): within each group of 16 lanes, lane s supplies the address of one 8-byte piece =
+// row (s >> 2), column quad (s & 3) of a [4 rows][16 columns] block of 16-bit elements, and lane t receives column t of the block
+// (4 elements, rows 0..3).  The four rows of a block may be any four rows (each lane has its own address); here they are rows
+// y0, y0 + 4, y0 + 8, y0 + 12 of a 16-row chunk, because with the tile's XOR swizzle (16-byte chunk ^ (row & 15), applied on the DMA source
+// address) rows that differ in bits 2..3 and agree in bits 0..1 put their four chunks on 16 different bank slots: the 32 lanes serviced
+// per LDS cycle cover all 64 banks exactly once.  Two reads (jj = 0, 1) fill one fragment, so fragment slot (hi, e) of chunk c is
+//     y = 16 c + 2 hi + (e >> 2) + 4 (e & 3)
+// — and the S / G accumulators must deliver P / dS in that order: the row-major fragment reads take tile row bwd_tr_row(i) for MFMA row i
+// (C layout: register r of lane-half hi is row (r & 3) + 8 (r >> 2) + 4 hi), which makes registers 8 c' + e of a 32-row half exactly
+// slot e of chunk c'.  Conflict-free for ds_read_b128 as well: the 16 lanes of a service group read rows that are distinct mod 16.
+M4D_DEV int bwd_tr_row(int i) { return (i & 16) | ((i & 3) << 2) | ((i >> 1) & 2) | ((i >> 3) & 1); }
+// byte offset (inside a row-major [64][128] bf16 tile, chunk c = 0) of the piece lane (li, hi) supplies for read jj of d-block dd
+M4D_DEV unsigned bwd_tr_addr(int li, int hi, int jj, int dd) {
+    const int g = li >> 4, s = li & 15;
+    const int row = 2 * hi + jj + 4 * (s >> 2);
+    const int chunk = (4 * dd + 2 * g + ((s >> 1) & 1)) ^ row;
+    return (unsigned)(row * 256 + chunk * 16 + (s & 1) * 8);
+}
+// statistics (lse / delta of a tile's 64 y) sit in LDS in accumulator-register order: position 32 half + 16 c + 8 hi + e holds y =
+M4D_DEV int bwd_tr_stat(int pos) { return (pos & 48) | (((pos >> 3) & 1) << 1) | ((pos >> 2) & 1) | ((pos & 3) << 2); }
+template <int OFF> M4D_DEV void bwd_tr_read(bf16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+M4D_DEV bf16x8 bwd_tr_join(const bf16x4& lo, const bf16x4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
 template <int MODE, int SMX>   // SMX: 1 = single-issue fp32 VALU forms in the elementwise step (default), 0 = packed v_pk_*_f32 (A/B)
 __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
     typedef bf16_t T;
     constexpr int D = 128, YB = 64, XB = 256;
     constexpr bool HAS_G = MODE != BWD_DV;
     constexpr bool STAT_Y = MODE != BWD_DQ;
-    constexpr int T1 = 16384;                          // second row-major tile (G operand)
-    constexpr int T2 = HAS_G ? 32768 : 16384;          // transposed tile (accumulate operand)
-    constexpr int STAT_OFF = T2 + 16384;
+    constexpr int T1 = 16384;                          // second row-major tile (G operand; dV: the accumulate operand dO)
+    constexpr int TT = MODE == BWD_DV ? T1 : 0;        // tile the transposing reads of the accumulate product go to (K / Q / dO)
+    constexpr int STAT_OFF = 32768;
     constexpr int STAGE = STAT_OFF + (STAT_Y ? 512 : 0);
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
+    constexpr int NST = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST * STAGE
 
     const int HB = p.heads * p.B;
     int xt, hb;
@@ -78,122 +109,109 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
         for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
     // absolute LDS addresses of this lane's fragments in the CURRENT stage; toggled by +-STAGE after every tile
-    unsigned ka[8], va[4];
+    unsigned ka[8], ta[2][4];
     {
         const unsigned lds0 = (unsigned)(uintptr_t)(LDS_AS char*)smem;
-        const int kr = perm23(li);
+        const int kr = bwd_tr_row(li);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ka[kk] = lds0 + kr * 256 + (((kk * 2 + hi) ^ (kr & 15)) << 4);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) va[c] = lds0 + T2 + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) ta[jj][dd] = lds0 + TT + bwd_tr_addr(li, hi, jj, dd);
     }
     const int k_r = lane >> 4, k_lc0 = lane & 15;     // row-major tile DMA: 4 rows x 256 B per instruction
-    const int v_r = lane >> 3, v_pc = lane & 7;       // transposed tile DMA: 8 rows x 128 B per instruction
 
     const T* gya = (const T*)p.ya + b * p.ya_bs + (int64_t)h * D;
-    const T* gyb = HAS_G ? (const T*)p.yb + b * p.yb_bs + (int64_t)h * D : nullptr;
-    const T* gyt = (const T*)p.yat + b * p.yat_bs + (int64_t)h * D * p.yat_ls;
+    const T* gyb = (const T*)p.yb + b * p.yb_bs + (int64_t)h * D;
     const float* glse = p.lse + ((int64_t)b * p.heads + h) * p.Lq;
     const float* gdel = p.delta + ((int64_t)b * p.heads + h) * p.Lq;
 
     // tile request: scalar bases + per-lane 32-bit offsets, in two parts so that the loop can spread the instructions over the first
     // MFMAs of a tile (round 4: issued back to back at the top of the tile, the 8 waves' requests queue on the CU's one texture-address
     // unit with every wave stuck behind its own — measured on the fused dK / dV kernel below: 6 ms of a 25 ms pass)
-    unsigned oya[2], oyb[2], oyt[2];
+    unsigned oya[2], oyb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int blk = (t >> 6) * 2 + i;
-        const int row = blk * 4 + k_r, trow = blk * 8 + v_r;
+        const int row = blk * 4 + k_r;
         oya[i] = (unsigned)((row * p.ya_ls + (k_lc0 ^ (row & 15)) * 8) * 2);
-        oyb[i] = HAS_G ? (unsigned)((row * p.yb_ls + (k_lc0 ^ (row & 15)) * 8) * 2) : 0u;
-        oyt[i] = (unsigned)((trow * p.yat_ls + (v_pc ^ ((trow >> 1) & 7)) * 8) * 2);
+        oyb[i] = (unsigned)((row * p.yb_ls + (k_lc0 ^ (row & 15)) * 8) * 2);
     }
     auto uniform_ptr = [](const char* q) {
         const unsigned long long v = (unsigned long long)q;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return (const char*)(((unsigned long long)hi2 << 32) | lo);
     };
-    const char *dya_b = nullptr, *dyb_b = nullptr, *dyt_b = nullptr;
+    const char *dya_b = nullptr, *dyb_b = nullptr;
     unsigned d_dst = 0;
     const unsigned lds0_ = (unsigned)(uintptr_t)(LDS_AS char*)smem;
     auto dma_prepare = [&](int stage, int64_t y0) {
         dya_b = uniform_ptr((const char*)(gya + y0 * p.ya_ls));
-        if constexpr (HAS_G) dyb_b = uniform_ptr((const char*)(gyb + y0 * p.yb_ls));
-        dyt_b = uniform_ptr((const char*)(gyt + y0));
+        dyb_b = uniform_ptr((const char*)(gyb + y0 * p.yb_ls));
         d_dst = __builtin_amdgcn_readfirstlane(lds0_ + stage * STAGE + wave * 2048);
     };
 #define M4D_BGLDS(DST, VOFF, SRC) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(DST), "v"(VOFF), "s"(SRC) : "memory", "m0")
-    auto dma_one = [&](int n) {          // n = 0..5, a literal at every call site
+    auto dma_one = [&](int n) {          // n = 0..3, a literal at every call site: FOUR instructions per wave and tile (the counted waits rely on it)
         if (n == 0) M4D_BGLDS(d_dst, oya[0], dya_b);
-        else if (n == 1) M4D_BGLDS(d_dst + T2, oyt[0], dyt_b);
+        else if (n == 1) M4D_BGLDS(d_dst + T1, oyb[0], dyb_b);
         else if (n == 2) M4D_BGLDS(d_dst + 1024, oya[1], dya_b);
-        else if (n == 3) M4D_BGLDS(d_dst + T2 + 1024, oyt[1], dyt_b);
-        else if (n == 4) { if constexpr (HAS_G) M4D_BGLDS(d_dst + T1, oyb[0], dyb_b); }
-        else { if constexpr (HAS_G) M4D_BGLDS(d_dst + T1 + 1024, oyb[1], dyb_b); }
+        else M4D_BGLDS(d_dst + T1 + 1024, oyb[1], dyb_b);
     };
     auto dma_tile = [&](int stage, int64_t y0) {
         dma_prepare(stage, y0);
-        dma_one(0); dma_one(1); dma_one(2); dma_one(3); dma_one(4); dma_one(5);
+        dma_one(0); dma_one(1); dma_one(2); dma_one(3);
     };
     auto reg_tile = [&](int stage, int64_t y0) {      // ragged last tile: zero filled, synchronous
         char* base = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = t + 512 * i;
-            {
-                const int row = c >> 4, ch = c & 15;
-                const int64_t y = y0 + row;
-                const bool ok = y < p.LY;
-                *reinterpret_cast<uint4*>(base + swz_off<256>(row, ch)) =
-                    ok ? *reinterpret_cast<const uint4*>(gya + y * p.ya_ls + ch * 8) : make_uint4(0, 0, 0, 0);
-                if constexpr (HAS_G)
-                    *reinterpret_cast<uint4*>(base + T1 + swz_off<256>(row, ch)) =
-                        ok ? *reinterpret_cast<const uint4*>(gyb + y * p.yb_ls + ch * 8) : make_uint4(0, 0, 0, 0);
-            }
-            {
-                const int row = c >> 3, ch = c & 7;
-                const int64_t y = y0 + ch * 8;
-                const T* src = gyt + row * p.yat_ls + y;
-                union { uint4 u; T e[8]; } tmp;
-                tmp.u = make_uint4(0, 0, 0, 0);
-                if (y + 8 <= p.LY) tmp.u = *reinterpret_cast<const uint4*>(src);
-                else if (y < p.LY) {
-                    for (int j = 0; j < 8; ++j)
-                        if (y + j < p.LY) tmp.e[j] = src[j];
-                }
-                *reinterpret_cast<uint4*>(base + T2 + swz_off<128>(row, ch)) = tmp.u;
-            }
+            const int row = c >> 4, ch = c & 15;
+            const int64_t y = y0 + row;
+            const bool ok = y < p.LY;
+            *reinterpret_cast<uint4*>(base + swz_off<256>(row, ch)) =
+                ok ? *reinterpret_cast<const uint4*>(gya + y * p.ya_ls + ch * 8) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(base + T1 + swz_off<256>(row, ch)) =
+                ok ? *reinterpret_cast<const uint4*>(gyb + y * p.yb_ls + ch * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto load_stat = [&](int64_t y0) -> float {       // threads 0..63: lse, 64..127: delta of row y0 + (t & 63)
+    auto load_stat = [&](int64_t y0) -> float {       // threads 0..63: lse, 64..127: delta; LDS position t & 63 holds row bwd_tr_stat(t & 63)
         if (!STAT_Y || t >= 128) return 0.f;
-        const int64_t y = y0 + (t & 63);
+        const int64_t y = y0 + bwd_tr_stat(t & 63);
         if (y >= p.LY) return t < 64 ? INFINITY : 0.f;   // lse = +inf => probability exactly 0
         return t < 64 ? glse[y] : gdel[y];
     };
 
     const int64_t y_begin = p.ws ? (int64_t)blockIdx.y * p.y_chunk : 0;
     const int64_t y_end = p.ws ? (y_begin + p.y_chunk < p.LY ? y_begin + p.y_chunk : p.LY) : p.LY;
-    bool cur_dma = y_begin + YB <= p.LY;
-    if (cur_dma && y_begin < y_end) dma_tile(0, y_begin);
+    // NST stages: tile it + NST - 1 is requested while tile it is computed (first version: two stages, vmcnt(0) in front of every tile).
+    // Full tiles travel by DMA, four instructions per wave and tile; a ragged last tile of the key / query range is staged synchronously.
+    const int NT = y_begin < y_end ? (int)((y_end - y_begin + YB - 1) / YB) : 0;
+    const int NF = p.LY - y_begin >= 0 ? (int)((p.LY - y_begin) / YB < NT ? (p.LY - y_begin) / YB : NT) : 0;      // full (DMA) tiles of this chunk
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j)
+        if (j < NF) dma_tile(j, y_begin + (int64_t)j * YB);
     float rstat = load_stat(y_begin);
-    int it = 0;
-    for (int64_t y0 = y_begin; y0 < y_end; y0 += YB, ++it) {
-        const int stage = it & 1;
+    int stage = 0;
+    for (int it = 0; it < NT; ++it) {
+        const int64_t y0 = y_begin + (int64_t)it * YB;
         if (STAT_Y && t < 128) reinterpret_cast<float*>(smem + stage * STAGE + STAT_OFF)[t] = rstat;
-        if (cur_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else reg_tile(stage, y0);
+        if (it < NF) {
+            const int younger = NF - 1 - it;          // requested tiles behind this one: min(younger, NST - 2) x 4 instructions may stay in flight
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else reg_tile(stage, y0);
         __syncthreads();
-        const int64_t ny0 = y0 + YB;
-        bool next_dma = false;
-        if (ny0 < y_end) {
-            next_dma = ny0 + YB <= p.LY;
-            if (next_dma) dma_prepare(stage ^ 1, ny0);
-            rstat = load_stat(ny0);
-        }
+        const bool next_dma = it + NST - 1 < NF;
+        if (next_dma) dma_prepare(stage == 0 ? NST - 1 : stage - 1, y0 + (int64_t)(NST - 1) * YB);
+        if (it + 1 < NT) rstat = load_stat(y0 + YB);
 #define M4D_BDMA(N) do { if (next_dma) dma_one(N); __builtin_amdgcn_sched_barrier(0); } while (0)
 
         bf16x8 fb0, fb1, fb2, fb3;
+        bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;      // transposed fragments: two ds_read_b64_tr_b16 each (chunk C = immediate offset)
+#define M4D_TR(F, C, DD) do { bwd_tr_read<(C) * 4096>(F##l, ta[0][DD]); bwd_tr_read<(C) * 4096>(F##h, ta[1][DD]); } while (0)
         bf16x8 pf[4];
         const float* st = reinterpret_cast<const float*>(smem + stage * STAGE + STAT_OFF);
 #define M4D_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
                     if constexpr (STAT_Y) {
                         if (!xvalid) pv = 0.f;
                     } else {
-                        if (y0 + yb + j >= p.LY) pv = 0.f;
+                        if (y0 + bwd_tr_stat(yb + j) >= p.LY) pv = 0.f;
                     }
                     out[j] = (T)pv;
                 }
@@ -269,8 +287,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
                 if constexpr (STAT_Y) {
                     if (!xvalid) pv = f32x2{0.f, 0.f};
                 } else {
-                    if (y0 + yb + j >= p.LY) pv[0] = 0.f;
-                    if (y0 + yb + j + 1 >= p.LY) pv[1] = 0.f;
+                    if (y0 + bwd_tr_stat(yb + j) >= p.LY) pv[0] = 0.f;
+                    if (y0 + bwd_tr_stat(yb + j + 1) >= p.LY) pv[1] = 0.f;
                 }
                 if constexpr (HAS_G) {
                     f32x2 nd;
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
         M4D_DSR(fb0, ka[0], SO); M4D_DSR(fb1, ka[0], GO); M4D_DSR(fb2, ka[1], SO); M4D_DSR(fb3, ka[1], GO);          \
         M4D_SGS(fb0, 0, SO, 3); M4D_H(0, ON); M4D_SGG(fb1, 0, GO, 3); M4D_SGS(fb2, 1, SO, 3); M4D_H(1, ON); M4D_SGG(fb3, 1, GO, 3);  \
         M4D_SGS(fb0, 2, SO, 3); M4D_H(2, ON); M4D_SGG(fb1, 2, GO, 3); M4D_SGS(fb2, 3, SO, 3); M4D_H(3, ON); M4D_SGG(fb3, 3, GO, 3);  \
-        M4D_SGS(fb0, 4, SO, 3); M4D_H(4, ON); M4D_SGG(fb1, 4, GO, 3); M4D_SGS(fb2, 5, SO, 3); M4D_H(5, ON); M4D_SGG(fb3, 5, GO, 3);  \
+        M4D_SGS(fb0, 4, SO, 3); M4D_SGG(fb1, 4, GO, 3); M4D_SGS(fb2, 5, SO, 3); M4D_SGG(fb3, 5, GO, 3);  \
         M4D_SGS(fb0, 6, SO, 3); M4D_SGG(fb1, 6, GO, 2); M4D_SGS(fb2, 7, SO, 1); M4D_SGG(fb3, 7, GO, 0);              \
     } while (0)
             {
@@ -312,10 +330,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s1[r] = 0.f; g1[r] = 0.f; }
                 M4D_SUB(8192, 24576, false);
-                // the first four transposed-tile fragments land under the elementwise arithmetic
-                M4D_DSR(fb0, va[0], 0); M4D_DSR(fb1, va[0], 4096); M4D_DSR(fb2, va[0], 8192); M4D_DSR(fb3, va[0], 12288);
+                // the first four transposed fragments land under the elementwise arithmetic (dK pass: behind it — with the tile statistics
+                // in registers as well the early request spills)
+                if constexpr (!STAT_Y) { M4D_TR(t0, 0, 0); M4D_TR(t1, 0, 1); M4D_TR(t2, 0, 2); M4D_TR(t3, 0, 3); }
                 pf[2] = elementwise(s1, g1, 1, 0);
                 pf[3] = elementwise(s1, g1, 1, 1);
+                if constexpr (STAT_Y) { M4D_TR(t0, 0, 0); M4D_TR(t1, 0, 1); M4D_TR(t2, 0, 2); M4D_TR(t3, 0, 3); }
             }
 #undef M4D_SUB
 #undef M4D_H
@@ -334,27 +354,30 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
             M4D_QK(fb0, 4, 0, 0, 3); M4D_QK(fb1, 4, 1, 8192, 3); M4D_QK(fb2, 5, 0, 0, 3); M4D_QK(fb3, 5, 1, 8192, 3);
             M4D_QK(fb0, 6, 0, 0, 3); M4D_QK(fb1, 6, 1, 8192, 2); M4D_QK(fb2, 7, 0, 0, 1); M4D_QK(fb3, 7, 1, 8192, 0);
 #undef M4D_QK
-            M4D_DSR(fb0, va[0], 0); M4D_DSR(fb1, va[0], 4096); M4D_DSR(fb2, va[0], 8192); M4D_DSR(fb3, va[0], 12288);
+            M4D_TR(t0, 0, 0); M4D_TR(t1, 0, 1); M4D_TR(t2, 0, 2); M4D_TR(t3, 0, 3);
 #pragma unroll
             for (int c = 0; c < 4; ++c) pf[c] = elementwise(s[c >> 1], s[c >> 1], c >> 1, c & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- acc^T += (transposed Y tile) . pf ----  16 (c, d) steps, fragments 4 steps ahead
-#define M4D_PV(B, C, DD, OFF, W) do { M4D_LGKM(W); mma32(B, pf[C], acc[DD]); if ((C) + 1 < 4) M4D_DSR(B, va[((C) + 1) & 3], OFF); } while (0)
-        M4D_PV(fb0, 0, 0, 0, 3); M4D_PV(fb1, 0, 1, 4096, 3); M4D_PV(fb2, 0, 2, 8192, 3); M4D_PV(fb3, 0, 3, 12288, 3);
-        M4D_PV(fb0, 1, 0, 0, 3); M4D_PV(fb1, 1, 1, 4096, 3); M4D_PV(fb2, 1, 2, 8192, 3); M4D_PV(fb3, 1, 3, 12288, 3);
-        M4D_PV(fb0, 2, 0, 0, 3); M4D_PV(fb1, 2, 1, 4096, 3); M4D_PV(fb2, 2, 2, 8192, 3); M4D_PV(fb3, 2, 3, 12288, 3);
-        M4D_PV(fb0, 3, 0, 0, 3); M4D_PV(fb1, 3, 1, 4096, 2); M4D_PV(fb2, 3, 2, 8192, 1); M4D_PV(fb3, 3, 3, 12288, 0);
+        // ---- acc^T += (Y tile)^T . pf ----  16 (c, d) steps, four fragments = eight transposing reads ahead
+#define M4D_PV(F, C, DD, W) do { M4D_LGKM(W); mma32(bwd_tr_join(F##l, F##h), pf[C], acc[DD]); } while (0)
+        M4D_PV(t0, 0, 0, 6); M4D_TR(t0, 1, 0); M4D_PV(t1, 0, 1, 6); M4D_TR(t1, 1, 1); M4D_PV(t2, 0, 2, 6); M4D_TR(t2, 1, 2); M4D_PV(t3, 0, 3, 6); M4D_TR(t3, 1, 3);
+        M4D_PV(t0, 1, 0, 6); M4D_TR(t0, 2, 0); M4D_PV(t1, 1, 1, 6); M4D_TR(t1, 2, 1); M4D_PV(t2, 1, 2, 6); M4D_TR(t2, 2, 2); M4D_PV(t3, 1, 3, 6); M4D_TR(t3, 2, 3);
+        M4D_PV(t0, 2, 0, 6); M4D_TR(t0, 3, 0); M4D_PV(t1, 2, 1, 6); M4D_TR(t1, 3, 1); M4D_PV(t2, 2, 2, 6); M4D_TR(t2, 3, 2); M4D_PV(t3, 2, 3, 6); M4D_TR(t3, 3, 3);
+        M4D_PV(t0, 3, 0, 6); M4D_PV(t1, 3, 1, 4); M4D_PV(t2, 3, 2, 2); M4D_PV(t3, 3, 3, 0);
 #undef M4D_PV
+#undef M4D_TR
 #undef M4D_LGKM
 #undef M4D_DSR
 #undef M4D_BDMA
-        cur_dma = next_dma;
-        const unsigned dl = stage ? (unsigned)-STAGE : (unsigned)STAGE;
+        const unsigned dl = stage == NST - 1 ? (unsigned)(-(NST - 1) * STAGE) : (unsigned)STAGE;
+        stage = stage == NST - 1 ? 0 : stage + 1;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) ka[kk] += dl;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) va[c] += dl;
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) ta[jj][dd] += dl;
     }
 #undef M4D_BGLDS
 
@@ -410,34 +433,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd128_kernel(BwdArgs p) {
 //   * ONE workgroup barrier per tile (stage hand-over); the tile request is 8 x (s_mov m0 + global_load_lds) with scalar bases and
 //     per-lane 32-bit offsets computed once (no 64-bit VALU address arithmetic in the loop).
 // 128 key rows per workgroup (4 pairs x 32), 64-query Y tiles of (Q, dO, Q^T, dO^T) in two 64.5 KiB stages.
-// ---- transposed operands without transposed copies: ds_read_b64_tr_b16 (round 4) ----
-// The accumulate products need the Y tile transposed (dV^T += dO^T P^T, dK^T += Q^T dS^T, dQ^T += K^T dS^T): A fragment = 32 d rows x 16 y,
-// lane (i = d, hi) holding 8 y values of column d of the row-major tile.  gfx950's transposing LDS read does exactly that gather.
-// Semantics (probed, tools/probes/ds_read_tr.hip): within each group of 16 lanes, lane s supplies the address of one 8-byte piece =
-// row (s >> 2), column quad (s & 3) of a [4 rows][16 columns] block of 16-bit elements, and lane t receives column t of the block
-// (4 elements, rows 0..3).  The four rows of a block may be any four rows (each lane has its own address); here they are rows
-// y0, y0 + 4, y0 + 8, y0 + 12 of a 16-row chunk, because with the tile's XOR swizzle (16-byte chunk ^ (row & 15), applied on the DMA source
-// address) rows that differ in bits 2..3 and agree in bits 0..1 put their four chunks on 16 different bank slots: the 32 lanes serviced
-// per LDS cycle cover all 64 banks exactly once.  Two reads (jj = 0, 1) fill one fragment, so fragment slot (hi, e) of chunk c is
-//     y = 16 c + 2 hi + (e >> 2) + 4 (e & 3)
-// — and the S / G accumulators must deliver P / dS in that order: the row-major fragment reads take tile row bwd_tr_row(i) for MFMA row i
-// (C layout: register r of lane-half hi is row (r & 3) + 8 (r >> 2) + 4 hi), which makes registers 8 c' + e of a 32-row half exactly
-// slot e of chunk c'.  Conflict-free for ds_read_b128 as well: the 16 lanes of a service group read rows that are distinct mod 16.
-M4D_DEV int bwd_tr_row(int i) { return (i & 16) | ((i & 3) << 2) | ((i >> 1) & 2) | ((i >> 3) & 1); }
-// byte offset (inside a row-major [64][128] bf16 tile, chunk c = 0) of the piece lane (li, hi) supplies for read jj of d-block dd
-M4D_DEV unsigned bwd_tr_addr(int li, int hi, int jj, int dd) {
-    const int g = li >> 4, s = li & 15;
-    const int row = 2 * hi + jj + 4 * (s >> 2);
-    const int chunk = (4 * dd + 2 * g + ((s >> 1) & 1)) ^ row;
-    return (unsigned)(row * 256 + chunk * 16 + (s & 1) * 8);
-}
-// statistics (lse / delta of a tile's 64 y) sit in LDS in accumulator-register order: position 32 half + 16 c + 8 hi + e holds y =
-M4D_DEV int bwd_tr_stat(int pos) { return (pos & 48) | (((pos >> 3) & 1) << 1) | ((pos >> 2) & 1) | ((pos & 3) << 2); }
-template <int OFF> M4D_DEV void bwd_tr_read(bf16x4& dst, unsigned addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-M4D_DEV bf16x8 bwd_tr_join(const bf16x4& lo, const bf16x4& hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
-
 #ifndef BKV_NST
 #define BKV_NST 4      // Y-tile stages of the fused dK / dV pass (tile i + NST - 1 is requested while tile i is computed)
 #endif
@@ -805,16 +800,16 @@ inline int launch_bwd_kv128(const BwdArgs& p, hipStream_t st) {
 template <int MODE>
 int launch_bwd128(const BwdArgs& p, hipStream_t st, int nsplit) {
     M4D_ENV_ONCE(smx, "M4D_ATTN_BWD_SMX", 1);
-    constexpr int STAGE = (MODE == BWD_DV ? 32768 : 49152) + (MODE == BWD_DQ ? 0 : 512);
+    constexpr int LDS = 4 * (32768 + (MODE == BWD_DQ ? 0 : 512));
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return -3;
-        hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        if (hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         configured = true;
     }
     dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B), (unsigned)nsplit), block(512);
-    if (smx == 1) hipLaunchKernelGGL((attn_bwd128_kernel<MODE, 1>), grid, block, 2 * STAGE, st, p);
-    else hipLaunchKernelGGL((attn_bwd128_kernel<MODE, 0>), grid, block, 2 * STAGE, st, p);
+    if (smx == 1) hipLaunchKernelGGL((attn_bwd128_kernel<MODE, 1>), grid, block, LDS, st, p);
+    else hipLaunchKernelGGL((attn_bwd128_kernel<MODE, 0>), grid, block, LDS, st, p);
     return 0;
 }

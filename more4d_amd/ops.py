@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/more4d_hip.h).  torch supplies device memory and the
 current HIP stream; every arithmetic op below runs in a hand-written gfx950 kernel.  No fallback."""
 import math
+import os
 
 import torch
 
@@ -929,11 +930,15 @@ def attention_bwd(q, k, v, o, d_o, lse, *, B, Lq, Lk, Lk_rows, heads, head_dim, 
             raise TypeError("attention_bwd: operands must share a dtype and be row-major")
         if t.dim() != 2 or t.shape[1] != C:
             raise ValueError("attention_bwd: operands are 2-D [rows, heads*head_dim] matrices")
-    qt, kt, dot = transpose(q), transpose(k), transpose(d_o)
+    # The bf16 / head_dim 128 passes (csrc/attention_bwd128.h, attention_bwd_kvp.h) read their transposed operands out of the row-major
+    # tiles; only the generic kernels (fp32 parity mode, other head dims, M4D_ATTN_BWD_GENERIC=1) want transposed copies of Q, K, dO.
+    need_t = not (q.dtype == torch.bfloat16 and head_dim == 128) or os.environ.get("M4D_ATTN_BWD_GENERIC", "0") not in ("", "0")
+    qt, kt, dot = (transpose(q), transpose(k), transpose(d_o)) if need_t else (None, None, None)
     delta = torch.empty((B, heads, Lq), device=q.device, dtype=torch.float32)
     a = _lib.AttnBwdArgs()
     a.q, a.k, a.v, a.o, a.d_o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr()
-    a.qt, a.kt, a.dot, a.lse, a.delta = qt.data_ptr(), kt.data_ptr(), dot.data_ptr(), lse.data_ptr(), delta.data_ptr()
+    a.qt, a.kt, a.dot = (qt.data_ptr(), kt.data_ptr(), dot.data_ptr()) if need_t else (0, 0, 0)
+    a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
     a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
 
     def st(t, L):
