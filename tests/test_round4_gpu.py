@@ -450,3 +450,25 @@ def test_gemm_persistent_sync_poll_path_and_two_streams():
         outs += [o1, o2]
     torch.cuda.synchronize()
     assert all(torch.equal(o, ref) for o in outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W", [(128, 40, 72), (64, 33, 40), (256, 24, 48)])
+def test_groupnorm_planar_store_path_equals_channels_last(C, H, W):
+    """groupnorm_apply_kernel's planar-16 output goes through a wave-local LDS transpose (full runs of a plane per store instruction);
+    blocks that are not full and the rows behind them take the direct stores.  Both must be the channels-last result, bit for bit."""
+    from more4d_amd import ops as o
+    F, HW = 5, H * W
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(F, HW, C, generator=g).bfloat16().to(DEV)
+    gw, gb = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    G = C // 8                                                                   # (channels per group must be a multiple of 4)
+    ref = o.groupnorm_cl(x, gw, gb, F=F, HW=HW, groups=G, silu=True)             # [F, HW, C]
+    parts = o.groupnorm_cl_planar(x, gw, gb, F=F, HW=HW, groups=G, frames_per_group=2)
+    f0 = 0
+    for pl in parts:
+        t = pl.t                                                                 # [C/16, frames, HW, 16]
+        got = t.permute(1, 2, 0, 3).reshape(t.shape[1], HW, C)
+        assert torch.equal(got, ref[f0:f0 + t.shape[1]])
+        f0 += t.shape[1]
+    assert f0 == F
