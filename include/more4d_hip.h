@@ -418,6 +418,11 @@ int m4d_adamw(m4d_dtype dt, void* param, const void* grad, m4d_dtype state_dt, v
  *   A + i1*a_bs1 + i2*a_bs2 elements with row stride lda, W likewise; i1 < nb1, i2 < nb2.
  * wgrad_reduce: dw[co][dt][dh][dw][ci] += sum_s part[dh][s][co][dw*cip + ci]; part float32 [kh, S, Mp, kw*cip], dw float32
  *   [cop, kt, kh, kw, cip] (the packed weight layout of m4d_conv_cl).
+ * gemm_bt_taps (bf16; the same weight gradient on the production 256 x 256 kernel, for Cout %% 32 == 0 and kw*cip >= 256): float32
+ *   out[s] [M, N] = A_s [M,K] . W_s [N,K]^T for K-slice s < nb1 (A_s = A + s*a_bs1, W_s = W + s*w_bs1 elements), where the
+ *   M = taps * tap_rows rows of A are STACKED TAPS: rows [t*tap_rows, (t+1)*tap_rows) are rows [0, tap_rows) of the matrix at A read
+ *   tap_s1*(t / tap_kh) + tap_s2*(t %% tap_kh) elements further along K — dy is the shifted operand, all kt*kh taps of a layer are
+ *   one launch.  wgrad_reduce_taps: dw[co][dt][dh][dw][ci] += sum_s part[s][dt*kh + dh][co][dw*cip + ci].
  * rmsnorm_silu_cl_bwd: backward of m4d_rmsnorm_silu_cl (wan_vae.py:43-58 + SiLU): dx T [P, C], dgamma float32 [C] (+=).
  * softmax_rows_bwd: dS = scale * P * (dP - rowsum(P dP)) on [rows, Cpad] (columns >= C written as 0): mid-block attention :244-266.
  * upsample2x_cl: nearest-exact 2x of channels-last frames [t,h,w,c] -> [t',2h,2w,c] (tsplit: input pixels hold 2c channels and
@@ -430,6 +435,9 @@ int m4d_pad_transpose(m4d_dtype dt, const void* src, int64_t pixel_stride, int C
 int m4d_gemm_bt_batched(m4d_dtype dt, const void* A, int64_t lda, int64_t a_bs1, int64_t a_bs2, const void* W, int64_t ldw,
                         int64_t w_bs1, int64_t w_bs2, float* out, int64_t M, int64_t N, int64_t K, int nb1, int nb2, m4d_stream stream);
 int m4d_wgrad_reduce(const float* part, float* dw, int S, int Mp, int cop, int kt, int kh, int kw, int cip, int dt, m4d_stream stream);
+int m4d_gemm_bt_taps(m4d_dtype dt, const void* A, int64_t lda, int64_t a_bs1, const void* W, int64_t ldw, int64_t w_bs1, float* out,
+                     int64_t M, int64_t N, int64_t K, int nb1, int tap_rows, int tap_kh, int64_t tap_s1, int64_t tap_s2, m4d_stream stream);
+int m4d_wgrad_reduce_taps(const float* part, float* dw, int S, int cop, int kt, int kh, int kw, int cip, m4d_stream stream);
 int m4d_rmsnorm_silu_cl_bwd(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, const void* dy, int64_t dy_ld, void* dx,
                             int64_t dx_ld, float* dgamma, int64_t P, int C, int silu, m4d_stream stream);
 int m4d_softmax_rows_bwd(m4d_dtype dt, const void* p, const float* dp, void* out, int64_t rows, int C, int Cpad, float scale,

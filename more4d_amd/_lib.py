@@ -89,6 +89,9 @@ SIGNATURES = {
     "m4d_gemm_bt_batched": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
                                     c_int64, c_int64, c_int, c_int, c_void_p]),
     "m4d_wgrad_reduce": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "m4d_gemm_bt_taps": (c_int, [c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                 c_int, c_int, c_int64, c_int64, c_void_p]),
+    "m4d_wgrad_reduce_taps": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "m4d_rmsnorm_silu_cl_bwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                         c_int, c_void_p]),
     "m4d_softmax_rows_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),

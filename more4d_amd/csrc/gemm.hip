@@ -24,6 +24,7 @@ extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_store(
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_gelu(const void* args, unsigned nwg, hipStream_t st);
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_resid(const void* args, unsigned nwg, hipStream_t st);
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_f32(const void* args, unsigned nwg, hipStream_t st);
+extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_f32_batched(const void* args, unsigned nwg, unsigned nby, hipStream_t st);
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_store_persistent(const void* args, unsigned nwg, unsigned ncu, hipStream_t st);
 extern "C" __attribute__((visibility("hidden"))) int m4d_launch_gemm_wide_gelu_persistent(const void* args, unsigned nwg, unsigned ncu, hipStream_t st);
 
@@ -576,7 +577,7 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.gate_stride = gate_stride; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : M;
     p.epilogue = epilogue; p.bias_on_m = bias_on_m;
-    p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0;
+    p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0; p.tap_rows = p.tap_kh = 0; p.tap_s1 = p.tap_s2 = 0;
     p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
     p.abl = 0; p.sync = nullptr;
 #ifdef M4D_ABLATIONS
@@ -730,11 +731,48 @@ extern "C" int m4d_gemm_bt_batched(m4d_dtype dt, const void* A, int64_t lda, int
     p.lda = lda; p.ldw = ldw; p.ldc = N; p.M = M; p.N = N; p.K = K;
     p.gate_stride = 0; p.rows_per_sample = M; p.epilogue = M4D_EPI_STORE_F32; p.bias_on_m = 0;
     p.nb1 = nb1; p.a_bs1 = a_bs1; p.a_bs2 = a_bs2; p.w_bs1 = w_bs1; p.w_bs2 = w_bs2; p.abl = 0; p.sync = nullptr;
+    p.tap_rows = p.tap_kh = 0; p.tap_s1 = p.tap_s2 = 0;
     p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
     p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(nb1 * nb2)), block(256);
     if (dt == M4D_BF16) hipLaunchKernelGGL(gemm_bt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_bt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
     M4D_CHECK_LAUNCH("gemm_bt_batched");
+    return 0;
+}
+
+// The conv weight gradient on the production kernel: out[s] (float32 [M, N], unrounded) = A_s [M, K] . W_s [N, K]^T for K-slice s of nb1
+// (A_s = A + s * a_bs1, W_s = W + s * w_bs1 elements), where the M = taps * tap_rows rows of A are STACKED TAPS: rows [t * tap_rows,
+// (t + 1) * tap_rows) are rows [0, tap_rows) of the matrix at A, read tap_s1 * (t / tap_kh) + tap_s2 * (t % tap_kh) elements further
+// along K.  dW[(dt, dh, co), (dw, ci)] = sum_p dy[p, co] x[p + tap(dt, dh) + dw, ci] contracts over pixels; with dy as the shifted
+// operand all kt * kh taps of a layer are ONE launch whose M (864 .. 3456) fills 256-row tiles — the generic 128 x 128 kernel ran one
+// batch element per tap at M = Cout (96 .. 384) and 290 TF (more4d_amd/vae_autograd.py:conv_wgrad, train_vae.py:173-187).
+extern "C" int m4d_gemm_bt_taps(m4d_dtype dt, const void* A, int64_t lda, int64_t a_bs1, const void* W, int64_t ldw, int64_t w_bs1, float* out,
+                                int64_t M, int64_t N, int64_t K, int nb1, int tap_rows, int tap_kh, int64_t tap_s1, int64_t tap_s2,
+                                m4d_stream stream) {
+    M4D_CHECK_ARG(dt == M4D_BF16, "gemm_bt_taps: bf16 only");
+    M4D_CHECK_ARG(A && W && out && nb1 > 0 && nb1 <= 65535, "gemm_bt_taps: null/empty");
+    M4D_CHECK_ARG(M >= 256 && N >= 256 && K >= 128 && K % 64 == 0 && N % 4 == 0, "gemm_bt_taps: M, N >= 256, K %% 64 == 0 (M=%lld N=%lld K=%lld)",
+                  (long long)M, (long long)N, (long long)K);
+    M4D_CHECK_ARG(tap_rows > 0 && tap_rows % 32 == 0 && M % tap_rows == 0 && tap_kh > 0 && (M / tap_rows) % tap_kh == 0,
+                  "gemm_bt_taps: M must be whole taps of tap_rows (a multiple of 32) rows");
+    M4D_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && a_bs1 % 8 == 0 && w_bs1 % 8 == 0 && tap_s1 % 8 == 0 && tap_s2 % 8 == 0,
+                  "gemm_bt_taps: strides and tap offsets must keep rows 16-byte aligned");
+    M4D_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 32) == 0, "gemm_bt_taps: pointer alignment");
+    GemmArgs p;
+    p.A = A; p.W = W; p.bias = nullptr; p.out = out; p.gate = nullptr;
+    p.lda = lda; p.ldw = ldw; p.ldc = N; p.M = M; p.N = N; p.K = K;
+    p.gate_stride = 0; p.rows_per_sample = M; p.epilogue = M4D_EPI_STORE_F32; p.bias_on_m = 0;
+    p.nb1 = nb1; p.a_bs1 = a_bs1; p.a_bs2 = 0; p.w_bs1 = w_bs1; p.w_bs2 = 0; p.abl = 0; p.sync = nullptr;
+    p.tap_rows = tap_rows; p.tap_kh = tap_kh; p.tap_s1 = tap_s1; p.tap_s2 = tap_s2;
+    p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
+    p.tiles_m = (int)((M + BM2 - 1) / BM2); p.tiles_n = (int)((N + BN2 - 1) / BN2);
+    const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+    if (m4d_launch_gemm_wide_f32_batched(&p, (unsigned)nwg, (unsigned)nb1, (hipStream_t)stream) != 0) {
+        m4d_set_error("gemm_bt_taps: cannot enable 128 KiB LDS (wide kernel)");
+        return -3;
+    }
+    M4D_CHECK_LAUNCH("gemm_bt_taps");
+    m4d_count_launch(M4D_KC_GEMM_WIDE);
     return 0;
 }

@@ -17,6 +17,10 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int64_t a_bs1, a_bs2, w_bs1, w_bs2;   // batched launches (gridDim.y = nb1 * nb2): element offsets of batch (i1, i2); out += batch * M * ldc
     int nb1;                               // 0 = not batched
+    // stacked taps (m4d_gemm_bt_taps, the conv weight gradient on the wide kernel): the M rows are tap_rows-row groups t = dt * tap_kh + dh
+    // of the SAME tap_rows rows of A, read tap_s1 * dt + tap_s2 * dh elements further along K (0 = off)
+    int tap_rows, tap_kh;
+    int64_t tap_s1, tap_s2;
     // split-K tail (m4d_gemm_bt_ws): the launch over the full tile rounds uses `remap_n` (< tiles_m*tiles_n) logical tiles; the tail
     // launch has ksplit > 0: block b computes K-slice b % ksplit of logical tile tile_base + b / ksplit into its float32 slab of `ws`
     int remap_n, tile_base, ksplit;

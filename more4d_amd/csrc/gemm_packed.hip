@@ -200,7 +200,7 @@ extern "C" int m4d_gemm_bt_packed(m4d_dtype dt, const void* A, int64_t lda, cons
     p.A = A; p.W = W; p.bias = bias; p.out = out; p.gate = gate;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.gate_stride = gate_stride; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : M;
-    p.epilogue = epilogue; p.bias_on_m = bias_on_m; p.abl = 0; p.sync = nullptr; p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0; p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
+    p.epilogue = epilogue; p.bias_on_m = bias_on_m; p.abl = 0; p.sync = nullptr; p.nb1 = 0; p.a_bs1 = p.a_bs2 = p.w_bs1 = p.w_bs2 = 0; p.tap_rows = p.tap_kh = 0; p.tap_s1 = p.tap_s2 = 0; p.remap_n = 0; p.tile_base = 0; p.ksplit = 0; p.ws = nullptr; p.tile_off = 0;
     p.tiles_m = (int)((M + PT - 1) / PT); p.tiles_n = (int)((N + PT - 1) / PT);
     const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
     M4D_CHECK_ARG(nwg < (1ll << 31), "gemm_bt_packed: too many tiles");

@@ -118,8 +118,10 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
             for (int e = 0; e < 4; ++e) { v0[e] = gelu_tanh_f(v0[e]); v1[e] = gelu_tanh_f(v1[e]); }
         }
         if constexpr (F32OUT) {
+            if (EPI != M4D_EPI_STORE_F32 || !p.nb1) {      // (batched split-K partial sums keep their float32 accumulators)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = round_through<T>(v0[e]); v1[e] = round_through<T>(v1[e]); }
+                for (int e = 0; e < 4; ++e) { v0[e] = round_through<T>(v0[e]); v1[e] = round_through<T>(v1[e]); }
+            }
             float* drow = (float*)p.out + m * p.ldc;
             if constexpr (EPI == M4D_EPI_RESID_GATE) {
                 if (p.gate) {
@@ -215,6 +217,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
     static_assert(!PERSIST || ((EPI == M4D_EPI_STORE || EPI == M4D_EPI_GELU_TANH) && ABL == 0), "persistent form: bf16 epilogues, no ablations");
     unsigned long long ts[6];
     if constexpr (ABL & 64) { ts[0] = __builtin_readcyclecounter(); ts[5] = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr (!PERSIST && EPI == M4D_EPI_STORE_F32) {
+        // batched launch (m4d_gemm_bt_taps: the K-slices of a conv weight gradient): blockIdx.y moves both operands along K and the
+        // float32 output to its own [M, ldc] slab
+        if (p.nb1) {
+            p.A = (const char*)p.A + (int64_t)blockIdx.y * p.a_bs1 * 2;
+            p.W = (const char*)p.W + (int64_t)blockIdx.y * p.w_bs1 * 2;
+            p.out = (float*)p.out + (int64_t)blockIdx.y * p.M * p.ldc;
+        }
+    }
     int tm, tn;
     int bid = blockIdx.x;
     tile_coords(p, tm, tn, bid);
@@ -246,7 +257,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
 #pragma unroll
     for (int jx = 0; jx < 8; ++jx) {
         const int row = (jx >> 2) * 128 + ((jx >> 1) & 1) * 64 + (jx & 1) * 32;     // jx = unit*4 + half*2 + (i & 1)
-        ra[jx] = uniform_ptr((const char*)p.A + ((PERSIST ? 0 : m0) + row) * p.lda * 2);
+        int64_t tap = 0;
+        if constexpr (!PERSIST && EPI == M4D_EPI_STORE_F32) {
+            // stacked taps: rows [t * tap_rows, (t + 1) * tap_rows) are the SAME tap_rows rows of A, shifted along K by tap (dt, dh) = (t / tap_kh,
+            // t % tap_kh); tap_rows is a multiple of 32, so a 32-row staging block never straddles two taps
+            if (p.tap_rows) {
+                const int64_t r = m0 + row;
+                const int t_ = (int)(r / p.tap_rows);
+                const int dt_ = t_ / p.tap_kh, dh_ = t_ - dt_ * p.tap_kh;
+                tap = (dt_ * p.tap_s1 + dh_ * p.tap_s2 - (int64_t)t_ * p.tap_rows * p.lda) * 2;
+            }
+        }
+        ra[jx] = uniform_ptr((const char*)p.A + ((PERSIST ? 0 : m0) + row) * p.lda * 2 + tap);
         rw[jx] = uniform_ptr((const char*)p.W + ((PERSIST ? 0 : n0) + row) * p.ldw * 2);
     }
     const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
 
 // launcher body shared by the per-epilogue translation units (gemm_wide_*.hip: one instantiation each, compiled in parallel)
 template <int EPI>
-int launch_gemm_wide(const GemmArgs& p, unsigned nwg, hipStream_t st) {
+int launch_gemm_wide(const GemmArgs& p, unsigned nwg, hipStream_t st, unsigned nby = 1) {
 #define W_LAUNCH(A)                                                                                                    \
     do {                                                                                                               \
         static bool configured = false;                                                                                \
@@ -547,7 +569,7 @@ int launch_gemm_wide(const GemmArgs& p, unsigned nwg, hipStream_t st) {
                 return -3;                                                                                             \
             configured = true;                                                                                         \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_bt256w_kernel<A, EPI>), dim3(nwg), dim3(256), 2 * W_BUF, st, p);                       \
+        hipLaunchKernelGGL((gemm_bt256w_kernel<A, EPI>), dim3(nwg, nby), dim3(256), 2 * W_BUF, st, p);                  \
     } while (0)
 #ifdef M4D_ABLATIONS
     if constexpr (EPI == M4D_EPI_STORE) {

@@ -95,6 +95,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     }
 }
 
+// part [S, kt*kh, cop, N] (m4d_gemm_bt_taps: every tap of the layer in one launch) -> dw[co][dt][dh][..] += sum over the K-slices
+__global__ __launch_bounds__(256) void wgrad_reduce_taps_kernel(const float* part, float* dw, int S, int cop, int taps, int64_t N) {
+    const int64_t total = (int64_t)cop * taps * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i % N;
+        const int t = (int)((i / N) % taps);
+        const int co = (int)(i / (N * taps));
+        const float* src = part + ((int64_t)t * cop + co) * N + n;
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += src[(int64_t)s * taps * cop * N];
+        dw[((int64_t)co * taps + t) * N + n] += acc;
+    }
+}
+
 // ------------------------------------------------------------------ RMS_norm (+SiLU) backward
 // y = silu?(round_T(x * sc * gamma)), sc = sqrt(C) / max(|x|, 1e-12):   a = du * gamma * sc,  dx = a - x * sum(a x) / |x|^2,
 // dgamma[c] += du[c] * x[c] * sc.   SW lanes per pixel, VPL 16-byte vectors per lane (as the forward kernel).
@@ -453,6 +467,14 @@ extern "C" int m4d_wgrad_reduce(const float* part, float* dw, int S, int Mp, int
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((int64_t)cop * kh * kw * cip)), dim3(256), 0, (hipStream_t)stream, part, dw, S, Mp,
                        cop, kt, kh, kw, cip, dt);
     M4D_CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}
+
+extern "C" int m4d_wgrad_reduce_taps(const float* part, float* dw, int S, int cop, int kt, int kh, int kw, int cip, m4d_stream stream) {
+    M4D_CHECK_ARG(part && dw && S > 0 && cop > 0 && kt > 0 && kh > 0 && kw > 0 && cip > 0, "wgrad_reduce_taps: bad arguments");
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(grid_for((int64_t)cop * kt * kh * kw * cip)), dim3(256), 0, (hipStream_t)stream, part, dw, S,
+                       cop, kt * kh, (int64_t)kw * cip);
+    M4D_CHECK_LAUNCH("wgrad_reduce_taps");
     return 0;
 }
 

@@ -679,6 +679,29 @@ def wgrad_reduce(part, dw, dt, M):
     return dw
 
 
+def gemm_bt_taps(a, w, *, M, N, K, nb1, a_bs1, w_bs1, tap_rows, tap_kh, tap_s1, tap_s2, a_off=0):
+    """float32 out[s] [M, N] = A_s . W_s^T on the production 256 x 256 kernel with the rows of A as stacked taps (m4d_gemm_bt_taps);
+    a_off: element offset of tap (0, 0) inside `a`'s rows."""
+    _dev(a, w)
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or a.stride(-1) != 1 or w.stride(-1) != 1:
+        raise TypeError("gemm_bt_taps: bf16 operands with contiguous rows")
+    out = torch.empty((nb1, M, N), device=a.device, dtype=torch.float32)
+    check(_lib.load().m4d_gemm_bt_taps(dt_code(a.dtype), a.data_ptr() + 2 * a_off, a.stride(0), a_bs1, _ptr(w), w.stride(0), w_bs1, _ptr(out),
+                                       M, N, K, nb1, tap_rows, tap_kh, tap_s1, tap_s2, _stream()), "m4d_gemm_bt_taps")
+    return out
+
+
+def wgrad_reduce_taps(part, dw):
+    """dw[co, dt, dh, dw_, ci] += sum_s part[s, dt*kh + dh, co, dw_*cip + ci]  (part float32 [S, kt*kh*cop, kw*cip])."""
+    _dev(part, dw)
+    cop, kt, kh, kw, cip = dw.shape
+    S = part.shape[0]
+    if part.shape[1:] != (kt * kh * cop, kw * cip) or part.dtype != torch.float32 or dw.dtype != torch.float32 or not part.is_contiguous():
+        raise ValueError("wgrad_reduce_taps: shape mismatch")
+    check(_lib.load().m4d_wgrad_reduce_taps(_ptr(part), _ptr(dw), S, cop, kt, kh, kw, cip, _stream()), "m4d_wgrad_reduce_taps")
+    return dw
+
+
 def rmsnorm_silu_cl_bwd(x, gamma, dy, *, silu=True):
     """Backward of rmsnorm_silu_cl: x, dy [P, C] (row-strided) -> (dx [P, C] in x.dtype, dgamma float32 [C])."""
     _dev(x, gamma, dy)

@@ -17,6 +17,7 @@ Gradients of a convolution (stride 1, causal in T, zero padding in H/W):
     per temporal tap (`ops.gemm_bt_batched`) and a reduction of the partial sums (`ops.wgrad_reduce`).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -68,6 +69,9 @@ def conv_wgrad(x, xps, Tin, Hin, Win, cip, dy, cop, k, pad_hw):
     ph, pw = pad_hw
     To = Tin - kt + 1
     Hp, Wp = Hin + 2 * ph, _round(Win + 2 * pw, 8)
+    if (dy.dtype == torch.bfloat16 and cop % 32 == 0 and kt * kh * cop >= 256 and kw * cip >= 256 and 2 * ph == kh - 1
+            and os.environ.get("M4D_WGRAD_TAPS", "1") != "0"):
+        return _conv_wgrad_taps(x, xps, Tin, Hin, Win, cip, dy, cop, k, ph, pw, To, Hp, Wp)
     P = To * Hp * Wp
     S = max(1, min(64, P // 4096))
     Ks = _round(-(-P // S), 64)
@@ -82,6 +86,34 @@ def conv_wgrad(x, xps, Tin, Hin, Win, cip, dy, cop, k, pad_hw):
         part = ops.gemm_bt_batched(a, b[:, dt * Hp * Wp:], M=M, N=N, K=Ks, nb1=S, a_bs1=Ks, w_bs1=Ks, nb2=kh, a_bs2=0, w_bs2=Wp)
         ops.wgrad_reduce(part, dw, dt, M)                                                         # part [kh, S, M, N]
     return dw
+
+
+def _conv_wgrad_taps(x, xps, Tin, Hin, Win, cip, dy, cop, k, ph, pw, To, Hp, Wp):
+    """The weight gradient on the production 256 x 256 GEMM kernel (ops.gemm_bt_taps): dy is the SHIFTED operand, so the kt*kh taps of
+    the layer stack along M (864 .. 3456 rows instead of one batch element of Cout rows per tap).  The dy panel is built in the
+    geometry [Tin, Hp, Wp] with the image kt - 1 frames and kh - 1 rows in (P_dy[q] = P0[q - (kt-1) Hp Wp - (kh-1) Wp], P0 = dy at the
+    origin), so tap (dt, dh) reads it (kt-1-dt) Hp Wp + (kh-1-dh) Wp columns further: no negative offsets.  The contraction then runs over
+    the Tin frames of the x panel: sum_j P0[j - off(dt, dh)] x[j + dw] = sum_p dy[p] x[p + off(dt, dh) + dw]."""
+    kt, kh, kw = k
+    dev = dy.device
+    HW = Hp * Wp
+    P = Tin * HW                                     # contraction length (the kt - 1 leading frames of the dy panel are zero)
+    S = max(1, min(64, P // 8192))
+    Ks = _round(-(-P // S), 128)
+    S = -(-P // Ks)
+    maxoff = (kt - 1) * HW + (kh - 1) * Wp
+    cols_a = S * Ks + maxoff
+    if kt > 1:                                       # kt - 1 zero frames in front of dy
+        dyz = torch.zeros((Tin * Hin * Win, cop), device=dev, dtype=dy.dtype)
+        dyz[(kt - 1) * Hin * Win:] = dy.reshape(To * Hin * Win, cop)
+    else:
+        dyz = dy
+    a = ops.pad_transpose(dyz, cop, cop, Tin, Hin, Win, Hp, Wp, kh - 1, 0, 1, cols_a)             # [cop, cols_a]
+    b = ops.pad_transpose(x, xps, cip, Tin, Hin, Win, Hp, Wp, ph, pw, kw, S * Ks)                 # [kw*cip, S*Ks]
+    part = ops.gemm_bt_taps(a, b, M=kt * kh * cop, N=kw * cip, K=Ks, nb1=S, a_bs1=Ks, w_bs1=Ks, tap_rows=cop, tap_kh=kh,
+                            tap_s1=-HW, tap_s2=-Wp, a_off=maxoff)
+    dw = torch.zeros((cop, kt, kh, kw, cip), device=dev, dtype=torch.float32)
+    return ops.wgrad_reduce_taps(part, dw)
 
 
 def _unpack_wgrad(dw, conv):

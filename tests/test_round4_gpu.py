@@ -472,3 +472,34 @@ def test_groupnorm_planar_store_path_equals_channels_last(C, H, W):
         assert torch.equal(got, ref[f0:f0 + t.shape[1]])
         f0 += t.shape[1]
     assert f0 == F
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 20, 36, 96, 96, (3, 3, 3)), (2, 16, 24, 128, 128, (1, 3, 3)), (3, 12, 20, 96, 192, (3, 3, 3)),
+                                   (5, 9, 13, 384, 384, (3, 3, 3))])
+def test_conv_wgrad_stacked_taps_on_the_production_gemm(shape, monkeypatch):
+    """vae_autograd.conv_wgrad for Cout % 32 == 0 layers runs ALL taps of a layer as one m4d_gemm_bt_taps launch on the 256 x 256 kernel
+    (dy as the shifted operand, taps stacked along M, K-slices in gridDim.y).  Against torch autograd through F.conv3d (fp32 on the
+    bf16-rounded operands) and against the batched generic path (M4D_WGRAD_TAPS=0), which sums the same products in another order."""
+    import torch.nn.functional as F
+    from more4d_amd import ops as o
+    from more4d_amd.vae_autograd import conv_wgrad
+    t, h, w, ci, co, k = shape
+    kt, kh, kw = k
+    g = torch.Generator().manual_seed(4)
+    Tin = t + kt - 1
+    x = torch.randn(Tin, h, w, ci, generator=g).bfloat16()
+    dy = torch.randn(t * h * w, co, generator=g).bfloat16()
+    xr = x.float().permute(3, 0, 1, 2)[None]
+    wr = torch.zeros(co, ci, kt, kh, kw, requires_grad=True)
+    y = F.conv3d(F.pad(xr, (kw // 2, kw // 2, kh // 2, kh // 2, 0, 0)), wr)
+    y.backward(dy.float().view(t, h, w, co).permute(3, 0, 1, 2)[None])
+    want = wr.grad.permute(0, 2, 3, 4, 1)
+    before = dict(o.launch_counts())
+    got = conv_wgrad(x.to(DEV), ci, Tin, h, w, ci, dy.to(DEV), co, k, (kh // 2, kw // 2))
+    after = o.launch_counts()
+    assert after["gemm_wide"] > before.get("gemm_wide", 0)                      # the production kernel ran
+    monkeypatch.setenv("M4D_WGRAD_TAPS", "0")
+    old = conv_wgrad(x.to(DEV), ci, Tin, h, w, ci, dy.to(DEV), co, k, (kh // 2, kw // 2))
+    assert rel_err(got.cpu(), want) < 2e-5 and rel_err(old.cpu(), want) < 2e-5
+    assert rel_err(got.cpu(), old.cpu()) < 2e-6
