@@ -503,3 +503,34 @@ def test_conv_wgrad_stacked_taps_on_the_production_gemm(shape, monkeypatch):
     old = conv_wgrad(x.to(DEV), ci, Tin, h, w, ci, dy.to(DEV), co, k, (kh // 2, kw // 2))
     assert rel_err(got.cpu(), want) < 2e-5 and rel_err(old.cpu(), want) < 2e-5
     assert rel_err(got.cpu(), old.cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_attention_backward_reruns_are_bit_identical_full_length():
+    """The fused dK / dV pass hands P from one wave to its partner through an LDS mailbox behind a flag, with tiles landing by DMA in two
+    rings: a lost hand-over or a tile read early would show as run-to-run differences.  Six reruns at L = 21 840 (ragged last query tile,
+    ragged last key workgroup) under a concurrent stream of unrelated launches must agree bit for bit."""
+    from more4d_amd import ops as o
+    from more4d_amd.ops import KV
+    L, heads, D = 21840, 8, 128
+    C = heads * D
+    g = torch.Generator(device=DEV).manual_seed(7)
+    q, k, v = (torch.randn(L, C, device=DEV, generator=g).bfloat16() for _ in range(3))
+    d_o = (torch.randn(L, C, device=DEV, generator=g) * 0.1).bfloat16()
+    lse = torch.empty(1, heads, L, device=DEV)
+    out = o.attention(q, [KV(k, o.transpose(v), L * C, C, L, L, L)], B=1, Lq=L, heads=heads, head_dim=D, q_bs=L * C, q_ls=C, lse=lse).view(L, C)
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=DEV)
+    ref = None
+    for it in range(6):
+        dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                junk = junk @ junk * 1e-4
+        o.attention_bwd(q, k, v, out, d_o, lse, B=1, Lq=L, Lk=L, Lk_rows=L, heads=heads, head_dim=D, dq=dq, dk=dk, dv=dv)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(dq.float()).all()) and bool(torch.isfinite(dk.float()).all()) and bool(torch.isfinite(dv.float()).all())
+        if ref is None:
+            ref = (dq, dk, dv)
+        else:
+            assert torch.equal(dq, ref[0]) and torch.equal(dk, ref[1]) and torch.equal(dv, ref[2])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """A/B of the attention backward at the train step's self-attention shape (B = 1, L = 21 840, 40 heads, d = 128, bf16): the fused
-dK/dV pass (default) against the separate dK and dV passes (M4D_ATTN_BWD_FUSED=0), alternating subprocesses on ONE box (environment
+dK/dV pass (M4D_ATTN_BWD_FUSED=2, default: attention_bwd_kvp.h; 1: the first fused kernel) against the separate dK and dV passes
+(M4D_ATTN_BWD_FUSED=0), alternating subprocesses on ONE box (environment
 switches are read once per process).  Prints ms per m4d_attention_bwd call (delta + transposes excluded: the ops.attention_bwd wrapper
 is timed as a whole and the pure-kernel time separately) and the MFMA fraction on the 10 L^2 d convention.
     python tools/ab_attn_bwd.py [rounds]"""
@@ -50,8 +51,8 @@ if __name__ == "__main__":
         sys.exit(0)
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     for r in range(rounds):
-        for name, val, wide in (("separate dK, dV passes", "0", "1"), ("fused, 8 x 32-row waves", "1", "0"), ("fused, 4 x 64-row waves", "1", "1")):
-            env = dict(os.environ, AB_CHILD="1", M4D_ATTN_BWD_FUSED=val, M4D_ATTN_BWD_WIDE=wide)
+        for name, val in (("separate dK, dV passes", "0"), ("first fused kernel (lock-step)", "1"), ("phased fused kernel (default)", "2")):
+            env = dict(os.environ, AB_CHILD="1", M4D_ATTN_BWD_FUSED=val)
             out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
             line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
             d = json.loads(line[-1]) if line else {"error": out.stderr[-400:]}

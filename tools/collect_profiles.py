@@ -35,6 +35,11 @@ cp(f"{src}/attn_phases.log", "attn_phases.log")
 cp(f"{src}/gemm_traffic_variants.log", "gemm_traffic_variants.log")
 cp(f"{src}/mfma_rate_probe.log", "mfma_rate_probe.log")
 cp(f"{src}/bw_probe.log", "bw_probe.log")
+cp(f"{src}/ab_attn_bwd.log", "ab_attn_bwd_final.log")
+cp(f"{src}/vae_train_bench.json", "vae_train_bench.json")
+cp(f"{src}/bench_gn_planar.log", "bench_gn_planar.log")
+for f in glob.glob(f"{src}/vae_train_ks/**/p_kernel_stats.csv", recursive=True):
+    cp(f, "vae_train_kernel_stats.csv")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "train_4layers_kernel_stats.csv")
 subprocess.run([sys.executable, "tools/summarize_prof.py", tag], check=False)
