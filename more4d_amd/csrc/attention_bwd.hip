@@ -377,7 +377,10 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         // cross-attention case (few keys, many queries, float workspace) keeps the two separate passes.  M4D_ATTN_BWD_FUSED=0: A/B.
         // 2 (default) = attn_bwd_kvp_kernel (attention_bwd_kvp.h: the forward kernel's phased schedule), 1 = the first fused kernel.
         M4D_ENV_ONCE(bwd_fused, "M4D_ATTN_BWD_FUSED", 2);
-        if (bwd_fused && nsplit == 1) {
+        // few keys against many queries (cross-attention, nsplit > 1): M4D_ATTN_BWD_FUSED_SHORT=1 sends that case through the fused kernel as
+        // well (ceil(Lk / 128) x heads workgroups, each walking all query tiles) instead of the split dK / dV passes + workspace reduction
+        M4D_ENV_ONCE(bwd_fused_short, "M4D_ATTN_BWD_FUSED_SHORT", 1);
+        if (bwd_fused && (nsplit == 1 || (bwd_fused == 2 && bwd_fused_short))) {
             p.out_b = a->dv; p.ob_bs = a->dv_bs; p.ob_ls = a->dv_ls;
             p.nx_tiles = (int)((a->Lk_rows + 127) / 128);
             if (bwd_fused == 2 ? launch_bwd_kvp(p, st) : launch_bwd_kv128(p, st)) { m4d_set_error("attention_bwd: cannot configure the fused dk/dv kernel"); return -3; }

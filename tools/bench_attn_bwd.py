@@ -45,3 +45,4 @@ def run(name, B, Lq, Lk, n, D=128, iters=3, check=True):
 
 run("self", 1, 21840, 21840, 40)
 run("cross_txt", 1, 21840, 512, 40, iters=10)
+run("cross_img", 1, 21840, 257, 40, iters=10)
