@@ -449,6 +449,12 @@ def main():
     from more4d_amd import _lib
     if _lib.ABLATION_BUILD:
         raise SystemExit("bench.py refuses the ablation build of the library (M4D_LIB=abl: kernels that skip work)")
+    # M4D_BENCH_ONE_GPU=1 (tool; the line is then marked valid: false like every M4D_* override): all ranks share cuda:0 and talk gloo
+    # (device tensors staged through the host) — the whole N-rank code path with the real kernels on a 1-GPU box, where RCCL refuses
+    # two ranks on one device.  Timings of such a run mean nothing; it exists to catch a crash before an 8-GPU node does.
+    one_gpu = os.environ.get("M4D_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_ranks = 1
@@ -459,7 +465,10 @@ def main():
         # sub-group that cannot be created) is reported as ONE JSON diagnostic line instead of a bare non-zero exit code
         stage = "init_process_group(nccl)"
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if one_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             stage = "all_reduce"
             ones = torch.ones(1, device=dev)
             dist.all_reduce(ones)                       # proves every rank is on the RCCL communicator

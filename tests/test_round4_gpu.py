@@ -534,3 +534,30 @@ def test_attention_backward_reruns_are_bit_identical_full_length():
             ref = (dq, dk, dv)
         else:
             assert torch.equal(dq, ref[0]) and torch.equal(dk, ref[1]) and torch.equal(dv, ref[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,world", [("denoise", 2), ("denoise", 4), ("train", 2)])
+def test_bench_n_ranks_on_one_gpu_over_gloo(mode, world):
+    """`bench.py --gpus N` end to end with REAL processes and the real kernels: RCCL refuses two ranks on one device, so the tool mode
+    M4D_BENCH_ONE_GPU=1 puts every rank on cuda:0 over gloo.  Both layouts (cfg2 x sp(N/2) and plain sp-N), the stand-in second pass
+    that measures the exposed collective time, the sharded data-parallel train step: the run must finish, stay finite and print one JSON
+    line that is marked invalid as a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--layers", "2", "--steps", "1", "--warmup", "1"]
+    cmd += ["--mode", "train"] if mode == "train" else ["--no-secondary", "--no-cpu-baseline"]
+    env = dict(os.environ, M4D_BENCH_ONE_GPU="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["valid"] is False and "M4D_BENCH_ONE_GPU" in d["env_overrides"]
+    assert d["value"] is not None and d["value"] > 0
+    if mode == "denoise":
+        assert d["secondary"]["sp_layout"]["finite"] and "collectives" in d
+    else:
+        assert math.isfinite(d["loss"])
