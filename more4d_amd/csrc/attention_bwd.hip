@@ -325,9 +325,12 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         return -2;
     }
     const int64_t strides[] = {a->q_bs, a->q_ls, a->k_bs, a->k_ls, a->v_bs, a->v_ls, a->o_bs, a->o_ls, a->do_bs, a->do_ls,
-                               a->qt_bs, a->qt_ls, a->kt_bs, a->kt_ls, a->dot_bs, a->dot_ls, a->dq_bs, a->dq_ls,
-                               a->dk_bs, a->dk_ls, a->dv_bs, a->dv_ls};
+                               a->dq_bs, a->dq_ls, a->dk_bs, a->dk_ls, a->dv_bs, a->dv_ls};
     for (int64_t s : strides) M4D_CHECK_ARG(s % 8 == 0, "attention_bwd: strides must be multiples of 8 elements");
+    if (a->qt || a->kt || a->dot) {      // (transposed copies: only the generic kernels read them)
+        const int64_t tstrides[] = {a->qt_bs, a->qt_ls, a->kt_bs, a->kt_ls, a->dot_bs, a->dot_ls};
+        for (int64_t s : tstrides) M4D_CHECK_ARG(s % 8 == 0, "attention_bwd: strides of the transposed operands must be multiples of 8 elements");
+    }
     const void* ptrs[] = {a->q, a->k, a->v, a->o, a->d_o, a->qt, a->kt, a->dot, a->dq, a->dk, a->dv};      // (null qt / kt / dot pass)
     for (const void* q : ptrs) M4D_CHECK_ARG(((uintptr_t)q % 16) == 0, "attention_bwd: tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;

@@ -561,3 +561,33 @@ def test_bench_n_ranks_on_one_gpu_over_gloo(mode, world):
         assert d["secondary"]["sp_layout"]["finite"] and "collectives" in d
     else:
         assert math.isfinite(d["loss"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lq,Lk,Lk_rows", [(2304, 2304, 2304), (1100, 257, 264), (330, 1000, 1000)])
+def test_attention_bwd_accumulate_flags_production_kernels(Lq, Lk, Lk_rows):
+    """accumulate_dq / accumulate_dkv through the phased dQ kernel and the fused dK / dV kernel (bf16, head_dim 128, B = 2; ragged query and
+    key tiles, padded key rows): out = previous content + gradient; padded key rows keep their previous content."""
+    from more4d_amd import ops as o
+    from more4d_amd.ops import KV
+    B, heads, D = 2, 3, 128
+    C = heads * D
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B * Lq, C, generator=g).bfloat16().to(DEV)
+    k = torch.randn(B * Lk_rows, C, generator=g).bfloat16().to(DEV)
+    v = torch.randn(B * Lk_rows, C, generator=g).bfloat16().to(DEV)
+    d_o = torch.randn(B * Lq, C, generator=g).bfloat16().to(DEV)
+    lse = torch.empty(B, heads, Lq, device=DEV)
+    out = o.attention(q, [KV(k, o.transpose(v), Lk_rows * C, C, Lk_rows, B * Lk_rows, Lk)], B=B, Lq=Lq, heads=heads, head_dim=D,
+                      q_bs=Lq * C, q_ls=C, lse=lse).view(B * Lq, C)
+    kw = dict(B=B, Lq=Lq, Lk=Lk, Lk_rows=Lk_rows, heads=heads, head_dim=D)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    o.attention_bwd(q, k, v, out, d_o, lse, dq=dq, dk=dk, dv=dv, **kw)
+    pq, pk, pv = (torch.randn(t.shape, generator=g).bfloat16().to(DEV) for t in (q, k, v))
+    aq, ak, av = pq.clone(), pk.clone(), pv.clone()
+    o.attention_bwd(q, k, v, out, d_o, lse, dq=aq, dk=ak, dv=av, accumulate_dq=True, accumulate_dkv=True, **kw)
+    for got, prev, grad in ((aq, pq, dq), (ak, pk, dk), (av, pv, dv)):
+        want = prev.float() + grad.float()
+        assert rel_err(got.float(), want) < 8e-3
+    pad = ak.view(B, Lk_rows, C)[:, Lk:]
+    assert torch.equal(pad, pk.view(B, Lk_rows, C)[:, Lk:]) and torch.equal(av.view(B, Lk_rows, C)[:, Lk:], pv.view(B, Lk_rows, C)[:, Lk:])
