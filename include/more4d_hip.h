@@ -51,7 +51,8 @@ typedef enum {
     M4D_KC_CONV_GNSTATS = 11,      /* a conv launch that emitted GroupNorm partial statistics from its epilogue */
     M4D_KC_ATTN_BWD128 = 12,       /* one pass of the production attention backward (attn_bwd128_kernel: dQ / dK / dV, bf16, head_dim 128) */
     M4D_KC_ATTN_BWD_GENERIC = 13,  /* one pass of the generic two-pass backward (fp32 / other head dims) */
-    M4D_KC_COUNT = 14
+    M4D_KC_ATTN_XP = 14,           /* attn128x_kernel: persistent pipeline over (query tile, key tile) pairs for short key lists (cross-attention) */
+    M4D_KC_COUNT = 15
 } m4d_kernel_class;
 /* launches of `kernel_class` since process start (or the last reset); reset != 0 clears that counter after reading it;
  * kernel_class < 0 with reset != 0 clears all counters and returns 0. */

@@ -533,6 +533,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
 
 #include "attention_phased.h"
 #include "attention_wide.h"
+#include "attention_xp.h"
+
+int attn_device_cus() {
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n[dev] = v;
+        else n[dev] = 256;
+    }
+    return n[dev];
+}
+// attn128x_kernel (attention_xp.h) takes bf16 / head_dim 128 calls with at least four query tiles of 256 and a key list too short for the
+// long-loop kernels (M4D_ATTN_XP=0: the lock-step 4-wave kernel as before)
+bool xp_ok(const AttnArgs& p, bool w8) {
+    M4D_ENV_ONCE(xp, "M4D_ATTN_XP", 1);
+    M4D_ENV_ONCE(force_lockstep, "M4D_ATTN_LOCKSTEP", 0);
+    M4D_ENV_ONCE(force_w4, "M4D_ATTN_W4", 0);
+    if (!xp || force_lockstep || force_w4 || w8 || p.Lq <= 1024) return false;
+    int64_t keys = 0;
+    for (int i = 0; i < p.kv.nseg; ++i) keys += p.kv.len[i] > 0 ? p.kv.len[i] : 0;
+    return keys > 0;
+}
 
 template <typename T>
 int launch(const AttnArgs& p, int D, hipStream_t st) {
@@ -598,6 +623,21 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             else if (prio == 0) hipLaunchKernelGGL((attn128p_kernel<1, 0>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
             else if (prio == 2) hipLaunchKernelGGL((attn128p_kernel<1, 2>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
             else hipLaunchKernelGGL((attn128p_kernel<1, 1>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
+        } else if (xp_ok(p, w8)) {
+            // short key lists against many queries (cross-attention): one persistent workgroup per CU walks (query tile, key tile) pairs
+            static bool configured_x = false;
+            if (!configured_x) {
+                if (hipFuncSetAttribute((const void*)attn128x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768) != hipSuccess) return -3;
+                configured_x = true;
+            }
+            q.nq_tiles = (int)((p.Lq + 255) / 256);
+            const int64_t items = (int64_t)q.nq_tiles * p.heads * p.B;
+            int nwg = attn_device_cus();
+            if (((p.heads * p.B) & 7) == 0) nwg &= ~7;
+            if (nwg < 8) nwg = 8;
+            if (items < nwg && ((p.heads * p.B) & 7) != 0) nwg = (int)items;
+            m4d_count_launch(M4D_KC_ATTN_XP);
+            hipLaunchKernelGGL((attn128x_kernel<1>), dim3((unsigned)nwg), dim3(512), 4 * 32768 + 32768, st, q);
         } else if (w8) {
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             m4d_count_launch(M4D_KC_ATTN_OTHER);
