@@ -68,6 +68,11 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
     // Per-lane constants of the rare paths (tile request offsets, repair, flush) are re-derived from an OPAQUE copy of the lane id where
     // they are used: hoisted out of the loop by the compiler they cost ~30 registers that the M stream does not have.
     auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    // Likewise the kernel arguments of the rare paths (Q fetch, flush, segment change): read through an opaque copy of the kernarg pointer
+    // they are scalar loads where they are used instead of ~25 SGPRs that live through the loop (the kernel ran out of SGPRs: hipcc parked
+    // loop state in VGPR lanes and put v_readlane / v_writelane pairs into the MFMA stream).
+    typedef const AttnArgs __attribute__((address_space(4))) * kernarg_t;
+    auto args = [&]() { kernarg_t a = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(a)); return a; };
     // ---- consumer side: the item whose tiles are being computed ----
     int64_t qrow = (int64_t)c_qt * QB + wave * 32 + li;
     bool qvalid = qrow < p.Lq;
@@ -77,8 +82,10 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
     // vmcnt(0) — behind the tile request issued twelve MFMAs earlier).  The wait is placed by hand: M stream, step 15, of the interval whose
     // QK half is the first to use them.  Rows beyond Lq re-read the last row (their outputs are never stored).
     auto load_q = [&](int b, int h, int64_t row) {
-        const int64_t r = row < p.Lq ? row : p.Lq - 1;
-        const T* qp = (const T*)p.q + b * p.q_bs + r * p.q_ls + (int64_t)h * D + (opaque_lane() >> 5) * 8;
+        kernarg_t a = args();
+        const int64_t Lq = a->Lq;
+        const int64_t r = row < Lq ? row : Lq - 1;
+        const T* qp = (const T*)a->q + b * a->q_bs + r * a->q_ls + (int64_t)h * D + (opaque_lane() >> 5) * 8;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[0]) : "v"(qp) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(qf[1]) : "v"(qp) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(qf[2]) : "v"(qp) : "memory");
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
     }
 
     // ---- DMA side: iterator over (item, segment, first key), three tiles ahead of the consumer ----
-    auto next_seg = [&](int sg) { ++sg; while (sg < p.kv.nseg && p.kv.len[sg] <= 0) ++sg; return sg; };
+    auto next_seg = [&](kernarg_t a, int sg) { ++sg; while (sg < a->kv.nseg && a->kv.len[sg] <= 0) ++sg; return sg; };
     int dseg = seg_first, d_b = c_b, d_h = c_h, d_qt = c_qt, d_left = nitems;
     int dk0 = 0, dlen = 0;
     bool d_add = p.accumulate != 0;
@@ -116,10 +123,11 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
     const T* dvb = nullptr;
     unsigned dkls2 = 0, dvls2 = 0;              // row strides of the current segment in bytes (segments need not share them)
     auto d_bases = [&]() {
-        dkb = (const T*)p.kv.k[dseg] + d_b * p.kv.k_bs[dseg] + (int64_t)d_h * D;
-        dvb = (const T*)p.kv.vt[dseg] + d_b * p.kv.vt_bs[dseg] + (int64_t)d_h * D * p.kv.vt_ls[dseg];
-        dlen = (int)p.kv.len[dseg];
-        dkls2 = (unsigned)(p.kv.k_ls[dseg] * 2); dvls2 = (unsigned)(p.kv.vt_ls[dseg] * 2);
+        kernarg_t a = args();
+        dkb = (const T*)a->kv.k[dseg] + d_b * a->kv.k_bs[dseg] + (int64_t)d_h * D;
+        dvb = (const T*)a->kv.vt[dseg] + d_b * a->kv.vt_bs[dseg] + (int64_t)d_h * D * a->kv.vt_ls[dseg];
+        dlen = (int)a->kv.len[dseg];
+        dkls2 = (unsigned)(a->kv.k_ls[dseg] * 2); dvls2 = (unsigned)(a->kv.vt_ls[dseg] * 2);
     };
     d_bases();
     auto uniform_ptr = [](const char* q) {
@@ -143,13 +151,14 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         dk0 += KVB;
         if (dk0 >= dlen) {
             dk0 = 0;
-            const int ns = next_seg(dseg);
-            if (ns < p.kv.nseg) {
-                if ((p.kv.new_softmax >> ns) & 1) { flags = F_GROUP_END | (d_add ? F_ADD : 0); d_add = true; }
+            kernarg_t a = args();
+            const int ns = next_seg(a, dseg);
+            if (ns < a->kv.nseg) {
+                if ((a->kv.new_softmax >> ns) & 1) { flags = F_GROUP_END | (d_add ? F_ADD : 0); d_add = true; }
                 dseg = ns;
             } else {
                 flags = F_GROUP_END | (d_add ? F_ADD : 0);
-                d_add = p.accumulate != 0;
+                d_add = a->accumulate != 0;
                 dseg = seg_first;
                 if (--d_left > 0) {
                     flags |= F_NEXT_ITEM;
@@ -299,7 +308,9 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
             l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         }
         const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-        if (p.lse && qvalid && hi == 0) p.lse[((int64_t)c_b * p.heads + c_h) * p.Lq + qrow] = m_run + log2f(l_tot);
+        kernarg_t a = args();
+        const int64_t Lq = a->Lq;
+        if (a->lse && qvalid && hi == 0) a->lse[((int64_t)c_b * a->heads + c_h) * Lq + qrow] = m_run + log2f(l_tot);
         if (!(M4D_ABL(p) & 4)) {
             // The accumulators hold 4 consecutive d per (lane, register quad): stored from there, every instruction touches 32 rows with
             // 16 bytes each — 4 096 sixteen-byte write transactions per item, measured at 4-5 us per flush (a quarter of this kernel's time).
@@ -310,9 +321,10 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
             const int er = l >> 3, ej = l & 7, fli = l & 31, fhi = l >> 5;
             const int64_t row0 = (int64_t)c_qt * QB + __builtin_amdgcn_readfirstlane(wave) * 32;
             // wave-uniform base (scalars only) + 32-bit lane offset: global_load / global_store in the saddr form
-            T* const obase = (T*)p.out + (c_b * p.o_bs + (int64_t)c_h * D + row0 * p.o_ls);
-            const unsigned ols = (unsigned)p.o_ls;
-            const int nrows = p.Lq - row0 < 32 ? (int)(p.Lq - row0) : 32;
+            const int64_t o_ls = a->o_ls;
+            T* const obase = (T*)a->out + (c_b * a->o_bs + (int64_t)c_h * D + row0 * o_ls);
+            const unsigned ols = (unsigned)o_ls;
+            const int nrows = Lq - row0 < 32 ? (int)(Lq - row0) : 32;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         if (flags & F_NEXT_ITEM) {
             advance(c_b, c_h, c_qt);
             qrow = (int64_t)c_qt * QB + wave * 32 + li;
-            qvalid = qrow < p.Lq;
+            qvalid = qrow < Lq;
         }
         return issued;
     };
