@@ -21,6 +21,9 @@
 // (b, h) on one workgroup so its K / V^T stay in that L2), a contiguous run of items per workgroup, gridDim = number of CUs.
 #pragma once
 #include "attention_phased.h"
+#ifndef XP_VAR
+#define XP_VAR 0      // side builds (tools/side_lib.sh): timing variants of the loop, results wrong — 1 no ragged mask in V, 2 no repair check,
+#endif                // 4 no flush / fetch tests in the loop, 8 interval-closing wait without the switch, 16 tile iterator without bookkeeping
 
 template <int PRIO>
 __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
@@ -31,61 +34,58 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, hi = lane >> 5;
     const int grp = wave >> 2;
-    const int nq = p.nq_tiles, HB = p.heads * p.B;
 
-    // ---- this workgroup's run of items ----
-    // Items are dealt round-robin: workgroup slot s of an XCD takes items s, s + nslots, ... of that XCD's list, so the workgroups of an XCD
-    // are always within one or two (b, h) of each other and their K / V^T (394 KB per (b, h)) stay in the 4 MiB L2 — with contiguous runs the
-    // 32 workgroups would be spread over all ten (b, h) of the XCD at once.
-    int c_b, c_h, c_qt, nitems, istep;
+    // The loop is short of SGPRs (the phased kernel's 75 + an iterator over items / segments / tiles): whatever only the rare paths need
+    // (segment change, Q fetch, flush) is NOT kept in registers.  Kernel arguments of those paths are read through an opaque copy of the
+    // kernarg pointer (scalar loads where they are used, not ~25 SGPRs that live through the loop), per-lane constants are re-derived from
+    // an opaque copy of the lane id (hoisted by the compiler they cost ~30 VGPRs).  With everything live hipcc parked loop state in VGPR
+    // lanes and put v_readlane / v_writelane pairs into the MFMA stream: 20 % per interval (tools/xp_vs_phased.py, side builds -DXP_VAR).
+    typedef const AttnArgs __attribute__((address_space(4))) * kernarg_t;
+    auto args = [&]() { kernarg_t a = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(a)); return a; };
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+
+    // ---- this workgroup's items ----
+    // Items = (b * heads + h, query tile), dealt round-robin: workgroup slot s of an XCD takes items s, s + nslots, ... of that XCD's list, so
+    // the workgroups of an XCD are always within one or two (b, h) of each other and their K / V^T (394 KB per (b, h)) stay in the 4 MiB L2.
+    auto item_step = [&](kernarg_t a) { return ((a->heads * a->B) & 7) == 0 ? (int)(gridDim.x >> 3) : (int)gridDim.x; };
+    int c_hb, c_qt, G;
     {
-        int e0, E, hb0;
+        const int nq = p.nq_tiles, HB = p.heads * p.B;
+        int e0, E, hb0, istep;
         if ((HB & 7) == 0) {
-            const int xcd = blockIdx.x & 7;
             e0 = blockIdx.x >> 3; istep = gridDim.x >> 3;
             E = (HB >> 3) * nq;
-            hb0 = xcd * (HB >> 3);
+            hb0 = (blockIdx.x & 7) * (HB >> 3);
         } else {
             e0 = (int)blockIdx.x; istep = (int)gridDim.x;
             E = HB * nq;
             hb0 = 0;
         }
         if (e0 >= E) return;
-        nitems = (E - e0 + istep - 1) / istep;
-        const int hb = hb0 + e0 / nq;
-        c_qt = e0 % nq; c_b = hb / p.heads; c_h = hb % p.heads;
+        c_hb = hb0 + e0 / nq; c_qt = e0 % nq;
+        int NTI = 0;                                 // key tiles per item
+        for (int sg = 0; sg < p.kv.nseg; ++sg) NTI += p.kv.len[sg] > 0 ? (int)((p.kv.len[sg] + KVB - 1) / KVB) : 0;
+        G = ((E - e0 + istep - 1) / istep) * NTI;    // intervals of this workgroup
     }
-    auto advance = [&](int& b, int& h, int& qt) {
-        qt += istep;
-        while (qt >= nq) { qt -= nq; if (++h == p.heads) { h = 0; ++b; } }
+    auto advance = [&](kernarg_t a, int& hb, int& qt) {
+        const int nq = a->nq_tiles;
+        qt += item_step(a);
+        while (qt >= nq) { qt -= nq; ++hb; }
     };
-    int seg_first = 0;
-    while (seg_first < p.kv.nseg && p.kv.len[seg_first] <= 0) ++seg_first;
-    int NTI = 0;                                 // key tiles per item
-    for (int sg = 0; sg < p.kv.nseg; ++sg) NTI += p.kv.len[sg] > 0 ? (int)((p.kv.len[sg] + KVB - 1) / KVB) : 0;
-    const int G = nitems * NTI;                  // intervals of this workgroup
 
-    // Per-lane constants of the rare paths (tile request offsets, repair, flush) are re-derived from an OPAQUE copy of the lane id where
-    // they are used: hoisted out of the loop by the compiler they cost ~30 registers that the M stream does not have.
-    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-    // Likewise the kernel arguments of the rare paths (Q fetch, flush, segment change): read through an opaque copy of the kernarg pointer
-    // they are scalar loads where they are used instead of ~25 SGPRs that live through the loop (the kernel ran out of SGPRs: hipcc parked
-    // loop state in VGPR lanes and put v_readlane / v_writelane pairs into the MFMA stream).
-    typedef const AttnArgs __attribute__((address_space(4))) * kernarg_t;
-    auto args = [&]() { kernarg_t a = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(a)); return a; };
-    // ---- consumer side: the item whose tiles are being computed ----
-    int64_t qrow = (int64_t)c_qt * QB + wave * 32 + li;
-    bool qvalid = qrow < p.Lq;
+    // ---- consumer side: Q fragments of the item whose tiles are being computed ----
     bf16x8 qf[8];
-    // Q fragments of one item: eight 16-byte pieces of the lane's query row, requested WITHOUT a wait (inline asm: a compiler-visible load
-    // into registers that live across the loop makes hipcc guard their first use, the first QK MFMA of every M stream, with s_waitcnt
-    // vmcnt(0) — behind the tile request issued twelve MFMAs earlier).  The wait is placed by hand: M stream, step 15, of the interval whose
-    // QK half is the first to use them.  Rows beyond Lq re-read the last row (their outputs are never stored).
-    auto load_q = [&](int b, int h, int64_t row) {
+    // eight 16-byte pieces of the lane's query row, requested WITHOUT a wait (inline asm: a compiler-visible load into registers that live
+    // across the loop makes hipcc guard their first use, the first QK MFMA of every M stream, with s_waitcnt vmcnt(0) — behind the tile
+    // request issued twelve MFMAs earlier).  The wait is placed by hand: M stream, step 15, of the interval whose QK half is the first to use
+    // them.  Rows beyond Lq re-read the last row (their outputs are never stored).
+    auto load_q = [&](int hb, int qt) {
         kernarg_t a = args();
-        const int64_t Lq = a->Lq;
+        const int heads = a->heads, b = hb / heads, h = hb - b * heads;
+        const int l = opaque_lane();
+        const int64_t Lq = a->Lq, row = (int64_t)qt * QB + wave * 32 + (l & 31);
         const int64_t r = row < Lq ? row : Lq - 1;
-        const T* qp = (const T*)a->q + b * a->q_bs + r * a->q_ls + (int64_t)h * D + (opaque_lane() >> 5) * 8;
+        const T* qp = (const T*)a->q + b * a->q_bs + r * a->q_ls + (int64_t)h * D + (l >> 5) * 8;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[0]) : "v"(qp) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(qf[1]) : "v"(qp) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(qf[2]) : "v"(qp) : "memory");
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(qf[6]) : "v"(qp) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:224" : "=v"(qf[7]) : "v"(qp) : "memory");
     };
-    load_q(c_b, c_h, qrow);
+    load_q(c_hb, c_qt);
 
     f32x16 o[4];
 #pragma unroll
@@ -114,86 +114,71 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         for (int c = 0; c < 4; ++c) va[c] = lds0 + VOFF + li * 128 + (((c * 2 + hi) ^ ((li >> 1) & 7)) << 4);
     }
 
-    // ---- DMA side: iterator over (item, segment, first key), three tiles ahead of the consumer ----
-    auto next_seg = [&](kernarg_t a, int sg) { ++sg; while (sg < a->kv.nseg && a->kv.len[sg] <= 0) ++sg; return sg; };
-    int dseg = seg_first, d_b = c_b, d_h = c_h, d_qt = c_qt, d_left = nitems;
-    int dk0 = 0, dlen = 0;
-    bool d_add = p.accumulate != 0;
-    const T* dkb = nullptr;
-    const T* dvb = nullptr;
-    unsigned dkls2 = 0, dvls2 = 0;              // row strides of the current segment in bytes (segments need not share them)
-    auto d_bases = [&]() {
+    // ---- DMA side: the NEXT tile to request (three tiles ahead of the consumer) as running source pointers + keys left in its segment ----
+    const char* kp = nullptr;                     // K rows of the next tile: (b, first key, h, 0)
+    const char* vp = nullptr;                     // V^T columns of the next tile: (b, h, d = 0, first key)
+    int drem = 0;                                 // keys of the current segment from the next tile's first key on
+    unsigned dkls2 = 0, dvls2 = 0;                // row strides of the current segment in bytes (segments need not share them)
+    int dsegx = 0;                                // current segment | 256 if the softmax group in progress is ADDED to the output
+    int d_hb = c_hb, d_qt = c_qt, d_left = G;     // (d_left: tiles still to request)
+    auto enter_segment = [&](kernarg_t a, int sg) {
+        const int heads = a->heads, b = d_hb / heads, h = d_hb - b * heads;
+        const int64_t vls = a->kv.vt_ls[sg];
+        kp = (const char*)((const T*)a->kv.k[sg] + b * a->kv.k_bs[sg] + (int64_t)h * D);
+        vp = (const char*)((const T*)a->kv.vt[sg] + b * a->kv.vt_bs[sg] + (int64_t)h * D * vls);
+        drem = (int)a->kv.len[sg];
+        dkls2 = (unsigned)(a->kv.k_ls[sg] * 2); dvls2 = (unsigned)(vls * 2);
+        dsegx = (dsegx & 256) | sg;
+    };
+    auto first_seg = [&](kernarg_t a) { int sg = 0; while (sg < a->kv.nseg && a->kv.len[sg] <= 0) ++sg; return sg; };
+    {
         kernarg_t a = args();
-        dkb = (const T*)a->kv.k[dseg] + d_b * a->kv.k_bs[dseg] + (int64_t)d_h * D;
-        dvb = (const T*)a->kv.vt[dseg] + d_b * a->kv.vt_bs[dseg] + (int64_t)d_h * D * a->kv.vt_ls[dseg];
-        dlen = (int)a->kv.len[dseg];
-        dkls2 = (unsigned)(a->kv.k_ls[dseg] * 2); dvls2 = (unsigned)(a->kv.vt_ls[dseg] * 2);
-    };
-    d_bases();
-    auto uniform_ptr = [](const char* q) {
-        const unsigned long long v = (unsigned long long)q;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return (const char*)(((unsigned long long)hi2 << 32) | lo);
-    };
-    const char* dma_kp = nullptr;
-    const char* dma_vp = nullptr;
-    unsigned dma_dst = 0;
-    int dma_lim = KVB;
-    unsigned dma_kls2 = 0, dma_vls2 = 0;
-    // scalar part of the request of the NEXT tile of the list; returns its code = valid keys | flags << 8
-    auto dma_prepare = [&](int stage) -> int {
-        const int rem = dlen - dk0;
-        const int lim = rem < KVB ? rem : KVB;
-        dma_kp = uniform_ptr((const char*)dkb + (int64_t)dk0 * dkls2);
-        dma_vp = uniform_ptr((const char*)(dvb + dk0));
-        dma_lim = lim; dma_kls2 = dkls2; dma_vls2 = dvls2;
+        dsegx = a->accumulate != 0 ? 256 : 0;
+        enter_segment(a, first_seg(a));
+    }
+    const unsigned dst_w = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);      // this wave's 2 KiB of every K / V^T image
+    // the tile just requested is behind us: returns its code = valid keys | flags << 8 and moves on to the next tile of the list
+    auto next_tile = [&]() -> int {
+        const int lim = drem < KVB ? drem : KVB;
         int flags = 0;
-        dk0 += KVB;
-        if (dk0 >= dlen) {
-            dk0 = 0;
+        kp += (size_t)KVB * dkls2; vp += KVB * 2; drem -= KVB; --d_left;
+        if (drem <= 0 && !(XP_VAR & 16)) {
             kernarg_t a = args();
-            const int ns = next_seg(a, dseg);
-            if (ns < a->kv.nseg) {
-                if ((a->kv.new_softmax >> ns) & 1) { flags = F_GROUP_END | (d_add ? F_ADD : 0); d_add = true; }
-                dseg = ns;
+            int sg = (dsegx & 255) + 1;
+            while (sg < a->kv.nseg && a->kv.len[sg] <= 0) ++sg;
+            if (sg < a->kv.nseg) {
+                if ((a->kv.new_softmax >> sg) & 1) { flags = F_GROUP_END | (dsegx & 256 ? F_ADD : 0); dsegx |= 256; }
             } else {
-                flags = F_GROUP_END | (d_add ? F_ADD : 0);
-                d_add = a->accumulate != 0;
-                dseg = seg_first;
-                if (--d_left > 0) {
-                    flags |= F_NEXT_ITEM;
-                    advance(d_b, d_h, d_qt);
-                }
+                flags = F_GROUP_END | (dsegx & 256 ? F_ADD : 0);
+                dsegx = a->accumulate != 0 ? 256 : 0;
+                sg = first_seg(a);
+                if (d_left > 0) { flags |= F_NEXT_ITEM; advance(a, d_hb, d_qt); }
             }
-            if (d_left > 0) d_bases();
-        }
-        dma_dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + wave * 2048);
+            if (d_left > 0) enter_segment(a, sg);
+        } else if (drem <= 0) { drem += 8192; }
         return lim | (flags << 8);
     };
     // per-lane source offsets (K piece = 4 rows x 256 B, V^T piece = 8 rows x 128 B, XOR swizzle on the source chunk).  Ragged tile: K rows
-    // beyond the segment re-read its last row (their scores are masked), V^T chunks entirely beyond it re-read chunk 0 of their row
-    // (zeroed in LDS afterwards, like the tail of the partial chunk)
-    // (four per-lane constants: K row / swizzled chunk of this lane's first K piece, V^T row / chunk of its first V^T piece; the second
-    // pieces are 4 / 8 rows further, which flips bit 2 of the swizzle term)
+    // beyond the segment re-read its last row (their scores are masked), V^T chunks entirely beyond it re-read chunk 0 of their row (zeroed
+    // in LDS afterwards, like the tail of the partial chunk).  Four per-lane constants: K row / swizzled chunk of this lane's first K piece,
+    // V^T row / chunk of its first V^T piece; the second pieces are 4 / 8 rows further, which flips bit 2 of the swizzle term.
     const int dk_row = wave * 8 + (lane >> 4), dv_row = wave * 16 + (lane >> 3);
     const unsigned dk_c = (unsigned)(((lane & 15) ^ (dk_row & 15)) << 4);
     const int dv_lc = (lane & 7) ^ ((dv_row >> 1) & 7);
-    auto dma_issue = [&](int n) {          // n = 0..3 (a literal at every call site): K rows, V^T rows, K rows, V^T rows
-        const unsigned dst = dma_dst;
-        const char* const kp = dma_kp;
-        const char* const vp = dma_vp;
+    auto dma_issue = [&](int n, int stage) {          // n = 0..3 (a literal at every call site): K rows, V^T rows, K rows, V^T rows
+        const unsigned dst = dst_w + stage * STAGE;
         if ((n & 1) == 0) {
             int krow = dk_row + (n >> 1) * 4;
             const unsigned kc = dk_c ^ ((n >> 1) * 64);
-            if (dma_lim < KVB) krow = krow < dma_lim ? krow : dma_lim - 1;
-            const unsigned ok = (unsigned)krow * dma_kls2 + kc;
+            if (drem < KVB) krow = krow < drem ? krow : drem - 1;
+            const unsigned ok = (unsigned)krow * dkls2 + kc;
             if (n == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(ok), "s"(kp) : "memory", "m0");
             else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + 1024), "v"(ok), "s"(kp) : "memory", "m0");
         } else {
             const int vrow = dv_row + (n >> 1) * 8;
             int lc = dv_lc ^ ((n >> 1) * 4);
-            if (dma_lim < KVB) lc = lc * 8 < dma_lim ? lc : 0;
-            const unsigned ov = (unsigned)vrow * dma_vls2 + (unsigned)(lc << 4);
+            if (drem < KVB) lc = lc * 8 < drem ? lc : 0;
+            const unsigned ov = (unsigned)vrow * dvls2 + (unsigned)(lc << 4);
             if (n == 1) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + VOFF), "v"(ov), "s"(vp) : "memory", "m0");
             else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst + VOFF + 1024), "v"(ov), "s"(vp) : "memory", "m0");
         }
@@ -297,8 +282,9 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         for (int c = 0; c < 4; ++c) pf[c] = pack8<T>(s[c >> 1], (c & 1) * 8);
     };
 
-    // close a softmax group: normalise o, store it (or add it to what the previous group stored), start the next group from zero.
-    // `next_item`: the group was the item's last, the output rows move on to the item whose Q fragments are already in qf.
+    // close a softmax group: normalise o, store it (or add it to what the previous group stored), start the next group from zero; returns the
+    // number of store instructions certainly issued.  F_NEXT_ITEM: the group was the item's last, the consumer moves on to the item whose Q
+    // fragments are already in qf.
     auto flush = [&](int flags) -> int {
         int issued = 0;
         float l_tot;
@@ -307,22 +293,21 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
             const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         }
-        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        const float inv = l_tot > 0.f ? __builtin_amdgcn_rcpf(l_tot) : 0.f;
         kernarg_t a = args();
+        const int heads = a->heads, c_b = c_hb / heads, c_h = c_hb - c_b * heads;
         const int64_t Lq = a->Lq;
-        if (a->lse && qvalid && hi == 0) a->lse[((int64_t)c_b * a->heads + c_h) * Lq + qrow] = m_run + log2f(l_tot);
+        const int l = opaque_lane();
+        const int64_t row0 = (int64_t)c_qt * QB + __builtin_amdgcn_readfirstlane(wave) * 32;
+        if (a->lse && row0 + (l & 31) < Lq && l < 32) a->lse[((int64_t)c_b * heads + c_h) * Lq + row0 + l] = m_run + log2f(l_tot);
         if (!(M4D_ABL(p) & 4)) {
             // The accumulators hold 4 consecutive d per (lane, register quad): stored from there, every instruction touches 32 rows with
-            // 16 bytes each — 4 096 sixteen-byte write transactions per item, measured at 4-5 us per flush (a quarter of this kernel's time).
-            // So each wave transposes its 32 x 128 tile through 4 KiB of LDS of its own, half of D at a time (row-major, 16-byte chunk ^
-            // ((row >> 1) & 7)), and writes rows: eight lanes cover the 128 contiguous bytes of a row, an instruction writes 8 full lines.
+            // 16 bytes each.  Each wave transposes its 32 x 128 tile through 4 KiB of LDS of its own, half of D at a time (row-major, 16-byte
+            // chunk ^ ((row >> 1) & 7)), and writes rows: eight lanes cover the 128 contiguous bytes of a row, an instruction 8 full lines.
             char* const ep = xsmem + 4 * STAGE + wave * 4096;
-            const int l = opaque_lane();
             const int er = l >> 3, ej = l & 7, fli = l & 31, fhi = l >> 5;
-            const int64_t row0 = (int64_t)c_qt * QB + __builtin_amdgcn_readfirstlane(wave) * 32;
-            // wave-uniform base (scalars only) + 32-bit lane offset: global_load / global_store in the saddr form
             const int64_t o_ls = a->o_ls;
-            T* const obase = (T*)a->out + (c_b * a->o_bs + (int64_t)c_h * D + row0 * o_ls);
+            T* const obase = (T*)a->out + (c_b * a->o_bs + (int64_t)c_h * D + row0 * o_ls);      // wave-uniform base + 32-bit lane offsets
             const unsigned ols = (unsigned)o_ls;
             const int nrows = Lq - row0 < 32 ? (int)(Lq - row0) : 32;
 #pragma unroll
@@ -371,32 +356,29 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
         m_run = -INFINITY; l_run = 0.f;
-        if (flags & F_NEXT_ITEM) {
-            advance(c_b, c_h, c_qt);
-            qrow = (int64_t)c_qt * QB + wave * 32 + li;
-            qvalid = qrow < Lq;
-        }
+        if (flags & F_NEXT_ITEM) advance(a, c_hb, c_qt);
         return issued;
     };
     // the item's last QK has been issued: fetch the next item's Q fragments into qf
     auto fetch_next_q = [&]() -> int {
-        int n_b = c_b, n_h = c_h, n_qt = c_qt;
-        advance(n_b, n_h, n_qt);
         if (M4D_ABL(p) & 8) return 0;
-        load_q(n_b, n_h, (int64_t)n_qt * QB + wave * 32 + (opaque_lane() & 31));
+        int n_hb = c_hb, n_qt = c_qt;
+        advance(args(), n_hb, n_qt);
+        load_q(n_hb, n_qt);
         return 8;
     };
 
+    // codes of tiles g-1 (early group: its flush is still owed), g, g+1, g+2, g+3: 12 bits each in one scalar pair
+    unsigned long long codes = (unsigned long long)KVB * 0x0001001001001000ull;
+#define cprev ((int)(codes & 0xfff))
+#define c0 ((int)((codes >> 12) & 0xfff))
+#define c1 ((int)((codes >> 24) & 0xfff))
+#define c2 ((int)((codes >> 36) & 0xfff))
+#define SET_CODE(I, V) (codes = (codes & ~(0xfffull << (12 * ((I) + 1)))) | ((unsigned long long)(V) << (12 * ((I) + 1))))
     // ---- pipeline prologue: tiles 0..2 requested, S(0) computed in lock-step, then the groups split ----
-    // codes of tiles g, g+1, g+2, g+3: 16 bits each in one scalar pair (c0 = tile g in the low bits)
-    unsigned long long codes = (unsigned long long)KVB * 0x0001000100010001ull;
-#define c0 ((int)(codes & 0xffff))
-#define c1 ((int)((codes >> 16) & 0xffff))
-#define c2 ((int)((codes >> 32) & 0xffff))
-#define SET_CODE(I, V) (codes = (codes & ~(0xffffull << (16 * (I)))) | ((unsigned long long)(V) << (16 * (I))))
-    { const int c = dma_prepare(0); SET_CODE(0, c); } dma_issue(0); dma_issue(1); dma_issue(2); dma_issue(3);
-    if (G > 1) { const int c = dma_prepare(1); SET_CODE(1, c); dma_issue(0); dma_issue(1); dma_issue(2); dma_issue(3); }
-    if (G > 2) { const int c = dma_prepare(2); SET_CODE(2, c); dma_issue(0); dma_issue(1); dma_issue(2); dma_issue(3); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i < G) { dma_issue(0, i); dma_issue(1, i); dma_issue(2, i); dma_issue(3, i); const int c = next_tile(); SET_CODE(i, c); }
     if (G > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tiles 0 and 1 (and the Q fragments) landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((c0 & 255) < KVB) sanitize(0, c0 & 255);
@@ -412,12 +394,13 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
 #define M4D_V_BODY(CODE)                                                                                              \
     do {                                                                                                             \
         m_prefetch<0, 4>(ring, va, ka);                                                                              \
-        if (!(M4D_ABL(p) & 1)) softmax((CODE) & 255);                                                                \
+        if (!(M4D_ABL(p) & 1)) softmax((XP_VAR & 1) ? KVB : ((CODE) & 255));                                         \
         asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));                                          \
         asm volatile("" : "+v"(l_run), "+v"(m_run));                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
-    // M(g): PV(g) then QK(g+1) as one stream of 32 MFMAs; in its shadows the request of tile g+3 and the fragment-address advances
+    // M(g): PV(g) then QK(g+1) as one stream of 32 MFMAs; in its shadows the request of tile g+3 (steps 4..7), the iterator's step to the
+    // tile after it (step 8) and the fragment-address advances
 #define M4D_M_BODY()                                                                                                  \
     do {                                                                                                             \
         const bool do_dma = g + 3 < G;                                                                               \
@@ -425,8 +408,8 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         const unsigned dk = ((g + 2) & 3) ? (unsigned)STAGE : (unsigned)(-3 * STAGE);                                \
         auto hook = [&](auto JJ) {                                                                                   \
             constexpr int J = decltype(JJ)::value;                                                                   \
-            if constexpr (J == 3) { if (do_dma) { const int c = dma_prepare((g + 3) & 3); SET_CODE(3, c); } }           \
-            if constexpr (J >= 4 && J < 8) { if (do_dma && !(M4D_ABL(p) & 16)) dma_issue(J - 4); }                   \
+            if constexpr (J >= 4 && J < 8) { if (do_dma && !(M4D_ABL(p) & 16)) dma_issue(J - 4, (g + 3) & 3); }      \
+            if constexpr (J == 8) { if (do_dma) { const int c = next_tile(); SET_CODE(3, c); } }                     \
             if constexpr (J >= 8 && J < 12) va[J - 8] += dv;                                                         \
             if constexpr (J >= 10 && J <= 24 && (J & 1) == 0) ka[(J - 10) >> 1] += dk;                               \
             if constexpr (J == 15) {      /* QK(g+1) opens the next item: its Q fragments (older than this interval's tile request) */ \
@@ -438,7 +421,8 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         };                                                                                                           \
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                      \
         if (!(M4D_ABL(p) & 2)) m_steps<0, 32, 0>(ring, va, ka, pf, qf, o, s, hook);                                  \
-        else { if (do_dma) { const int c = dma_prepare((g + 3) & 3); SET_CODE(3, c); dma_issue(0); dma_issue(1); dma_issue(2); dma_issue(3); }    \
+        else { if (do_dma) { dma_issue(0, (g + 3) & 3); dma_issue(1, (g + 3) & 3); dma_issue(2, (g + 3) & 3); dma_issue(3, (g + 3) & 3);   \
+                             const int c = next_tile(); SET_CODE(3, c); }                                            \
                _Pragma("unroll") for (int c = 0; c < 4; ++c) va[c] += dv;                                            \
                _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) ka[kk] += dk; }                                      \
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                      \
@@ -448,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
     // its 4 DMA pieces + AFTER = the stores of a flush / the Q fragments of the next item that are known to have been issued behind it.
 #define M4D_END_INTERVAL(AFTER)                                                                                       \
     do {                                                                                                             \
-        switch ((g + 3 < G ? 4 : 0) + (AFTER)) {                                                                     \
+        switch ((XP_VAR & 8) ? (g + 3 < G ? 4 : 0) : (g + 3 < G ? 4 : 0) + (AFTER)) {                                \
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                                          \
             case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                          \
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;                                          \
@@ -457,10 +441,10 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
             case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;                                        \
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
         }                                                                                                            \
-        if (g + 2 < G && (c2 & 255) < KVB) sanitize((g + 2) & 3, c2 & 255);                                          \
+        if (!(XP_VAR & 2) && g + 2 < G && (c2 & 255) < KVB) sanitize((g + 2) & 3, c2 & 255);                         \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         __builtin_amdgcn_s_barrier();                                                                                \
-        codes >>= 16;                                                                                                \
+        codes >>= 12;                                                                                                \
     } while (0)
 #define M4D_LAST_PV()                                                                                                 \
     do {                                                                                                             \
@@ -472,15 +456,15 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
     // The early group flushes tile g at the head of interval g+1 (its stores are then older than that interval's tile request), the late
     // group between M(g) and V(g+1).  (Both groups flushing in interval g — the early one behind its M(g) — was measured 2 % slower: the
     // flush's VALU work then runs beside the late group's softmax instead of beside its MFMA stream.)
-    int cprev = 0;                                                    // code of tile g-1 (early group: its flush is still owed)
     if (grp == 0) {
         // early group, interval g: [flush of tile g-1] [next item's Q if tile g is its item's last] V(g) M(g)
         for (; g + 1 < G; ++g) {
-            if ((cprev >> 8) & F_GROUP_END) flush(cprev >> 8);
-            if ((c0 >> 8) & F_NEXT_ITEM) fetch_next_q();
+            if (!(XP_VAR & 4)) {
+                if ((cprev >> 8) & F_GROUP_END) flush(cprev >> 8);
+                if ((c0 >> 8) & F_NEXT_ITEM) fetch_next_q();
+            }
             M4D_V_BODY(c0);
             M4D_M_BODY();
-            cprev = c0;
             M4D_END_INTERVAL(0);
         }
         if ((cprev >> 8) & F_GROUP_END) flush(cprev >> 8);
@@ -493,14 +477,17 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
         for (; g + 1 < G; ++g) {
             M4D_M_BODY();
             int after = 0;
-            if ((c0 >> 8) & F_GROUP_END) after = flush(c0 >> 8);
-            if ((c1 >> 8) & F_NEXT_ITEM) after += fetch_next_q();
+            if (!(XP_VAR & 4)) {
+                if ((c0 >> 8) & F_GROUP_END) after = flush(c0 >> 8);
+                if ((c1 >> 8) & F_NEXT_ITEM) after += fetch_next_q();
+            }
             M4D_V_BODY(c1);
             M4D_END_INTERVAL(after);
         }
         M4D_LAST_PV();
     }
     flush((c0 >> 8) & ~F_NEXT_ITEM);
+#undef cprev
 #undef c0
 #undef c1
 #undef c2
