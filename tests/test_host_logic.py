@@ -515,3 +515,29 @@ def test_scheduler_entry_points_match_reference(monkeypatch):
     out = sch.step(z["v"], sch.timesteps[10], z["x"], return_dict=False)[0]
     assert rel_err(out, z["x_step"]) < 1e-6 and sch.step_index == int(z["step_index_after"])
     assert rel_err(sch.add_noise(z["x"], z["n"], z["ts"]), z["noisy_mid"]) < 1e-6
+
+
+def test_production_kernels_do_not_spill():
+    """Code-object metadata of the built objects (no GPU needed): the production MFMA kernels use no scratch memory.  A spill in one of
+    them is a build regression (hipcc under register pressure), and scratch loads share vmcnt with the hand-counted tile waits."""
+    import importlib.util
+    import glob
+    spec = importlib.util.spec_from_file_location("kernel_regs", os.path.join(ROOT, "tools", "kernel_regs.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    objs = {os.path.basename(o): o for o in glob.glob(os.path.join(ROOT, "more4d_amd", "build", "*.hip.o")) if ".abl." not in o and o.count(".") == 2}
+    if "attention.hip.o" not in objs:
+        pytest.skip("objects not built (python -m more4d_amd.build)")
+    want = {"attention.hip.o": ("attn128p_kernel", "attn128x_kernel", "attn128_kernel"),
+            "attention_bwd.hip.o": ("attn_bwd_kvp_kernel", "attn_bwd_dqp_kernel"),
+            "gemm_wide_store.hip.o": ("gemm_bt256w_kernel",), "gemm_wide_resid.hip.o": ("gemm_bt256w_kernel",),
+            "gemm_wide_gelu.hip.o": ("gemm_bt256w_kernel",), "conv.hip.o": ("conv_halo_kernel",)}
+    seen = 0
+    for obj, names in want.items():
+        if obj not in objs:
+            continue
+        for k in kr.kernels(objs[obj]):
+            if any(n in k["name"] for n in names):
+                seen += 1
+                assert int(k["scratch"]) == 0 and int(k["spill"]) == 0, (obj, k)
+    assert seen >= 8
