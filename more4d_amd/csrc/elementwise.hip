@@ -81,12 +81,12 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
 // b, b + gridDim.x, ... (one row per wave, as above), re-filling the LDS when the walk crosses a sample boundary.  Per-row arithmetic and
 // its order are the kernel's above: same bits.  (Four waves per SIMD like the kernel above: without the bound hipcc takes 173 VGPRs
 // for the loop and halves the occupancy — the first version of this kernel was 9 % slower for that reason alone.)
-template <typename TI, typename TO, int MAXV>
-__global__ __launch_bounds__(256, 3) void ln_modulate_rows_kernel(LnArgs p) {
+template <typename TI, typename TO, int MAXV, int OCC = 3, bool NT = false, bool FULL = false>
+__global__ __launch_bounds__(256, OCC) void ln_modulate_rows_kernel(LnArgs p) {
     extern __shared__ __attribute__((aligned(16))) float ln_ab[];      // A[C], B[C]
     constexpr int G = 64;
     const int tid = threadIdx.x;
-    const int sub = tid >> 6, lt = tid & 63;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6), lt = tid & 63;      // (wave-uniform row: scalar base + lane offset addressing)
     const int C = p.C, nv = C >> 2;
     const bool affine = p.ln_w != nullptr;
     const int64_t nblk = (p.rows + 3) / 4;
@@ -114,8 +114,12 @@ __global__ __launch_bounds__(256, 3) void ln_modulate_rows_kernel(LnArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) {
-                v[i] = load4(xr + c4 * 4);
+            if (FULL || c4 < nv) {      // FULL: C == MAXV * 256 (host-checked), no per-piece lane predicates
+                // (scalar base stepped per group of four pieces + one lane offset + immediates: not twenty offset registers)
+                const TI* xg = xr + (i >> 2) * (4 * G * 4);
+                const int cg = lt * 4 + (i & 3) * (G * 4);
+                if constexpr (NT && sizeof(TI) == 4) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xg + cg));
+                else v[i] = load4(xg + cg);
                 s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
             }
         }
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256, 3) void ln_modulate_rows_kernel(LnArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) {
+            if (FULL || c4 < nv) {      // FULL: C == MAXV * 256 (host-checked), no per-piece lane predicates
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
             }
@@ -132,17 +136,19 @@ __global__ __launch_bounds__(256, 3) void ln_modulate_rows_kernel(LnArgs p) {
         const float rstd = rsqrtf(wave_sum(q) / C + p.eps);
         if (!active) continue;
         TO* orow = (TO*)p.out + row * C;
+        const float* lnB = (const float*)__builtin_assume_aligned(ln_ab + C, 16);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) {
+            if (FULL || c4 < nv) {      // FULL: C == MAXV * 256 (host-checked), no per-piece lane predicates
                 const int c = c4 * 4;
                 f32x4 y;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd;
-                y = y * *reinterpret_cast<const f32x4*>(ln_ab + c) + *reinterpret_cast<const f32x4*>(ln_ab + C + c);
-                store4(orow + c, y);
+                y = y * *reinterpret_cast<const f32x4*>(ln_ab + c) + *reinterpret_cast<const f32x4*>(lnB + c);
+                store4(orow + (i >> 2) * (4 * G * 4) + lt * 4 + (i & 3) * (G * 4), y);
             }
+            if ((i & (OCC >= 4 ? 1 : 3)) == (OCC >= 4 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);      // (A / B reads of at most four / two pieces in flight: hoisted further they cost registers)
         }
     }
 }
@@ -179,6 +185,14 @@ template <typename T, int EPV> M4D_DEV void store_vec(T* p, const float (&v)[EPV
         for (int e = 0; e < 4; ++e) r[e] = v[e];
         *reinterpret_cast<f32x4*>(p) = r;
     }
+}
+
+// one rotation (a, b) -> (a c - b s, a s + b c) with the contraction spelled out, so that every kernel that rotates rounds alike
+M4D_DEV void rope_pair(float a, float b, float c, float s, float& y0, float& y1) {
+#pragma clang fp contract(off)
+    const float bs = b * s, bc = b * c;
+    y0 = __builtin_fmaf(a, c, -bs);
+    y1 = __builtin_fmaf(a, s, bc);
 }
 
 template <typename T, int MAXV>
@@ -237,13 +251,92 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs p) {
                     const f32x2 cs = *reinterpret_cast<const f32x2*>(ct + pi + (e >> 1));
                     const f32x2 sn = *reinterpret_cast<const f32x2*>(st + pi + (e >> 1));
                     const float a0 = y[e], b0 = y[e + 1], a1 = y[e + 2], b1 = y[e + 3];
-                    y[e] = a0 * cs[0] - b0 * sn[0];
-                    y[e + 1] = a0 * sn[0] + b0 * cs[0];
-                    y[e + 2] = a1 * cs[1] - b1 * sn[1];
-                    y[e + 3] = a1 * sn[1] + b1 * cs[1];
+                    rope_pair(a0, b0, cs[0], sn[0], y[e], y[e + 1]);
+                    rope_pair(a1, b1, cs[1], sn[1], y[e + 2], y[e + 3]);
                 }
             }
             store_vec<T, EPV>(xr + c, y);
+        }
+    }
+}
+
+// The DiT's shape of the kernel above (C = 5120: every lane owns exactly NVEC 16-byte pieces of its row; rows >= 4096) as a straight-line,
+// persistent form.  What the general kernel costs there (ISA, round 4): its per-piece lane predicates put every row load into a basic
+// block of its own, so hipcc waits for each piece before requesting the next (ten serial HBM round trips per row), and the second pass
+// loads the weight (20 KB of fp32 per 10 KB row) and eight-byte cos / sin pairs from L2 behind the reduction, piece by piece: 130 vector
+// memory instructions per row of which 20 move the row.  Here a workgroup walks row blocks b, b + gridDim.x, ... (one row per wave), all
+// pieces of a row are requested back to back, the weight sits in LDS (staged once per workgroup), and the rotation pairs of a lane are the
+// SAME for all its pieces (a piece step is 64 lanes x 16 bytes = a multiple of head_dim): two 16-byte loads per row, requested with the
+// row.  Arithmetic and its order are the general kernel's: same bits.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256, 4) void rmsnorm_rope_rows_kernel(RmsArgs p) {
+    constexpr int EPV = 16 / sizeof(T);
+    constexpr int NVEC = MAXV * 4 / EPV;
+    extern __shared__ __attribute__((aligned(16))) float rms_w[];      // C weights (norm == true)
+    const int tid = threadIdx.x;
+    const int sub = __builtin_amdgcn_readfirstlane(tid >> 6), lt = tid & 63;
+    const int which = blockIdx.y;
+    const int C = p.C;
+    const float* w = p.w[which];
+    const bool norm = w != nullptr;
+    if (norm) {
+        for (int c4 = tid; c4 < (C >> 2); c4 += 256) *reinterpret_cast<f32x4*>(rms_w + c4 * 4) = load4(w + c4 * 4);
+        __syncthreads();
+    }
+    const int half = p.head_dim >> 1;
+    const int pi = ((lt * EPV) % p.head_dim) >> 1;      // first pair index inside the head of every piece of this lane
+    const int64_t nblk = (p.rows + 3) / 4;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t row = blk * 4 + sub;
+        if (row >= p.rows) continue;                    // wave-uniform
+        T* xr = (T*)p.x[which] + row * p.ld;
+        const int64_t l = row % p.rows_per_sample;
+        const bool rot = p.cos_t && l < p.rope_len;
+        float v[NVEC][EPV];
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) load_vec<T, EPV>(xr + (i >> 2) * (4 * 64 * EPV) + lt * EPV + (i & 3) * (64 * EPV), v[i]);
+        float cs[EPV / 2], sn[EPV / 2];
+        if (rot) {
+            const float* ct = p.cos_t + (p.pos_offset + l) * half + pi;
+            const float* st = p.sin_t + (p.pos_offset + l) * half + pi;
+#pragma unroll
+            for (int e = 0; e < EPV / 2; e += 2) {
+                const f32x2 c2 = *reinterpret_cast<const f32x2*>(ct + e), s2 = *reinterpret_cast<const f32x2*>(st + e);
+                cs[e] = c2[0]; cs[e + 1] = c2[1]; sn[e] = s2[0]; sn[e + 1] = s2[1];
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) s += v[i][e] * v[i][e];
+        const float inv = rsqrtf(wave_sum(s) / C + p.eps);
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+            const int c = (i >> 2) * (4 * 64 * EPV) + lt * EPV + (i & 3) * (64 * EPV);
+            float y[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; e += 4) {
+                if (norm) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(rms_w + c + e);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[e + j] = round_through<T>(v[i][e + j] * inv) * wv[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[e + j] = v[i][e + j];
+                }
+            }
+            if (rot) {
+#pragma unroll
+                for (int e = 0; e < EPV; e += 4) {
+                    const float c0 = cs[e >> 1], c1 = cs[(e >> 1) + 1], s0 = sn[e >> 1], s1 = sn[(e >> 1) + 1];
+                    const float a0 = y[e], b0 = y[e + 1], a1 = y[e + 2], b1 = y[e + 3];
+                    rope_pair(a0, b0, c0, s0, y[e], y[e + 1]);
+                    rope_pair(a1, b1, c1, s1, y[e + 2], y[e + 3]);
+                }
+            }
+            store_vec<T, EPV>(xr + c, y);
+            if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -468,9 +561,17 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
         }
         const int ncu = ncu_dev[dev];
         const size_t lds = (size_t)C * 8;
-        const int per_cu = 3;          // 168 VGPRs: three waves per SIMD
+        // C == 5120: every lane owns exactly twenty pieces of its row — no per-piece lane predicates (FULL).  With them each piece sits in a
+        // basic block of its own: 106 SGPRs of masks, 168 VGPRs, twenty offset registers; without: 67 / 134 and 4.5 -> 5.2 TB/s
+        // (M4D_LN_VAR=5: the predicated form, A/B; four waves per SIMD and non-temporal row loads measured no different: tools/ab_elem.sh)
+        M4D_ENV_ONCE(ln_var, "M4D_LN_VAR", 0);
+        const int per_cu = 3;          // three waves per SIMD
         grid = dim3((unsigned)std::min<int64_t>((rows + 3) / 4, (int64_t)ncu * per_cu));
-#define LN_ROWS_LAUNCH(TI, TO) hipLaunchKernelGGL((ln_modulate_rows_kernel<TI, TO, 20>), grid, block, lds, st, p)
+#define LN_ROWS_LAUNCH(TI, TO)                                                                                        \
+    do {                                                                                                             \
+        if (C == 5120 && ln_var != 5) hipLaunchKernelGGL((ln_modulate_rows_kernel<TI, TO, 20, 3, false, true>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((ln_modulate_rows_kernel<TI, TO, 20>), grid, block, lds, st, p);                     \
+    } while (0)
         if (x_dt == M4D_F32 && out_dt == M4D_F32) LN_ROWS_LAUNCH(float, float);
         else if (x_dt == M4D_F32 && out_dt == M4D_BF16) LN_ROWS_LAUNCH(float, bf16_t);
         else if (x_dt == M4D_BF16 && out_dt == M4D_BF16) LN_ROWS_LAUNCH(bf16_t, bf16_t);
@@ -513,6 +614,26 @@ extern "C" int m4d_rmsnorm_rope(m4d_dtype dt, void* x0, void* x1, int64_t ld, co
     p.rope_len = rope_len; p.pos_offset = pos_offset; p.C = C; p.head_dim = head_dim; p.eps = eps;
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256), grid((unsigned)((rows + 3) / 4), x1 ? 2 : 1);
+    // straight-line persistent form for the DiT's width (M4D_RMS_ROWS=0: the general kernel, same bits)
+    M4D_ENV_ONCE(rms_rows, "M4D_RMS_ROWS", 1);
+    const int epv = dt == M4D_BF16 ? 8 : 4;
+    if (rms_rows && C == 5120 && rows >= 4096 && (64 * epv) % head_dim == 0 && (dt == M4D_BF16 || dt == M4D_F32) &&
+        (cos_t == nullptr || (((uintptr_t)cos_t | (uintptr_t)sin_t) % 8 == 0 && head_dim % 4 == 0))) {
+        static int ncu_dev[64] = {0};       // per device: a process may drive several GPUs
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+        if (!ncu_dev[dev]) {
+            int v = 0;
+            ncu_dev[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        }
+        const int64_t per_y = std::max<int64_t>(1, (int64_t)ncu_dev[dev] * 4 / (x1 ? 2 : 1));
+        const dim3 gr((unsigned)std::min<int64_t>((rows + 3) / 4, per_y), x1 ? 2 : 1);
+        const size_t lds = w0 ? (size_t)C * 4 : 0;
+        if (dt == M4D_BF16) hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<bf16_t, 20>), gr, block, lds, st, p);
+        else hipLaunchKernelGGL((rmsnorm_rope_rows_kernel<float, 20>), gr, block, lds, st, p);
+        M4D_CHECK_LAUNCH("rmsnorm_rope");
+        return 0;
+    }
 #define RMS_LAUNCH(T)                                                                                 \
     do {                                                                                              \
         if (C <= 2048) hipLaunchKernelGGL((rmsnorm_rope_kernel<T, 8>), grid, block, 0, st, p);        \
