@@ -300,7 +300,8 @@ def test_train_step_configs4_per_gpu_work_two_layers():
     # the recomputing forward is WanAttentionBlock.run (gated residual fused into the GEMM epilogue), the storing forward is
     # block_backward's forward half (separate resid_gate pass): same values up to one fp32 rounding of the residual stream, which
     # moves a few bf16 roundings downstream
-    assert math.isfinite(l0) and abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+    # (measured 3e-6 .. 1.3e-5 depending on which bf16 roundings the last-bit difference happens to move)
+    assert math.isfinite(l0) and abs(l0 - l1) <= 5e-5 * abs(l0), (l0, l1)
     for n in names:
         assert float(g0[n].abs().max()) > 0
         # two bf16 evaluations whose residual streams differ in the last fp32 bit: they differ from each other like each differs
