@@ -195,11 +195,14 @@ M4D_DEV void flush_partials(const f32x4 (&part)[MAXV], float* lds, float* out, i
     __syncthreads();
 }
 
-template <typename TD, int MAXV>
+// FULL: C == MAXV * 256 (host-checked) — every lane owns all MAXV pieces of its row, no per-piece lane predicates.  With them each piece
+// sits in a basic block of its own and hipcc waits for its loads before it requests the next piece's (elementwise.hip: the same finding
+// on the forward kernels); the wave index is made scalar so that rows are addressed as scalar base + lane offset.
+template <typename TD, int MAXV, bool FULL = false>
 __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
     constexpr int G = 64;
     extern __shared__ __attribute__((aligned(16))) float red_lds[];   // C floats
-    const int lt = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lt = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sample = blockIdx.y;
     const int C = p.C, nv = C >> 2;
     const float* sc = p.scale ? p.scale + (int64_t)sample * p.mod_stride : nullptr;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) {
+            if (FULL || c4 < nv) {
                 v[i] = load4(xr + c4 * 4);
                 g[i] = load4(dr + c4 * 4);
                 dxo[i] = load4(dxr + c4 * 4);     // issued with the other loads: one memory round trip per row
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) {
+            if (FULL || c4 < nv) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
             }
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) {
+            if (FULL || c4 < nv) {
                 const int c = c4 * 4;
                 f32x4 xh = (v[i] - mean) * rstd;
                 ps[i] += g[i];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * G;
-            if (c4 < nv) store4(dxr + c4 * 4, dxo[i] + (g[i] - m1 - v[i] * m2) * rstd);
+            if (FULL || c4 < nv) store4(dxr + c4 * 4, dxo[i] + (g[i] - m1 - v[i] * m2) * rstd);
         }
     }
     if (p.dshift) {
@@ -356,10 +359,10 @@ struct RmsBwdArgs {
     int C, head_dim; float eps;
 };
 
-template <typename T, int MAXV>
+template <typename T, int MAXV, bool FULL = false>      // FULL: C == MAXV * 256 and 256 % head_dim == 0 (host-checked), see ln_bwd_kernel
 __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float red_lds[];   // C floats
-    const int lt = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lt = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int which = blockIdx.y;
     const int C = p.C, nv = C >> 2;
     const float* w = p.w[which];
@@ -376,17 +379,23 @@ __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
         const float* st = rot ? p.sin_t + (p.pos_offset + l) * half : nullptr;
         f32x4 v[MAXV], g[MAXV];
         float s = 0.f;
+        f32x2 cs0 = {0.f, 0.f}, sn0 = {0.f, 0.f};      // FULL: a piece step (256 elements) is a multiple of head_dim — one pair of loads per row
+        if (FULL && rot) {
+            const int pi0 = ((lt * 4) % p.head_dim) >> 1;
+            cs0 = *reinterpret_cast<const f32x2*>(ct + pi0);
+            sn0 = *reinterpret_cast<const f32x2*>(st + pi0);
+        }
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * 64;
-            if (c4 < nv) {
+            if (FULL || c4 < nv) {
                 const int c = c4 * 4;
                 v[i] = load4(xr + c);
                 g[i] = load4(dr + c);
                 if (rot) {   // transpose of the forward rotation on pairs (c, c+1), (c+2, c+3)
                     const int pi = (c % p.head_dim) >> 1;
-                    const f32x2 cs = *reinterpret_cast<const f32x2*>(ct + pi);
-                    const f32x2 sn = *reinterpret_cast<const f32x2*>(st + pi);
+                    const f32x2 cs = FULL ? cs0 : *reinterpret_cast<const f32x2*>(ct + pi);
+                    const f32x2 sn = FULL ? sn0 : *reinterpret_cast<const f32x2*>(st + pi);
                     const float a0 = g[i][0], b0 = g[i][1], a1 = g[i][2], b1 = g[i][3];
                     g[i][0] = a0 * cs[0] + b0 * sn[0];
                     g[i][1] = -a0 * sn[0] + b0 * cs[0];
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * 64;
-            if (c4 < nv) {
+            if (FULL || c4 < nv) {
                 const f32x4 xh = v[i] * inv;
                 pw[i] += g[i] * xh;
                 g[i] = g[i] * load4(w + c4 * 4);
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c4 = lt + i * 64;
-            if (c4 < nv) store4(dr + c4 * 4, (g[i] - v[i] * m2) * inv);
+            if (FULL || c4 < nv) store4(dr + c4 * 4, (g[i] - v[i] * m2) * inv);
         }
     }
     flush_partials<MAXV>(pw, red_lds, p.dw[which], nv, lt, wv);
@@ -570,7 +579,9 @@ extern "C" int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* 
     const size_t lds = (size_t)C * sizeof(float);
 #define LNB(TD, MV) hipLaunchKernelGGL((ln_bwd_kernel<TD, MV>), grid, block, lds, st, p)
     const bool bf = dy_dt == M4D_BF16;
-    if (C <= 2048) { if (bf) LNB(bf16_t, 8); else LNB(float, 8); }
+    M4D_ENV_ONCE(full_ok, "M4D_TRAIN_ROWS_FULL", 1);      // 0: the predicated kernels (A/B)
+    if (C == 5120 && full_ok) { if (bf) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 20, true>), grid, block, lds, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<float, 20, true>), grid, block, lds, st, p); }
+    else if (C <= 2048) { if (bf) LNB(bf16_t, 8); else LNB(float, 8); }
     else if (C <= 5120) { if (bf) LNB(bf16_t, 20); else LNB(float, 20); }
     else { if (bf) LNB(bf16_t, 32); else LNB(float, 32); }
 #undef LNB
@@ -619,7 +630,9 @@ extern "C" int m4d_rmsnorm_rope_bwd(m4d_dtype dt, void* dy0, void* dy1, int64_t 
     const size_t lds = (size_t)C * sizeof(float);
 #define RMB(T, MV) hipLaunchKernelGGL((rms_bwd_kernel<T, MV>), grid, block, lds, st, p)
     const bool bf = dt == M4D_BF16;
-    if (C <= 2048) { if (bf) RMB(bf16_t, 8); else RMB(float, 8); }
+    M4D_ENV_ONCE(full_ok, "M4D_TRAIN_ROWS_FULL", 1);      // 0: the predicated kernels (A/B)
+    if (C == 5120 && full_ok && 256 % p.head_dim == 0) { if (bf) hipLaunchKernelGGL((rms_bwd_kernel<bf16_t, 20, true>), grid, block, lds, st, p); else hipLaunchKernelGGL((rms_bwd_kernel<float, 20, true>), grid, block, lds, st, p); }
+    else if (C <= 2048) { if (bf) RMB(bf16_t, 8); else RMB(float, 8); }
     else if (C <= 5120) { if (bf) RMB(bf16_t, 20); else RMB(float, 20); }
     else { if (bf) RMB(bf16_t, 32); else RMB(float, 32); }
 #undef RMB
