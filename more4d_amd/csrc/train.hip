@@ -16,7 +16,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(TrArgs p) {
     __shared__ T tile[64][64 + PAD];
     const int t = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    {
+    const bool inner = r0 + 64 <= p.R && c0 + 64 <= p.C;      // (workgroup-uniform) tile entirely inside: no per-access predicates —
+    if (inner) {                                              // predicated, every load sits in its own basic block and is waited for alone
+        const int cx = (t & 15) * 4, ry = t >> 4;
+        const T* src = (const T*)p.in + (r0 + ry) * p.ld_in + c0 + cx;
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = load4(src + i * 16 * p.ld_in);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[ry + i * 16][cx + e] = (T)v[i][e];
+    } else {
         const int cx = (t & 15) * 4, ry = t >> 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -36,7 +47,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(TrArgs p) {
         }
     }
     __syncthreads();
-    {
+    if (inner) {
+        const int rx = (t & 15) * 4, cy = t >> 4;
+        T* dst = (T*)p.out + (c0 + cy) * p.ld_out + r0 + rx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)tile[rx + e][cy + i * 16];
+            store4(dst + i * 16 * p.ld_out, v);
+        }
+    } else {
         const int rx = (t & 15) * 4, cy = t >> 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

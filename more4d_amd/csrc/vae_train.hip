@@ -448,12 +448,81 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p) {
 
 }  // namespace
 
+namespace {
+// All `nshift` (<= 4) shifted copies of one 64-pixel x 64-channel tile from ONE load of its 64 + nshift - 1 pixels: the shifted panels of
+// a conv's weight-gradient operand differ by one pixel each, and the per-pixel index arithmetic (two 64-bit divisions) costs more than the
+// 32 bytes it fetches.  Same output as pad_transpose_kernel launched once per shift.
+template <typename T>
+__global__ __launch_bounds__(256) void pad_transpose_ms_kernel(PadTArgs p, int nshift) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ __attribute__((aligned(16))) T tile[64 + 3][64 + EPV];
+    const int c0 = blockIdx.y * 64;
+    const int64_t q0 = (int64_t)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int64_t hw = (int64_t)p.Hp * p.Wp;
+    const bool vec_in = (p.ps % EPV) == 0 && (((uintptr_t)p.src) & 15) == 0;
+    for (int px = t >> 2; px < 64 + nshift - 1; px += 64) {      // pixel px of the tile, 16 channels starting at (t % 4) * 16
+        const int cpart = (t & 3) * 16;
+        const int64_t q = q0 + px;
+        const int64_t fr = q / hw;
+        const int r = (int)(q - fr * hw);
+        const int h = r / p.Wp - p.pad_top, w = r % p.Wp - p.pad_left;
+        const bool ok = fr < p.T && h >= 0 && h < p.H && w >= 0 && w < p.W;
+        const T* sp = (const T*)p.src + ((fr * p.H + h) * (int64_t)p.W + w) * p.ps + c0 + cpart;
+#pragma unroll
+        for (int v = 0; v < 16 / EPV; ++v) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            const int c = c0 + cpart + v * EPV;
+            if (ok && c + EPV <= p.C && vec_in) raw = *reinterpret_cast<const uint4*>(sp + v * EPV);
+            else if (ok && c < p.C) {
+                T tmp[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) tmp[e] = (c + e < p.C) ? sp[v * EPV + e] : (T)0.f;
+                raw = *reinterpret_cast<const uint4*>(tmp);
+            }
+            *reinterpret_cast<uint4*>(&tile[px][cpart + v * EPV]) = raw;
+        }
+    }
+    __syncthreads();
+    const int ch = t >> 2, qpart = (t & 3) * 16;
+    const int c = c0 + ch;
+    if (c >= p.C) return;
+    T col[16 + 3];
+#pragma unroll
+    for (int k = 0; k < 16 + 3; ++k) col[k] = tile[qpart + k][ch];
+    const bool vec_out = (p.ld_out % EPV) == 0 && (((uintptr_t)p.out) & 15) == 0;
+#pragma unroll
+    for (int sft = 0; sft < 4; ++sft) {
+        if (sft >= nshift) break;
+        T* op = (T*)p.out + ((int64_t)sft * p.C + c) * p.ld_out + q0 + qpart;
+#pragma unroll
+        for (int v = 0; v < 16 / EPV; ++v) {
+            T tmp[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) tmp[e] = col[sft + v * EPV + e];
+            if (vec_out && q0 + qpart + v * EPV + EPV <= p.cols) *reinterpret_cast<uint4*>(op + v * EPV) = *reinterpret_cast<const uint4*>(tmp);
+            else
+                for (int e = 0; e < EPV; ++e)
+                    if (q0 + qpart + v * EPV + e < p.cols) op[v * EPV + e] = tmp[e];
+        }
+    }
+}
+}  // namespace
+
 extern "C" int m4d_pad_transpose(m4d_dtype dt, const void* src, int64_t pixel_stride, int C, int T, int H, int W, int Hp, int Wp,
                                  int pad_top, int pad_left, int nshift, void* out, int64_t cols, m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "pad_transpose: bad dtype");
     M4D_CHECK_ARG(src && out && C > 0 && T > 0 && H > 0 && W > 0 && nshift > 0 && cols > 0, "pad_transpose: null/empty");
     M4D_CHECK_ARG(Hp >= H + pad_top && Wp >= W + pad_left && pixel_stride >= C, "pad_transpose: padded geometry smaller than the image");
     PadTArgs p{src, out, pixel_stride, cols, cols, C, T, H, W, Hp, Wp, pad_top, pad_left};
+    M4D_ENV_ONCE(ms, "M4D_PADT_MS", 1);      // 0: one workgroup per shift (A/B)
+    if (ms && nshift >= 2 && nshift <= 4) {
+        dim3 gm((unsigned)((cols + 63) / 64), (unsigned)((C + 63) / 64), 1), bm(256);
+        if (dt == M4D_BF16) hipLaunchKernelGGL(pad_transpose_ms_kernel<bf16_t>, gm, bm, 0, (hipStream_t)stream, p, nshift);
+        else hipLaunchKernelGGL(pad_transpose_ms_kernel<float>, gm, bm, 0, (hipStream_t)stream, p, nshift);
+        M4D_CHECK_LAUNCH("pad_transpose");
+        return 0;
+    }
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)nshift), block(256);
     if (dt == M4D_BF16) hipLaunchKernelGGL(pad_transpose_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(pad_transpose_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
