@@ -311,6 +311,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dqp_kernel(BwdArgs p) {
 
     if (xrow < p.LXs) {
         T* oa = (T*)p.out_a + b * p.oa_bs + xrow * p.oa_ls + (int64_t)h * D + hi * 4;
+        // accumulate mode: ALL sixteen previous quads are requested before the first store (interleaved load / add / store, every
+        // load is waited for alone behind the store in front of it: sixteen serial round trips per workgroup)
+        f32x4 prev[4][4];
+        if (p.accumulate) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) prev[d][rq] = load4(oa + d * 32 + rq * 8);
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -320,9 +329,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dqp_kernel(BwdArgs p) {
                 for (int e = 0; e < 4; ++e) v[e] = acc[d][rq * 4 + e];
                 T* dst = oa + d * 32 + rq * 8;
                 if (p.accumulate) {
-                    f32x4 prev = load4(dst);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += prev[e];
+                    for (int e = 0; e < 4; ++e) v[e] += prev[d][rq][e];
                 }
                 store4(dst, v);
             }
