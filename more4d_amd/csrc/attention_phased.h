@@ -341,26 +341,34 @@ __global__ __launch_bounds__(512, 2) void attn128p_kernel(AttnArgs p) {
         const T* kbase = seg_k(sg);
         const T* vbase = seg_v(sg);
         char* base = psmem;
+        // all four 16-byte pieces of a thread are requested unconditionally from clamped, in-bounds addresses and masked afterwards
+        // (predicated — `key < len ? load : 0` — each load sits in a basic block of its own and is waited for alone: four serial
+        // round trips in front of every workgroup's first MFMA).  K rows beyond the segment re-read its last row; V^T chunks beyond it
+        // re-read the first chunk of the tail; a partial chunk's padding columns exist (strides are multiples of 8) and are zeroed here.
+        const int rem = (int)(len - tail0);                      // 1 .. 63 valid keys
+        uint4 kraw[2], vraw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + 512 * i;
+            const int row = c >> 4, ch = c & 15;
+            kraw[i] = *reinterpret_cast<const uint4*>(kbase + (tail0 + (row < rem ? row : rem - 1)) * kls + ch * 8);
+            const int vrow = c >> 3, vch = c & 7;
+            vraw[i] = *reinterpret_cast<const uint4*>(vbase + vrow * vls + tail0 + (vch * 8 < rem ? vch * 8 : 0));
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = t + 512 * i;
             {
                 const int row = c >> 4, ch = c & 15;
-                const int64_t key = tail0 + row;
-                const uint4 v = key < len ? *reinterpret_cast<const uint4*>(kbase + key * kls + ch * 8) : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(base + swz_off<256>(row, ch)) = v;
+                *reinterpret_cast<uint4*>(base + swz_off<256>(row, ch)) = row < rem ? kraw[i] : make_uint4(0, 0, 0, 0);
             }
             {
                 const int row = c >> 3, ch = c & 7;
-                const int64_t key = tail0 + ch * 8;
-                const T* src = vbase + row * vls + key;
-                union { uint4 u; T e[8]; } tmp;
-                tmp.u = make_uint4(0, 0, 0, 0);
-                if (key + 8 <= len) tmp.u = *reinterpret_cast<const uint4*>(src);
-                else if (key < len) {
-                    for (int j = 0; j < 8; ++j)
-                        if (key + j < len) tmp.e[j] = src[j];
-                }
+                union { uint4 u; unsigned short e[8]; } tmp;
+                tmp.u = vraw[i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (ch * 8 + j >= rem) tmp.e[j] = 0;
                 *reinterpret_cast<uint4*>(base + VOFF + swz_off<128>(row, ch)) = tmp.u;
             }
         }

@@ -160,3 +160,30 @@ print(ops.launch_counts()["attn_xp"])
             outs.append(torch.load(f))
     assert counts == [1, 0]
     assert rel_err(outs[0].float(), outs[1].float()) < 8e-3
+
+
+def test_phased_kernel_ragged_tail_with_poisoned_padding():
+    """attn128p_kernel's peeled ragged tile reads whole 16-byte chunks from clamped addresses and masks them: NaN in the K rows / V^T
+    columns beyond the segment must not reach the output (2 048 + 37 keys, two segments with ragged tails)."""
+    from more4d_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(14)
+    B, n, d, Lq = 1, 8, 128, 1300
+    C = n * d
+    q = torch.randn(B, Lq, C, generator=g, device=DEV).to(BF)
+    for lens in ((2048 + 37,), (1024 + 5, 1100)):
+        segs, refs = make_segs(g, B, C, lens)
+        if len(lens) > 1:      # the phased kernel shares one V^T row stride across segments: both segments as column ranges of one buffer
+            from more4d_amd.ops import KV
+            Lp = [max(8, (L + 7) // 8 * 8) for L in lens]
+            k = torch.cat([s.k.view(B, lp, C) for s, lp in zip(segs, Lp)], 1).contiguous()
+            vt = torch.cat([s.vt.view(C, B, lp) for s, lp in zip(segs, Lp)], 2).contiguous()
+            tot = sum(Lp)
+            segs = [KV(k.view(-1)[off * C:], vt.view(C, B * tot)[:, off:], tot * C, C, tot, B * tot, L)
+                    for off, L in zip((0, Lp[0]), lens)]
+        ops.launch_counts(reset=True)
+        out = ops.attention(q, segs, B=B, Lq=Lq, heads=n, head_dim=d)
+        assert ops.launch_counts()["attn_phased"] == 1
+        assert torch.isfinite(out.float()).all()
+        rows = torch.arange(0, Lq, 3).to(DEV)
+        want = torch_groups(q, refs, [list(range(len(lens)))], B, Lq, n, d, rows)
+        assert rel_err(out[:, rows].float(), want.float()) < 8e-3
