@@ -309,12 +309,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dqp_kernel(BwdArgs p) {
 #undef DQP_GLDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if (xrow < p.LXs) {
-        T* oa = (T*)p.out_a + b * p.oa_bs + xrow * p.oa_ls + (int64_t)h * D + hi * 4;
+    // (epilogue-only kernel arguments through an opaque copy of the kernarg pointer: attention_bwd_kvp.h)
+    typedef const BwdArgs __attribute__((address_space(4))) * kernarg_t;
+    kernarg_t pa = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pa));
+    const int accumulate = pa->accumulate;
+    if (xrow < pa->LXs) {
+        T* oa = (T*)pa->out_a + b * pa->oa_bs + xrow * pa->oa_ls + (int64_t)h * D + hi * 4;
         // accumulate mode: ALL sixteen previous quads are requested before the first store (interleaved load / add / store, every
         // load is waited for alone behind the store in front of it: sixteen serial round trips per workgroup)
         f32x4 prev[4][4];
-        if (p.accumulate) {
+        if (accumulate) {
 #pragma unroll
             for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dqp_kernel(BwdArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[d][rq * 4 + e];
                 T* dst = oa + d * 32 + rq * 8;
-                if (p.accumulate) {
+                if (accumulate) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += prev[d][rq][e];
                 }

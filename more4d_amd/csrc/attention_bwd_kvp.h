@@ -433,15 +433,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
     }
 #undef KVP_GLDS
 
-    if (xrow < p.LXs) {
-        T* oa = ds_role ? (T*)p.out_a + b * p.oa_bs + xrow * p.oa_ls : (T*)p.out_b + b * p.ob_bs + xrow * p.ob_ls;
+    // (epilogue-only kernel arguments through an opaque copy of the kernarg pointer: scalar loads here instead of ~16 SGPRs that live
+    // through the loop of a kernel that is out of them — attention_xp.h)
+    typedef const BwdArgs __attribute__((address_space(4))) * kernarg_t;
+    kernarg_t pa = (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pa));
+    const int accumulate = pa->accumulate;
+    if (xrow < pa->LXs) {
+        T* oa = ds_role ? (T*)pa->out_a + b * pa->oa_bs + xrow * pa->oa_ls : (T*)pa->out_b + b * pa->ob_bs + xrow * pa->ob_ls;
         oa += (int64_t)h * D + hi * 4;
-        const float osc = ds_role ? p.scale : 1.f;       // dK = scale * sum (P (G - delta))^T Q
+        const float osc = ds_role ? pa->scale : 1.f;       // dK = scale * sum (P (G - delta))^T Q
         const bool keep = xvalid;                         // rows in [LX, LXs) are stored as zeros
         // accumulate mode: ALL sixteen previous quads are requested before the first store (interleaved load / add / store, every
         // load is waited for alone behind the store in front of it: sixteen serial round trips per workgroup)
         f32x4 prev[4][4];
-        if (p.accumulate) {
+        if (accumulate) {
 #pragma unroll
             for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = keep ? acc[d][rq * 4 + e] * osc : 0.f;
                 T* dst = oa + d * 32 + rq * 8;
-                if (p.accumulate) {
+                if (accumulate) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += prev[d][rq][e];
                 }
