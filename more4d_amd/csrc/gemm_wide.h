@@ -38,7 +38,11 @@ constexpr int W_A0 = 0, W_A1 = W_GRP, W_B0 = 2 * W_GRP, W_B1 = 3 * W_GRP;
 // per-element branch, no dependent load in front of a store) and 8 lanes cover one contiguous 128-byte (bf16) / 256-byte (fp32)
 // row segment.  EPI is a template parameter: the arithmetic is the shared epilogue's (gemm_common.h: epilogue_half_lds), in the
 // same order, so the results are bit-identical.
-template <typename T, int EPI>
+// INNER (gated residual only): the tile is not shifted into a neighbour (every row / column of it is this tile's to write) — the residual
+// loads and stores carry no lane predicates.  Predicated, each of them sits in an exec-masked basic block, hipcc cannot count what is in
+// flight across them and drains the queue (s_waitcnt vmcnt(0)) in front of every block's first update: the residual requests and stores
+// of the previous block's last iterations are waited for four times per tile and wave.  Straight-line it waits for the two loads it needs.
+template <typename T, int EPI, bool INNER = false>
 M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, const f32x16& a01, const f32x16& a10, const f32x16& a11,
                               int64_t m_base, int64_t n_base, int64_t m_lo, int64_t n_lo, int lane,
                               f32x4 (&r0)[8], f32x4 (&r1)[8], bool first, bool has_next, int64_t m_next, int64_t n_next) {
@@ -57,11 +61,28 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
     // Now a rolling window of eight iterations' residual values (r0 / r1, owned by the caller): the tile's first block requests all eight
     // before its accumulators go through LDS, and every iteration re-fills its slot with the same iteration of the NEXT block right after its
     // own store — a load has a whole block (~1.5 us) to arrive.
+    // INNER addressing: scalar base of (block, iteration) + two per-lane 32-bit offsets for the whole block (row lane >> 3, the lane's two
+    // chunks) — per-iteration 64-bit row pointers cost the 512-register kernel spills
+    auto uni64 = [](int64_t v) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi2 = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+        return (int64_t)(((unsigned long long)hi2 << 32) | lo);
+    };
+    const unsigned ldc4 = (unsigned)p.ldc * 4u;
+    const unsigned voffA = (unsigned)(lane >> 3) * ldc4 + (unsigned)cA * 16u, voffB = (unsigned)(lane >> 3) * ldc4 + (unsigned)cB * 16u;
     auto fetch = [&](int it, int64_t mb, int64_t nbase) {
+        if constexpr (INNER) {
+            const char* bi = (const char*)p.out + (uni64(mb) * p.ldc + uni64(nbase)) * 4 + (size_t)it * 8 * ldc4;
+            r0[it] = *reinterpret_cast<const f32x4*>(bi + voffA);
+            r1[it] = *reinterpret_cast<const f32x4*>(bi + voffB);
+            return;
+        }
         const int64_t m = mb + it * 8 + (lane >> 3);
         const float* src = (const float*)p.out + m * p.ldc + nbase;
-        r0[it] = (m >= m_lo && nbase + cA * 4 >= n_lo) ? load4(src + cA * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        r1[it] = (m >= m_lo && nbase + cB * 4 >= n_lo) ? load4(src + cB * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (INNER) { r0[it] = load4(src + cA * 4); r1[it] = load4(src + cB * 4); }
+        else {
+            r0[it] = (m >= m_lo && nbase + cA * 4 >= n_lo) ? load4(src + cA * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            r1[it] = (m >= m_lo && nbase + cB * 4 >= n_lo) ? load4(src + cB * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     };
     f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = {1.f, 1.f, 1.f, 1.f};
     bool one_gate = false;
@@ -71,6 +92,7 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
             for (int it = 0; it < 8; ++it) fetch(it, m_base, n_base);
         }
         one_gate = p.gate && m_base / p.rows_per_sample == (m_base + 63) / p.rows_per_sample;      // (wave-uniform) the block lies in one sample
+        if constexpr (INNER) one_gate = __builtin_amdgcn_readfirstlane((int)one_gate) != 0;        // ... and the compiler is told so
         if (one_gate) {
             const float* grow = p.gate + (m_base / p.rows_per_sample) * p.gate_stride;
             g0 = load4(grow + nb); g1 = load4(grow + nb2);
@@ -131,8 +153,14 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
                         v0 = v0 * load4(grow + nb); v1 = v1 * load4(grow + nb2);
                     }
                 }
-                if (m >= m_lo && nb >= n_lo) { v0 += r0[it]; store4(drow + nb, v0); }
-                if (m >= m_lo && nb2 >= n_lo) { v1 += r1[it]; store4(drow + nb2, v1); }
+                if constexpr (INNER) {
+                    char* bi = (char*)p.out + (uni64(m_base) * p.ldc + uni64(n_base)) * 4 + (size_t)it * 8 * ldc4;
+                    v0 += r0[it]; *reinterpret_cast<f32x4*>(bi + voffA) = v0;
+                    v1 += r1[it]; *reinterpret_cast<f32x4*>(bi + voffB) = v1;
+                } else {
+                    if (m >= m_lo && nb >= n_lo) { v0 += r0[it]; store4(drow + nb, v0); }
+                    if (m >= m_lo && nb2 >= n_lo) { v1 += r1[it]; store4(drow + nb2, v1); }
+                }
                 if (has_next) fetch(it, m_next, n_next);
             } else {
                 if (m >= m_lo && nb >= n_lo) store4(drow + nb, v0);
@@ -526,15 +554,22 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
     // (the host sends bf16 outputs whose rows are not 16-byte aligned, and the erf-GELU / SiLU epilogues of a few small GEMMs, to
     // gemm_bt256p_kernel)
     f32x4 res0[8], res1[8];      // rolling residual window of the gated-residual epilogue (unused by the others)
+    auto epilogue = [&](auto INNER_T) {
+        constexpr bool INNER = decltype(INNER_T)::value;
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
+        for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
-            const int nxt = nh * 2 + mh + 1;        // next block in this order: (nh', mh') = (nxt >> 1, nxt & 1)
-            epilogue_block64<T, EPI>(p, wl, acc[nh * 2][mh * 2], acc[nh * 2][mh * 2 + 1], acc[nh * 2 + 1][mh * 2], acc[nh * 2 + 1][mh * 2 + 1],
-                                 m0 + wm * 128 + mh * 64, n0 + wn * 128 + nh * 64, m_lo, n_lo, lane, res0, res1, nxt == 1, nxt < 4,
-                                 m0 + wm * 128 + (nxt & 1) * 64, n0 + wn * 128 + (nxt >> 1) * 64);
-        }
+            for (int mh = 0; mh < 2; ++mh) {
+                const int nxt = nh * 2 + mh + 1;        // next block in this order: (nh', mh') = (nxt >> 1, nxt & 1)
+                epilogue_block64<T, EPI, INNER>(p, wl, acc[nh * 2][mh * 2], acc[nh * 2][mh * 2 + 1], acc[nh * 2 + 1][mh * 2], acc[nh * 2 + 1][mh * 2 + 1],
+                                                m0 + wm * 128 + mh * 64, n0 + wn * 128 + nh * 64, m_lo, n_lo, lane, res0, res1, nxt == 1, nxt < 4,
+                                                m0 + wm * 128 + (nxt & 1) * 64, n0 + wn * 128 + (nxt >> 1) * 64);
+            }
+    };
+    if constexpr (EPI == M4D_EPI_RESID_GATE) {
+        if (m0 >= m_lo && n0 >= n_lo) epilogue(std::true_type{});        // (workgroup-uniform) the tile is not shifted into a neighbour
+        else epilogue(std::false_type{});
+    } else epilogue(std::false_type{});
     if constexpr (ABL & 64) {       // timestamps (shader cycles) + 100 MHz wall clock + hardware id into the tile's first output row
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = __builtin_readcyclecounter();
