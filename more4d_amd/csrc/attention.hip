@@ -628,6 +628,8 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             static bool configured_x = false;
             if (!configured_x) {
                 if (hipFuncSetAttribute((const void*)attn128x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768) != hipSuccess) return -3;
+                hipFuncSetAttribute((const void*)attn128x_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768);
+                hipFuncSetAttribute((const void*)attn128x_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768);
                 configured_x = true;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
@@ -637,7 +639,10 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             if (nwg < 8) nwg = 8;
             if (items < nwg && ((p.heads * p.B) & 7) != 0) nwg = (int)items;
             m4d_count_launch(M4D_KC_ATTN_XP);
-            hipLaunchKernelGGL((attn128x_kernel<1>), dim3((unsigned)nwg), dim3(512), 4 * 32768 + 32768, st, q);
+            M4D_ENV_ONCE(xprio, "M4D_ATTN_XP_PRIO", 1);      // A/B: 0 no s_setprio, 1 raised around every MFMA stream, 2 static (younger group)
+            if (xprio == 2) hipLaunchKernelGGL((attn128x_kernel<2>), dim3((unsigned)nwg), dim3(512), 4 * 32768 + 32768, st, q);
+            else if (xprio == 0) hipLaunchKernelGGL((attn128x_kernel<0>), dim3((unsigned)nwg), dim3(512), 4 * 32768 + 32768, st, q);
+            else hipLaunchKernelGGL((attn128x_kernel<1>), dim3((unsigned)nwg), dim3(512), 4 * 32768 + 32768, st, q);
         } else if (w8) {
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             m4d_count_launch(M4D_KC_ATTN_OTHER);

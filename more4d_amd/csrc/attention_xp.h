@@ -389,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void attn128x_kernel(AttnArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) ka[kk] += STAGE;                    // K side now points at tile 1 (stage 1)
 
+    if constexpr (PRIO == 2) { if (grp == 1) __builtin_amdgcn_s_setprio(1); }      // static: the younger wave group at priority 1, no per-phase flips
     int g = 0;
     // V(t): softmax of S(t) -> P(t); the first four fragments of the following PV are requested in front of it
 #define M4D_V_BODY(CODE)                                                                                              \
