@@ -426,6 +426,40 @@ __global__ __launch_bounds__(256) void unary_kernel(const TI* x, TO* out, int64_
     }
 }
 
+// eight elements per thread and iteration with 16-byte accesses (n % 8 == 0, both pointers 16-byte aligned: the residual-stream casts of
+// the DiT): the element-wise form above moves 4 + 2 bytes per lane and instruction — 1.8 TB/s where this one is bound by HBM
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void unary_vec8_kernel(const TI* x, TO* out, int64_t n8, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        if constexpr (sizeof(TI) == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+        } else {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+        }
+        if (act != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act == 1 ? silu_f(v[e]) : act == 2 ? gelu_tanh_f(v[e]) : gelu_erf_f(v[e]);
+        }
+        if constexpr (sizeof(TO) == 4) {
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+            *reinterpret_cast<f32x4*>(out + i * 8) = a;
+            *reinterpret_cast<f32x4*>(out + i * 8 + 4) = b;
+        } else {
+            bf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(out + i * 8) = a;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void add_bcast_kernel(const float* a, const float* bias, float* out, int64_t total, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = a[i] + bias[i % n];
@@ -699,6 +733,16 @@ extern "C" int m4d_unary(m4d_dtype in_dt, const void* x, m4d_dtype out_dt, void*
     M4D_CHECK_ARG(act >= 0 && act <= 3, "unary: bad act %d", act);
     dim3 block(256), grid(grid_for(n));
     hipStream_t st = (hipStream_t)stream;
+    if (n % 8 == 0 && n >= (1 << 16) && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        const dim3 g8(grid_for(n / 8));
+        if (in_dt == M4D_F32 && out_dt == M4D_F32) hipLaunchKernelGGL((unary_vec8_kernel<float, float>), g8, block, 0, st, (const float*)x, (float*)out, n / 8, act);
+        else if (in_dt == M4D_F32 && out_dt == M4D_BF16) hipLaunchKernelGGL((unary_vec8_kernel<float, bf16_t>), g8, block, 0, st, (const float*)x, (bf16_t*)out, n / 8, act);
+        else if (in_dt == M4D_BF16 && out_dt == M4D_BF16) hipLaunchKernelGGL((unary_vec8_kernel<bf16_t, bf16_t>), g8, block, 0, st, (const bf16_t*)x, (bf16_t*)out, n / 8, act);
+        else if (in_dt == M4D_BF16 && out_dt == M4D_F32) hipLaunchKernelGGL((unary_vec8_kernel<bf16_t, float>), g8, block, 0, st, (const bf16_t*)x, (float*)out, n / 8, act);
+        else { m4d_set_error("unary: bad dtypes"); return -1; }
+        M4D_CHECK_LAUNCH("unary");
+        return 0;
+    }
     if (in_dt == M4D_F32 && out_dt == M4D_F32) hipLaunchKernelGGL((unary_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)out, n, act);
     else if (in_dt == M4D_F32 && out_dt == M4D_BF16) hipLaunchKernelGGL((unary_kernel<float, bf16_t>), grid, block, 0, st, (const float*)x, (bf16_t*)out, n, act);
     else if (in_dt == M4D_BF16 && out_dt == M4D_BF16) hipLaunchKernelGGL((unary_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)out, n, act);
