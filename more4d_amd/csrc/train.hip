@@ -474,6 +474,15 @@ struct AdamArgs {
     float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;
     const float* grad_scale;     // optional device scalar multiplied into the gradient (clip coefficient)
 };
+// one element's update; the contraction is pinned (no fma) so that the element-wise and the eight-per-thread kernel round alike
+M4D_DEV void adamw_update(const AdamArgs& a, float g, float& w, float& m, float& v) {
+#pragma clang fp contract(off)
+    w *= 1.f - a.lr * a.wd;
+    m = a.beta1 * m + (1.f - a.beta1) * g;
+    v = a.beta2 * v + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    w -= (a.lr / a.bc1) * (m / denom);
+}
 template <typename T, typename TS>
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const float gs = a.grad_scale ? *a.grad_scale : 1.f;
@@ -481,14 +490,49 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
         const float g = (float)((const T*)a.g)[i] * gs;
         float w = (float)((T*)a.p)[i];
         float m = (float)((TS*)a.m)[i], v = (float)((TS*)a.v)[i];
-        w *= 1.f - a.lr * a.wd;
-        m = a.beta1 * m + (1.f - a.beta1) * g;
-        v = a.beta2 * v + (1.f - a.beta2) * g * g;
-        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        w -= (a.lr / a.bc1) * (m / denom);
+        adamw_update(a, g, w, m, v);
         ((T*)a.p)[i] = (T)w;
         ((TS*)a.m)[i] = (TS)m;
         ((TS*)a.v)[i] = (TS)v;
+    }
+}
+
+// eight elements per thread and iteration, 16-byte (bf16) / 2 x 16-byte (fp32) accesses; same arithmetic per element as adamw_kernel
+template <typename T> M4D_DEV void ld8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)r[e];
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    }
+}
+template <typename T> M4D_DEV void st8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x8*>(p) = r;
+    } else {
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+        *reinterpret_cast<f32x4*>(p) = a;
+        *reinterpret_cast<f32x4*>(p + 4) = b;
+    }
+}
+template <typename T, typename TS>
+__global__ __launch_bounds__(256) void adamw_vec8_kernel(AdamArgs a) {
+    const float gs = a.grad_scale ? *a.grad_scale : 1.f;
+    const int64_t n8 = a.n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float g[8], w[8], m[8], v[8];
+        ld8((const T*)a.g + i * 8, g); ld8((const T*)a.p + i * 8, w); ld8((const TS*)a.m + i * 8, m); ld8((const TS*)a.v + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) adamw_update(a, g[e] * gs, w[e], m[e], v[e]);
+        st8((T*)a.p + i * 8, w); st8((TS*)a.m + i * 8, m); st8((TS*)a.v + i * 8, v);
     }
 }
 
@@ -686,6 +730,14 @@ extern "C" int m4d_adamw(m4d_dtype dt, void* param, const void* grad, m4d_dtype 
     a.grad_scale = grad_scale;
     dim3 grid(grid_for(n, 256, 8192)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (n % 8 == 0 && n >= (1 << 16) && (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0) {
+        const dim3 g8(grid_for(n / 8, 256, 8192));
+        if (dt == M4D_BF16 && state_dt == M4D_BF16) hipLaunchKernelGGL((adamw_vec8_kernel<bf16_t, bf16_t>), g8, block, 0, st, a);
+        else if (dt == M4D_BF16) hipLaunchKernelGGL((adamw_vec8_kernel<bf16_t, float>), g8, block, 0, st, a);
+        else hipLaunchKernelGGL((adamw_vec8_kernel<float, float>), g8, block, 0, st, a);
+        M4D_CHECK_LAUNCH("adamw");
+        return 0;
+    }
     if (dt == M4D_BF16 && state_dt == M4D_BF16) hipLaunchKernelGGL((adamw_kernel<bf16_t, bf16_t>), grid, block, 0, st, a);
     else if (dt == M4D_BF16) hipLaunchKernelGGL((adamw_kernel<bf16_t, float>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((adamw_kernel<float, float>), grid, block, 0, st, a);
