@@ -9,7 +9,7 @@ cd $R
 timeout 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -1 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench.json; python -c "
 import json; d=json.load(open('$O/bench.json')); print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['mfma_frac_whole_step'])"
-timeout 600 python bench.py --mode train --steps 2 --warmup 1 > $O/train.log 2>&1; tail -1 $O/train.log > $O/train_bench.json; tail -c 400 $O/train_bench.json
+timeout 600 python bench.py --mode train --steps 2 --warmup 2 > $O/train.log 2>&1; tail -1 $O/train.log > $O/train_bench.json; tail -c 400 $O/train_bench.json
 bash tools/prof.sh > $O/prof.log 2>&1
 bash tools/prof_vae.sh > $O/prof_vae.log 2>&1
 export TMPDIR=/tmp
