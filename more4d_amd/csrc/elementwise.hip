@@ -18,11 +18,11 @@ struct LnArgs {
     int C; float eps;
 };
 
-template <typename TI, typename TO, int MAXV>
+template <typename TI, typename TO, int MAXV, bool FULL = false>      // FULL: C == MAXV * 256 (host-checked): no per-piece lane predicates (see the rows kernel below)
 __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
     constexpr int G = 64;
     const int tid = threadIdx.x;
-    const int sub = tid >> 6, lt = tid & 63;
+    const int sub = FULL ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lt = tid & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + sub;
     const bool active = row < p.rows;   // wave-uniform
     const int C = p.C, nv = C >> 2;
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c4 = lt + i * G;
-        if (c4 < nv) {
+        if (FULL || c4 < nv) {
             v[i] = load4(xr + c4 * 4);
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c4 = lt + i * G;
-        if (c4 < nv) {
+        if (FULL || c4 < nv) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
         }
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c4 = lt + i * G;
-        if (c4 < nv) {
+        if (FULL || c4 < nv) {
             const int c = c4 * 4;
             f32x4 y;
 #pragma unroll
@@ -617,7 +617,8 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
     }
 #define LN_LAUNCH(TI, TO)                                                                             \
     do {                                                                                              \
-        if (C <= 2048) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 8>), grid, block, 0, st, p);    \
+        if (C == 5120) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 20, true>), grid, block, 0, st, p); \
+        else if (C <= 2048) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 8>), grid, block, 0, st, p);    \
         else if (C <= 5120) hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 20>), grid, block, 0, st, p); \
         else hipLaunchKernelGGL((ln_modulate_kernel<TI, TO, 32>), grid, block, 0, st, p);             \
     } while (0)
