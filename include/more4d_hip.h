@@ -30,6 +30,9 @@ typedef enum { M4D_F32 = 0, M4D_BF16 = 1 } m4d_dtype;
 typedef void* m4d_stream;
 
 int m4d_version(void);
+/* sha256 (hex) of the csrc/ + include/ files the library was compiled from; more4d_amd/_lib.py refuses to load a
+ * library whose hash differs from the tree's, more4d_amd/build.py rebuilds on a mismatch (no reference counterpart). */
+const char* m4d_source_hash(void);
 const char* m4d_last_error(void);
 
 /* ---- diagnostics: which kernel structure the calls of this process dispatched to ----

@@ -34,6 +34,7 @@ class AttnBwdArgs(Structure):
 # name -> (restype, argtypes); mirrors include/more4d_hip.h one to one
 SIGNATURES = {
     "m4d_version": (c_int, []),
+    "m4d_source_hash": (c_char_p, []),
     "m4d_launch_count": (c_int64, [c_int, c_int]),
     "m4d_last_error": (c_char_p, []),
     "m4d_gemm_bt": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64,
@@ -152,6 +153,14 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if not ABLATION_BUILD:
+        # the shipped binary must be what the tracked sources compile to: the hash of csrc/ + include/ is compiled in (api.cpp)
+        from .build import source_hash
+        got, want = lib.m4d_source_hash().decode(), source_hash()
+        if got != want:
+            raise More4DHipError(
+                f"{LIB_PATH} was built from other sources (library {got[:16]}, tree {want[:16]}): "
+                "rebuild with `python -m more4d_amd.build`")
     _lib = lib
     return lib
 

@@ -19,6 +19,13 @@ extern "C" const char* m4d_last_error(void) { return g_err; }
 
 extern "C" int m4d_version(void) { return 100; }
 
+// sha256 of csrc/ + include/ at build time (more4d_amd/build.py: source_hash); _lib.load() refuses a library whose hash is not the tree's
+#ifndef M4D_SRC_HASH
+#define M4D_SRC_HASH "unhashed"
+#endif
+static const char g_src_hash[] = "M4D_SRC_HASH=" M4D_SRC_HASH;      // the tag lets build.py read the hash out of the file without dlopen
+extern "C" const char* m4d_source_hash(void) { return g_src_hash + 13; }
+
 // ---- per-kernel-class launch counters (diagnostics; see more4d_hip.h) ----
 static std::atomic<int64_t> g_launches[M4D_KC_COUNT];
 

@@ -43,6 +43,29 @@ def test_library_exports_every_declared_symbol():
         assert n == len(_lib.SIGNATURES[name][1]), f"{name}: header has {n} parameters, binding {len(_lib.SIGNATURES[name][1])}"
 
 
+def test_library_is_built_from_the_tracked_sources(tmp_path):
+    """build() proves itself: the sha256 of csrc/ + include/ is compiled into the library (m4d_source_hash) and _lib.load()
+    refuses a binary whose hash is not the tree's — a stale shipped .so cannot pass."""
+    import ctypes
+    import shutil
+    import subprocess
+    import sys
+    from more4d_amd import _lib, build
+    assert build.built_hash(_lib.LIB_PATH) == build.source_hash()
+    lib = _lib.load()
+    assert lib.m4d_source_hash().decode() == build.source_hash()
+    # a library with another hash is refused: copy the package skeleton, change one source byte, keep the binary
+    pkg = tmp_path / "more4d_amd"
+    shutil.copytree(os.path.join(ROOT, "more4d_amd"), pkg, ignore=shutil.ignore_patterns("build", "__pycache__", "libmore4d_hip_*.so"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    with open(pkg / "csrc" / "common.h", "a") as fh:
+        fh.write("\n// edited after the build\n")
+    code = "from more4d_amd import _lib\ntry:\n    _lib.load()\nexcept _lib.More4DHipError as e:\n    print('REFUSED', e)\n"
+    r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True,
+                       env={**os.environ, "PYTHONPATH": str(tmp_path)})
+    assert "REFUSED" in r.stdout and "other sources" in r.stdout, r.stdout + r.stderr
+
+
 def test_product_path_fails_loudly_without_gpu():
     from more4d_amd import ops
     from more4d_amd._lib import More4DHipError
