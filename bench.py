@@ -59,6 +59,105 @@ def flops_per_forward(cfg, L, B):
     return B * gemm, B * attn
 
 
+class ClockMonitor:
+    """Shader clock and socket power of ONE GPU, sampled by a thread while a region runs, so that two runs on different boxes (or
+    two commits on the same box) can be normalised: the loop is power-limited, boxes differ by +-4 % with identical code.
+    Sources, first that works: amdgpu sysfs of the device with torch's PCI address (pp_dpm_sclk: the starred level = current average
+    gfx clock; hwmon power1_average / power1_input in microwatts), else `rocm-smi --showclocks --showpower --json` as a child.
+    `region()` returns the mean / min / max of the samples taken between start() and stop() — `effective_clock_mhz` is the mean."""
+
+    def __init__(self, index=0, period=0.25):
+        import glob
+        import threading
+        self.period, self.samples, self._run, self._thr = period, [], False, None
+        self.source, self._sclk, self._power = None, None, None
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            want = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cands = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+        if want is not None:
+            hit = [c for c in cands if os.path.basename(os.path.realpath(c)).lower().startswith(want)]
+            cands = hit or (cands if len(cands) == 1 else [])
+        if cands:
+            d = cands[0]
+            self._sclk = os.path.join(d, "pp_dpm_sclk")
+            for f in ("power1_average", "power1_input"):
+                g = glob.glob(os.path.join(d, "hwmon", "hwmon*", f))
+                if g:
+                    self._power = g[0]
+                    break
+            self.source = "sysfs " + os.path.basename(os.path.realpath(d))
+        elif os.path.exists("/opt/rocm/bin/rocm-smi"):
+            self.source = f"rocm-smi -d {index}"
+        self._index = index
+        self._threading = threading
+
+    def _sample(self):
+        if self._sclk:
+            mhz = None
+            with open(self._sclk) as fh:
+                for line in fh:
+                    if "*" in line:
+                        mhz = float("".join(ch for ch in line.split(":")[1] if ch.isdigit() or ch == "."))
+            w = None
+            if self._power:
+                with open(self._power) as fh:
+                    w = float(fh.read()) / 1e6
+            return mhz, w
+        import subprocess
+        r = subprocess.run(["/opt/rocm/bin/rocm-smi", "-d", str(self._index), "--showclocks", "--showpower", "--json"],
+                           capture_output=True, text=True, timeout=10)
+        card = next(iter(json.loads(r.stdout).values()))
+        mhz = w = None
+        for k, v in card.items():
+            if k.startswith("sclk clock speed"):
+                mhz = float("".join(ch for ch in str(v) if ch.isdigit() or ch == "."))
+            if "Socket" in k and "Power" in k and "(W)" in k:
+                w = float(v)
+        return mhz, w
+
+    def _loop(self):
+        while self._run:
+            try:
+                self.samples.append((time.perf_counter(),) + tuple(self._sample()))
+            except Exception as ex:      # a monitor must never sink the measurement
+                self.error = repr(ex)[:200]
+                return
+            time.sleep(self.period)
+
+    def start(self):
+        if self.source is None:
+            return self
+        self.samples, self._run, self.error = [], True, None
+        self._thr = self._threading.Thread(target=self._loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        self._run = False
+        if self._thr is not None:
+            self._thr.join(timeout=15)
+
+    def region(self, t0=None, t1=None):
+        """statistics of the samples with t0 <= t <= t1 (perf_counter stamps; None = all)"""
+        if self.source is None:
+            return {"source": None, "note": "no amdgpu sysfs entry / rocm-smi for this device"}
+        ss = [x for x in self.samples if (t0 is None or x[0] >= t0) and (t1 is None or x[0] <= t1)]
+        out = {"source": self.source, "samples": len(ss), "period_s": self.period}
+        if getattr(self, "error", None):
+            out["error"] = self.error
+        for i, key in ((1, "clock_mhz"), (2, "socket_power_w")):
+            v = [x[i] for x in ss if x[i] is not None]
+            if v:
+                out[key] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+        if "clock_mhz" in out:
+            out["effective_clock_mhz"] = out["clock_mhz"]["mean"]
+        return out
+
+
 class KernelTimer:
     """HIP-event timing of individual launches on the stream they are enqueued on (torch's current stream —
     the one ops.py hands to the C ABI)."""
@@ -158,13 +257,15 @@ def secondary_figures(model, cfg, dev):
         def bwd_flops(q, k, v, o, d_o, lse, **kk):      # 10 L^2 d per head: S, dP, dV, dQ, dK (2 L^2 d each)
             return 10 * kk["B"] * kk["Lq"] * kk["Lk"] * kk["heads"] * kk["head_dim"]
         orig = kt.wrap(ops, "attention_bwd", bwd_flops)
+        mon = ClockMonitor(dev.index or 0).start()
         try:
             r = bench_train.run_train(model, cfg, dev, steps=3, warmup=1)
         finally:
             ops.attention_bwd = orig
+            mon.stop()
         ab = kt.summary().get("attention_bwd", {})
         out["roofline_attention_bwd"] = {
-            "kernel": "attn_bwd128_kernel<dQ|dK|dV> via m4d_attention_bwd (self + cross, 4 train steps incl. warm-up)", "bound": "mfma",
+            "kernel": "attn_bwd_kvp_kernel (fused dK / dV) + attn_bwd_dqp_kernel (dQ) via m4d_attention_bwd (self + cross, 4 train steps incl. warm-up)", "bound": "mfma",
             "achieved": ab.get("tflops", 0.0), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ab.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
             "launches": ab.get("launches", 0), "flops_convention": "10 B Lq Lk heads head_dim per call"}
         del ag
@@ -174,7 +275,7 @@ def secondary_figures(model, cfg, dev):
         med = each[len(each) // 2]
         out["train_step"] = {"s_per_step": med, "s_per_step_mean": r["value"], "each_step_s": r["each_step_s"],
                              "mfma_frac": r["mfma_frac"] * r["value"] / med, "max_mem_gb": r["max_mem_gb"],
-                             "stored_blocks": r["stored_blocks"],
+                             "stored_blocks": r["stored_blocks"], "clock": mon.region(),
                              "workload": "14B DiT fwd + bwd (+ recompute where activations are not stored) + clip + AdamW, batch 1, "
                                          "L=21840, bf16 params and optimizer state"}
     except Exception as ex:
@@ -562,6 +663,7 @@ def main():
                 return 4 * kk["B"] * kk["Lq"] * klen * kk["heads"] * kk["head_dim"]
             originals = {"gemm_bt": kt.wrap(ops, "gemm_bt", gemm_flops), "attention": kt.wrap(ops, "attention", attn_flops,
                                               lambda q, segs, **kk: "cross" if sum(sg.len for sg in segs) < 2048 else "self")}
+        mon = ClockMonitor(local_rank).start()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -571,6 +673,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        mon.stop()
+        clock = mon.region(t0, t0 + dt)
         if kt is not None:
             for name, fn in originals.items():
                 setattr(ops, name, fn)
@@ -658,7 +762,14 @@ def main():
             "rccl_ranks": rccl_ranks, "collectives": exposed,
             "step_tflop": step_flops / 1e12,
             "mfma_frac_whole_step": step_flops / (dt / args.steps) / 1e12 / (MFMA_BF16_PEAK_TF * world),
+            # shader clock / socket power of rank 0's GPU over the timed region: what a run has to be normalised by before two boxes
+            # are compared (same code: +-4 % box to box, all of it clock).  `mfma_frac_at_clock` = the whole-step MFMA fraction against
+            # the peak AT THE CLOCK THE BOARD GRANTED (2.5 PF is quoted at 2.4 GHz): how busy the pipes were, independent of the box.
+            "clock": clock,
         }
+        if clock.get("effective_clock_mhz"):
+            out["effective_clock_mhz"] = clock["effective_clock_mhz"]
+            out["mfma_frac_at_clock"] = out["mfma_frac_whole_step"] * 2400.0 / clock["effective_clock_mhz"]
         if kt is not None:
             ks = kt.summary()
             gk = ks.get("gemm_bt", {})
