@@ -29,7 +29,7 @@ def source_hash():
     h = hashlib.sha256()
     for d in (CSRC, INC):
         for f in sorted(os.listdir(d)):
-            if f.endswith((".hip", ".cpp", ".h")):
+            if f.endswith((".hip", ".cpp", ".h", ".inc")):
                 h.update(f.encode() + b"\0")
                 with open(os.path.join(d, f), "rb") as fh:
                     h.update(fh.read())
@@ -78,7 +78,7 @@ def _compile(src, abl=False):
     """One object per source.  Staleness is decided by CONTENT (source + every header + flags, kept beside the object as
     <obj>.hash), not by time stamps: a snapshot or a checkout does not preserve them."""
     obj = os.path.join(OBJDIR, src + (".abl.o" if abl else ".o"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
            [os.path.join(INC, f) for f in os.listdir(INC)]
     path = os.path.join(CSRC, src)
     stamp = ['-DM4D_SRC_HASH="%s"' % source_hash()] if src == "api.cpp" else []      # api.cpp carries the hash of the whole tree

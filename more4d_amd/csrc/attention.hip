@@ -534,6 +534,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn128_kernel(AttnArgs p) {
 #include "attention_phased.h"
 #include "attention_wide.h"
 #include "attention_xp.h"
+#include "attention_q64.h"
 
 int attn_device_cus() {
     static int n[64] = {0};
@@ -578,6 +579,21 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         for (int i = 1; i < p.kv.nseg; ++i)
             if (p.kv.len[i] > 0 && (p.kv.k_ls[i] != p.kv.k_ls[0] || p.kv.vt_ls[i] != p.kv.vt_ls[0])) same_strides = false;
         if (p.kv.len[0] <= 0) same_strides = p.kv.nseg == 1;
+        M4D_ENV_ONCE(q64_mode, "M4D_ATTN_Q64", 0);     // 1: one wave per SIMD, 4 x 64 query rows, generated instruction stream (attention_q64.h)
+        if (w8 && q64_mode && p.kv.nseg == 1 && !p.kv.new_softmax && !p.accumulate && p.kv.len[0] >= 4 * 64 &&
+            p.kv.k_ls[0] < (1 << 20) && p.kv.vt_ls[0] < (1 << 23) && p.q_ls < (1 << 20) && p.o_ls < (1 << 20)) {
+            static int configured_q[16] = {0};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+            if (dev >= 0 && dev < 16 && !configured_q[dev]) {
+                if (hipFuncSetAttribute((const void*)attn128q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768) != hipSuccess) return -3;
+                configured_q[dev] = 1;
+            }
+            q.nq_tiles = (int)((p.Lq + 255) / 256);
+            m4d_count_launch(M4D_KC_ATTN_OTHER);
+            hipLaunchKernelGGL(attn128q_kernel, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(256), 5 * 32768, st, q);
+            return 0;
+        }
         M4D_ENV_ONCE(wide_mode, "M4D_ATTN_WIDE", 0);   // 1: 64-queries-per-wave kernel (attention_wide.h); same-box A/B: phased 1048 vs wide 1020 TF sustained
         if (w8 && same_strides && keys >= 4 * 64 + 64 * p.kv.nseg && wide_mode && !p.kv.new_softmax) {
             // 64 queries per wave: half the LDS traffic per MFMA, softmax interleaved into the MFMA stream (attention_wide.h)

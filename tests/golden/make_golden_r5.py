@@ -1,0 +1,74 @@
+"""Round-5 fixtures, produced by RUNNING THE REFERENCE in the build container (needs /root/reference):
+
+    python tests/golden/make_golden_r5.py [stack40|all]
+
+* dit_stack40_14b.npz + bf16_calibration.json["stack40_14b"] — FORTY stacked 14B-width WanAttentionBlocks (the depth of the
+  Wan2.1-14B DiT, wan_transformer4d.py:633-688 forty times, each layer with its own weights) at L = 2080 tokens: the reference's fp32
+  output (sampled rows, row norms) and how far the reference's OWN bf16-autocast run of the same stack sits from it, in the metrics of
+  tests/test_round5_gpu.py::test_stack_of_forty_14b_blocks_vs_reference.  L = 2080 keeps every projection on the production 256 x 256
+  GEMM tiles and the self-attention on the production long-key kernel; intermediate depths (4, 10, 20, 40) are recorded so that
+  error GROWTH over depth is visible, not only its end point.
+  Weights: tests/golden/weights.py:fill_hash (device-agnostic integer-hash recipe — the GPU test builds the same bits on the device).
+Data only; no reference source is stored."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+from make_golden import npz_save  # noqa: E402
+from make_golden_r4 import _block_metrics, _long_inputs, ref_bf16  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+DEPTHS = (4, 10, 20, 40)
+
+
+def _block14_hash(ref, seed):
+    from weights import block_shapes, fill_hash
+    blk = ref.dit.WanAttentionBlock("i2v_cross_attn", 5120, 13824, 40, (-1, -1), True, True, 1e-6, use_spatial_guidance=False).eval()
+    sd = fill_hash(block_shapes(5120, 13824), 500 + seed)
+    blk.load_state_dict({k[len("blocks.0."):]: v for k, v in sd.items()})
+    return blk
+
+
+def make_stack40(ref):
+    L, grid, x, e0, ctx, freqs = _long_inputs(ref)
+    args = (torch.tensor([L]), torch.tensor([list(grid)]), freqs, ctx, None)
+    ys32, ys16 = x, x
+    rows = torch.cat([torch.arange(0, L, 32), torch.tensor([L - 1])])
+    calib, arrs = {}, {}
+    t0 = time.time()
+    for layer in range(max(DEPTHS)):
+        blk = _block14_hash(ref, layer)
+        ys32 = blk(ys32, e0, *args, dtype=torch.float32, t=0, dino_features=None)
+        with ref_bf16(ref):
+            ys16 = blk(ys16, e0, *args, dtype=torch.bfloat16, t=0, dino_features=None).float()
+        del blk
+        if layer + 1 in DEPTHS:
+            d = layer + 1
+            calib[f"depth{d}"] = _block_metrics(ys16, ys32, x)
+            arrs[f"out_rows_{d}"] = ys32[0, rows].clone()
+            arrs[f"row_norm_{d}"] = ys32[0].norm(dim=-1)
+            arrs[f"delta_rows_{d}"] = (ys32 - x)[0, rows].clone()
+            arrs[f"delta_norm_{d}"] = (ys32 - x)[0].norm(dim=-1)
+            print(f"depth {d}: {calib[f'depth{d}']}  |x| rms {float(ys32.pow(2).mean().sqrt()):.3f}  ({time.time() - t0:.0f} s)", flush=True)
+    npz_save("dit_stack40_14b.npz", grid=np.array(grid), rows=rows, depths=np.array(DEPTHS), **arrs)
+    path = os.path.join(HERE, "bf16_calibration.json")
+    out = json.load(open(path))
+    out["stack40_14b"] = calib
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    ref = _ref_import.load_reference()
+    if what in ("stack40", "all"):
+        make_stack40(ref)

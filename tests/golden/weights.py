@@ -77,3 +77,33 @@ def randn_named(key, shape, seed, scale=1.0, dtype=torch.float32):
     """Seeded N(0, scale^2) tensor for fixture INPUTS too large to commit."""
     g = torch.Generator().manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) % (2 ** 63))
     return (torch.randn(tuple(shape), generator=g, dtype=torch.float32) * scale).to(dtype)
+
+
+# ---- device-agnostic recipe (round 5) ----
+# torch.randn is reproducible per device only: CPU (mt19937) and GPU (Philox) streams differ, so `fill` has to run on the host — 3-4 s per
+# 14B-width block, minutes for 40 of them.  `fill_hash` derives every value from integer arithmetic that is exact on both devices (a 32-bit
+# mixing hash of the element index, all intermediate products < 2^63), maps the top 24 bits to an exactly representable fp32 in [-1, 1) and
+# applies ONE rounding multiply: the reference (CPU, fixture generation) and the GPU test build bit-identical weights, each on its own device.
+def _hash_uniform(numel, key_seed, device):
+    i = torch.arange(numel, dtype=torch.int64, device=device)
+    h = (i + int(key_seed)) & 0xFFFFFFFF
+    h = ((h ^ (h >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+    h = ((h ^ (h >> 16)) * 0x45D9F3B) & 0xFFFFFFFF
+    h = h ^ (h >> 16)
+    return (h >> 8).to(torch.float32) * (2.0 ** -23) - 1.0          # 24 bits -> [-1, 1), exact
+
+
+def make_tensor_hash(key, shape, seed, device="cpu", dtype=torch.float32):
+    kind, s = _scale_for(key, tuple(shape))
+    n = 1
+    for d in shape:
+        n *= d
+    ks = (int(seed) * 1000003 + zlib.crc32(key.encode())) & 0xFFFFFFFF
+    t = _hash_uniform(n, ks, device).reshape(tuple(shape)) * float(torch.tensor(math.sqrt(3.0) * s, dtype=torch.float32))   # unit variance x s
+    if kind == "one_plus":
+        t = t + 1.0
+    return t.to(dtype)
+
+
+def fill_hash(shapes, seed, device="cpu", dtype=torch.float32):
+    return {k: make_tensor_hash(k, tuple(v), seed, device, dtype) for k, v in shapes.items()}
