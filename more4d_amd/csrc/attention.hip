@@ -579,8 +579,14 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         for (int i = 1; i < p.kv.nseg; ++i)
             if (p.kv.len[i] > 0 && (p.kv.k_ls[i] != p.kv.k_ls[0] || p.kv.vt_ls[i] != p.kv.vt_ls[0])) same_strides = false;
         if (p.kv.len[0] <= 0) same_strides = p.kv.nseg == 1;
-        M4D_ENV_ONCE(q64_mode, "M4D_ATTN_Q64", 0);     // 1: one wave per SIMD, 4 x 64 query rows, generated instruction stream (attention_q64.h)
-        if (w8 && q64_mode && p.kv.nseg == 1 && !p.kv.new_softmax && !p.accumulate && p.kv.len[0] >= 4 * 64 &&
+        // attn128q_kernel (attention_q64.h): one wave per SIMD, 4 x 64 query rows, generated instruction stream.  It folds scale * log2(e)
+        // into Q with ONE bf16 rounding per element; a caller that has already folded it into q (scale * log2(e) == 1: the DiT's
+        // self-attention folds it into the RMSNorm weight of q) gets q's bits unchanged.  With any other scale the log-sum-exp would
+        // not match the unrounded scores the backward recomputes, so lse calls take this kernel only with a folded scale.
+        M4D_ENV_ONCE(q64_mode, "M4D_ATTN_Q64", 1);     // A/B: 0 = attn128p_kernel
+        const bool folded = fabsf(p.sc - 1.f) < 1e-6f;
+        if (folded) q.sc = 1.f;
+        if (w8 && q64_mode && p.kv.nseg == 1 && !p.kv.new_softmax && !p.accumulate && p.kv.len[0] >= 4 * 64 && (folded || !p.lse) &&
             p.kv.k_ls[0] < (1 << 20) && p.kv.vt_ls[0] < (1 << 23) && p.q_ls < (1 << 20) && p.o_ls < (1 << 20)) {
             static int configured_q[16] = {0};
             int dev = 0;
@@ -590,7 +596,7 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
                 configured_q[dev] = 1;
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
-            m4d_count_launch(M4D_KC_ATTN_OTHER);
+            m4d_count_launch(M4D_KC_ATTN_Q64);
             hipLaunchKernelGGL(attn128q_kernel, dim3((unsigned)((int64_t)q.nq_tiles * p.heads * p.B)), dim3(256), 5 * 32768, st, q);
             return 0;
         }

@@ -84,6 +84,24 @@ def _f32(p, cache):
     return hit[1]
 
 
+LOG2E = 1.4426950408889634
+# The softmax scale of the DiT's self-attention, folded into q where q is made: q' = rope(rmsnorm(x) * (w * c)), c = head_dim^-0.5 *
+# log2(e) — RoPE is linear, so q' = c * q exactly in fp32, and the bf16 store of q' is the ONE rounding q gets either way.  The attention
+# kernels are then called with scale = ln 2 (scale * log2(e) == 1): attn128q_kernel takes q' as its Q~ operand bit for bit instead of
+# rounding Q * c to bf16 a second time (csrc/attention_q64.h).  bf16 inference with qk_norm only; M4D_FOLD_QSCALE=0 = A/B.
+_FOLD_QSCALE = os.environ.get("M4D_FOLD_QSCALE", "1") != "0"
+
+
+def _folded_norm_weight(p, head_dim, cache):
+    """float32 norm_q weight times head_dim^-0.5 * log2(e), cached per (storage, version)."""
+    key = (p.data_ptr(), p._version, tuple(p.shape), head_dim)
+    hit = cache.get(("fold", id(p)))
+    if hit is None or hit[0] != key:
+        hit = (key, (p.detach().float() * (head_dim ** -0.5 * LOG2E)).contiguous())
+        cache[("fold", id(p))] = hit
+    return hit[1]
+
+
 class WanRMSNorm(nn.Module):
     def __init__(self, dim, eps=1e-5):
         super().__init__()
@@ -142,8 +160,12 @@ class WanSelfAttention(nn.Module):
         one gate vector (default: a sample's Lp rows; 1 = per-token gates)."""
         B, Lp, C = xn.shape
         n, d = self.num_heads, self.head_dim
+        sm = {}                           # softmax-scale keyword of every attention call below
         if self.qk_norm:
             wq, wk = _f32(self.norm_q.weight, c.f32cache), _f32(self.norm_k.weight, c.f32cache)
+            if _FOLD_QSCALE and xn.dtype == torch.bfloat16:
+                wq = _folded_norm_weight(self.norm_q.weight, d, c.f32cache)
+                sm = dict(scale=1.0 / LOG2E)
         else:       # norm_q / norm_k are nn.Identity (:431-432): the same kernel with NULL weights rotates only
             wq = wk = None
         rope = dict(head_dim=d, eps=self.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
@@ -165,7 +187,7 @@ class WanSelfAttention(nn.Module):
             ops.rmsnorm_rope(q, wq, k, wk, **rope)
             segs = [KV(k, vt, Lp * q_ls, q_ls, Lp, B * Lp, c.key_len)]
         elif c.sp.mode == "ulysses":
-            o = self._ulysses(xn, wq, wk, rope, c)
+            o = self._ulysses(xn, wq, wk, rope, c, sm)
             segs = None
         else:
             # T-sharded: K and V^T are all-gathered over xGMI while the next projections run (async collectives)
@@ -181,7 +203,7 @@ class WanSelfAttention(nn.Module):
                 # and merge the two partial softmaxes through their log-sum-exps (== one softmax over all keys)
                 r = c.sp.rank
                 n_loc = max(0, min(Lp, c.key_len - r * Lp))
-                kw = dict(B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C)
+                kw = dict(B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C, **sm)
                 o = None
                 if n_loc > 0:
                     lse = torch.empty((B, n, Lp), device=q.device, dtype=torch.float32)
@@ -197,13 +219,13 @@ class WanSelfAttention(nn.Module):
             else:
                 segs = c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)
         if segs is not None:
-            o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * q_ls, q_ls=q_ls)
+            o = ops.attention(q, segs, B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * q_ls, q_ls=q_ls, **sm)
         ops.gemm_bt(o, self.o.weight, self.o.bias, out=xres, epilogue=EPI_RESID_GATE, gate=gate,
                     gate_stride=gate_stride, rows_per_sample=gate_rows or Lp)
         return xres
 
 
-    def _ulysses(self, xn, wq, wk, rope, c):
+    def _ulysses(self, xn, wq, wk, rope, c, sm):
         """Head-split sequence parallelism: project + norm + RoPE on the local tokens (WanRMSNorm runs over the full 5120-wide
         row, so it stays in front of the split), one all-to-all each for q, k, V^T (chunk j = the heads of rank j), attention of
         ALL tokens for the local heads with one K/V segment per source rank, one all-to-all back.  Buffers travel token-major
@@ -231,7 +253,7 @@ class WanSelfAttention(nn.Module):
         L = W * Lp
         og = torch.empty((L, B, cl), device=q.device, dtype=q.dtype)
         ops.attention(qg.view(L, B, cl), [s for s in segs if s.len > 0], B=B, Lq=L, heads=nl, head_dim=d, q_bs=cl, q_ls=B * cl,
-                      out=og.permute(1, 0, 2))
+                      out=og.permute(1, 0, 2), **sm)
         ob = c.sp.all_to_all(og.view(W, Lp, B, cl))                                # [W(head group), Lp, B, cl]
         return ob.permute(2, 1, 0, 3).reshape(B, Lp, C)
 

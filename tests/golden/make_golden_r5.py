@@ -54,9 +54,10 @@ def make_stack40(ref):
         if layer + 1 in DEPTHS:
             d = layer + 1
             calib[f"depth{d}"] = _block_metrics(ys16, ys32, x)
-            arrs[f"out_rows_{d}"] = ys32[0, rows].clone()
+            if d == max(DEPTHS):      # sampled rows of the end point only (fixture size); intermediate depths keep the norms
+                arrs[f"out_rows_{d}"] = ys32[0, rows].clone()
+                arrs[f"delta_rows_{d}"] = (ys32 - x)[0, rows].clone()
             arrs[f"row_norm_{d}"] = ys32[0].norm(dim=-1)
-            arrs[f"delta_rows_{d}"] = (ys32 - x)[0, rows].clone()
             arrs[f"delta_norm_{d}"] = (ys32 - x)[0].norm(dim=-1)
             print(f"depth {d}: {calib[f'depth{d}']}  |x| rms {float(ys32.pow(2).mean().sqrt()):.3f}  ({time.time() - t0:.0f} s)", flush=True)
     npz_save("dit_stack40_14b.npz", grid=np.array(grid), rows=rows, depths=np.array(DEPTHS), **arrs)
