@@ -718,10 +718,20 @@ def main():
     # context cache; the headline `value` stays the layout chosen by --parallelism.
     other = None
     if world > 1 and world % 2 == 0 and not args.no_other_layout:
+        def agreed(flag):
+            """every rank learns whether ALL ranks got this far (a rank that threw must not leave its peers waiting in a barrier)"""
+            t_ = torch.tensor([1.0 if flag else 0.0], device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            return bool(t_.item() > 0.5)
+        err, x2, d2 = None, None, None
         try:
-            br2 = set_layout(not cfgp)
-            with torch.no_grad():
-                cc2 = model.prepare_context(ctx, torch.cat([clip, clip])) if br2 is None else model.prepare_context([ctx[br2]], clip)
+            try:
+                br2 = set_layout(not cfgp)
+                with torch.no_grad():
+                    cc2 = model.prepare_context(ctx, torch.cat([clip, clip])) if br2 is None else model.prepare_context([ctx[br2]], clip)
+            except Exception as ex:
+                err = repr(ex)[:400]
+            if agreed(err is None):
 
                 def run2(i0, n, x_):
                     class _S:
@@ -730,19 +740,35 @@ def main():
                             return sch.step_cfg_(lat_, v, gs, i0 + i, round_dtype)
                     return denoise_latents(model, _S, x_, ts[i0:i0 + n], 6.0, cc2, y=y, full_ref=full_ref, seq_len=Lv,
                                            first_frame_features=ffeat)
-                x2 = run2(0, max(1, args.warmup), lat)
-                dist.barrier()
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                x2 = run2(max(1, args.warmup), args.steps, x2)
-                dist.barrier()
-                torch.cuda.synchronize()
-                d2 = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
-            dist.all_reduce(d2, op=dist.ReduceOp.MAX)
-            other = {"parallelism": layout_name(br2), "ms_per_step": float(d2) / args.steps * 1e3, "value": args.steps / float(d2),
-                     "unit": "denoise-steps/s", "finite": bool(torch.isfinite(x2).all()), "steps": args.steps}
-        except Exception as ex:
-            other = {"error": repr(ex)[:400]}
+                try:
+                    with torch.no_grad():
+                        x2 = run2(0, max(1, args.warmup), lat)
+                except Exception as ex:
+                    err = repr(ex)[:400]
+                if agreed(err is None):           # only now is it safe to meet in a barrier
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    try:
+                        with torch.no_grad():
+                            x2 = run2(max(1, args.warmup), args.steps, x2)
+                    except Exception as ex:
+                        err = repr(ex)[:400]
+                    if agreed(err is None):
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        d2 = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+                        dist.all_reduce(d2, op=dist.ReduceOp.MAX)
+            if d2 is not None:
+                other = {"parallelism": layout_name(br2), "ms_per_step": float(d2) / args.steps * 1e3, "value": args.steps / float(d2),
+                         "unit": "denoise-steps/s", "finite": bool(torch.isfinite(x2).all()), "steps": args.steps}
+            else:
+                other = {"error": err or "another rank failed in the other-layout pass"}
+        finally:
+            try:
+                branch = set_layout(cfgp)          # the rest of main() (and anything the caller does next) sees the layout it chose
+            except Exception as ex:
+                other = {"error": f"restoring the layout failed: {ex!r}"[:400]}
 
     if rank == 0:
         gemm_fl, attn_fl = flops_per_forward(cfg, L, 2)

@@ -244,8 +244,9 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     eps = blk.eps
     f32 = lambda p: _f32(p, c.f32cache)  # noqa: E731
     G = {}
-    if not sa.qk_norm:
-        raise NotImplementedError("training without qk_norm")
+    # qk_norm=False (reference wan_transformer4d.py:431-432): norm_q / norm_k are nn.Identity — the self-attention's norm + RoPE kernel
+    # then only rotates (NULL weights, forward and backward), the cross-attention's norms vanish, and there are no norm-weight gradients
+    nw = lambda mod: f32(mod.weight) if getattr(mod, "weight", None) is not None else None  # noqa: E731
 
     def zeros(*shape):
         return torch.zeros(shape, device=dev, dtype=torch.float32)
@@ -271,7 +272,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     rope = dict(head_dim=d, eps=sa.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
                 pos_offset=c.pos_offset)
-    ops.rmsnorm_rope(q, f32(sa.norm_q.weight), k, f32(sa.norm_k.weight), **rope)
+    ops.rmsnorm_rope(q, nw(sa.norm_q), k, nw(sa.norm_k), **rope)
     o, lse1 = saved.get("o"), saved.get("lse1")
     if o is None:
         vt = ops.transpose(v)                                        # V^T [C, R]
@@ -290,7 +291,8 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     if qc_pre is None:
         qc_pre = ops.gemm_bt(xn3, ca.q.weight, ca.q.bias)
     qc = qc_pre.clone()
-    ops.rmsnorm_rope(qc, f32(ca.norm_q.weight), head_dim=d, eps=ca.eps)
+    if nw(ca.norm_q) is not None:
+        ops.rmsnorm_rope(qc, nw(ca.norm_q), head_dim=d, eps=ca.eps)
     srcs = [("txt", txt, txt_len, ca.k, ca.v, ca.norm_k)]
     if img is not None and getattr(ca, "has_img", False):
         srcs.append(("img", img, img_len, ca.k_img, ca.v_img, ca.norm_k_img))
@@ -301,7 +303,8 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
         s2 = src.reshape(Bc * Sp, C)
         k_pre = ops.gemm_bt(s2, kl.weight, kl.bias)
         kk = k_pre.clone()
-        ops.rmsnorm_rope(kk, f32(nk.weight), head_dim=d, eps=ca.eps)
+        if nw(nk) is not None:
+            ops.rmsnorm_rope(kk, nw(nk), head_dim=d, eps=ca.eps)
         vv = ops.gemm_bt(s2, vl.weight, vl.bias)
         vvt = ops.transpose(vv)
         lse = torch.empty((B, n, Lp), device=dev, dtype=torch.float32)
@@ -352,16 +355,18 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
         dv = torch.empty_like(vv)
         ops.attention_bwd(qc, kk, vv, oo, doc, lse, B=B, Lq=Lp, Lk=valid, Lk_rows=Sp, heads=n, head_dim=d, dq=dqc, dk=dk,
                           dv=dv, accumulate_dq=i > 0)
-        dwn = zeros(C)
-        ops.rmsnorm_rope_bwd_(dk, k_pre, f32(nk.weight), dwn, head_dim=d, eps=ca.eps)
         sfx = "_img" if name == "img" else ""
-        G[f"cross_attn.norm_k{sfx}.weight"] = dwn
+        if nw(nk) is not None:
+            dwn = zeros(C)
+            ops.rmsnorm_rope_bwd_(dk, k_pre, nw(nk), dwn, head_dim=d, eps=ca.eps)
+            G[f"cross_attn.norm_k{sfx}.weight"] = dwn
         ds_k, G[f"cross_attn.k{sfx}.weight"], G[f"cross_attn.k{sfx}.bias"] = linear_bwd(s2, kl.weight, dk)
         ds_v, G[f"cross_attn.v{sfx}.weight"], G[f"cross_attn.v{sfx}.bias"] = linear_bwd(s2, vl.weight, dv)
         dctx[name] = ops.add(ds_k, ds_v).view(-1, Sp, C)
-    dwq = zeros(C)
-    ops.rmsnorm_rope_bwd_(dqc, qc_pre, f32(ca.norm_q.weight), dwq, head_dim=d, eps=ca.eps)
-    G["cross_attn.norm_q.weight"] = dwq
+    if nw(ca.norm_q) is not None:
+        dwq = zeros(C)
+        ops.rmsnorm_rope_bwd_(dqc, qc_pre, nw(ca.norm_q), dwq, head_dim=d, eps=ca.eps)
+        G["cross_attn.norm_q.weight"] = dwq
     dxn3, G["cross_attn.q.weight"], G["cross_attn.q.bias"] = linear_bwd(xn3, ca.q.weight, dqc)
     if blk.cross_attn_norm:
         dw3, db3 = zeros(C), zeros(C)
@@ -377,10 +382,13 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     dqkv = torch.empty((R, 3 * C), device=dev, dtype=T)
     ops.attention_bwd(q, k, v, o, do, lse1, B=B, Lq=Lp, Lk=c.key_len, Lk_rows=Lp, heads=n, head_dim=d,
                       dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
-    dwq, dwk = zeros(C), zeros(C)
-    ops.rmsnorm_rope_bwd_(dqkv[:, :C], qkv_pre[:, :C], f32(sa.norm_q.weight), dwq, dqkv[:, C:2 * C], qkv_pre[:, C:2 * C],
-                          f32(sa.norm_k.weight), dwk, **rope)
-    G["self_attn.norm_q.weight"], G["self_attn.norm_k.weight"] = dwq, dwk
+    if sa.qk_norm:
+        dwq, dwk = zeros(C), zeros(C)
+        G["self_attn.norm_q.weight"], G["self_attn.norm_k.weight"] = dwq, dwk
+    else:
+        dwq = dwk = None
+    ops.rmsnorm_rope_bwd_(dqkv[:, :C], qkv_pre[:, :C], nw(sa.norm_q), dwq, dqkv[:, C:2 * C], qkv_pre[:, C:2 * C], nw(sa.norm_k), dwk,
+                          **rope)
     wt = torch.empty((C, 3 * C), device=dev, dtype=T)               # [Wq^T | Wk^T | Wv^T]
     for j, lin in enumerate((sa.q, sa.k, sa.v)):
         ops.transpose(lin.weight, out=wt[:, j * C:(j + 1) * C])

@@ -588,12 +588,10 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         if (folded) q.sc = 1.f;
         if (w8 && q64_mode && p.kv.nseg == 1 && !p.kv.new_softmax && !p.accumulate && p.kv.len[0] >= 4 * 64 && (folded || !p.lse) &&
             p.kv.k_ls[0] < (1 << 20) && p.kv.vt_ls[0] < (1 << 23) && p.q_ls < (1 << 20) && p.o_ls < (1 << 20)) {
-            static int configured_q[16] = {0};
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-            if (dev >= 0 && dev < 16 && !configured_q[dev]) {
+            static PerDeviceOnce configured_q;
+            if (configured_q.pending()) {
                 if (hipFuncSetAttribute((const void*)attn128q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768) != hipSuccess) return -3;
-                configured_q[dev] = 1;
+                configured_q.mark();
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             m4d_count_launch(M4D_KC_ATTN_Q64);
@@ -603,15 +601,15 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         M4D_ENV_ONCE(wide_mode, "M4D_ATTN_WIDE", 0);   // 1: 64-queries-per-wave kernel (attention_wide.h); same-box A/B: phased 1048 vs wide 1020 TF sustained
         if (w8 && same_strides && keys >= 4 * 64 + 64 * p.kv.nseg && wide_mode && !p.kv.new_softmax) {
             // 64 queries per wave: half the LDS traffic per MFMA, softmax interleaved into the MFMA stream (attention_wide.h)
-            static bool configured_w = false;
-            if (!configured_w) {
+            static PerDeviceOnce configured_w;
+            if (configured_w.pending()) {
                 if (hipFuncSetAttribute((const void*)attn128w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
 #ifdef M4D_ABLATIONS
-                hipFuncSetAttribute((const void*)attn128w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
-                hipFuncSetAttribute((const void*)attn128w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
-                hipFuncSetAttribute((const void*)attn128w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
+                if (hipFuncSetAttribute((const void*)attn128w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
+                if (hipFuncSetAttribute((const void*)attn128w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
+                if (hipFuncSetAttribute((const void*)attn128w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
 #endif
-                configured_w = true;
+                configured_w.mark();
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             m4d_count_launch(M4D_KC_ATTN_OTHER);
@@ -628,13 +626,13 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
 #endif
         } else if (w8 && same_strides && !force_lockstep && !p.kv.new_softmax) {
             // two wave groups half a tile apart: softmax of one under the MFMAs of the other (attention_phased.h)
-            static bool configured = false;
-            if (!configured) {
+            static PerDeviceOnce configured;
+            if (configured.pending()) {
                 if (hipFuncSetAttribute((const void*)attn128p_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
-                hipFuncSetAttribute((const void*)attn128p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
-                hipFuncSetAttribute((const void*)attn128p_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
-                hipFuncSetAttribute((const void*)attn128p_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192);
-                configured = true;
+                if (hipFuncSetAttribute((const void*)attn128p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
+                if (hipFuncSetAttribute((const void*)attn128p_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
+                if (hipFuncSetAttribute((const void*)attn128p_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 8192) != hipSuccess) return -3;
+                configured.mark();
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             M4D_ENV_ONCE(smx, "M4D_ATTN_SMX", 1);   // 1 = scalar softmax arithmetic (default: +9 % sustained over the packed form), 0 = packed
@@ -647,12 +645,12 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
             else hipLaunchKernelGGL((attn128p_kernel<1, 1>), gp, dim3(512), 4 * 32768 + ((M4D_ABL(q) & 128) ? 8192 : 0), st, q);
         } else if (xp_ok(p, w8)) {
             // short key lists against many queries (cross-attention): one persistent workgroup per CU walks (query tile, key tile) pairs
-            static bool configured_x = false;
-            if (!configured_x) {
+            static PerDeviceOnce configured_x;
+            if (configured_x.pending()) {
                 if (hipFuncSetAttribute((const void*)attn128x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768) != hipSuccess) return -3;
-                hipFuncSetAttribute((const void*)attn128x_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768);
-                hipFuncSetAttribute((const void*)attn128x_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768);
-                configured_x = true;
+                if (hipFuncSetAttribute((const void*)attn128x_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768) != hipSuccess) return -3;
+                if (hipFuncSetAttribute((const void*)attn128x_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 32768) != hipSuccess) return -3;
+                configured_x.mark();
             }
             q.nq_tiles = (int)((p.Lq + 255) / 256);
             const int64_t items = (int64_t)q.nq_tiles * p.heads * p.B;

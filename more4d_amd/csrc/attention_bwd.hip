@@ -292,11 +292,11 @@ template <typename T, int D, bool KV>
 int launch_one(const BwdArgs& p, hipStream_t st) {
     constexpr int YB = TileCfg<T>::KVB;
     constexpr int LDS = (KV ? 4 : 3) * YB * D * (int)sizeof(T) + 2 * YB * 4;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.pending()) {
         if (hipFuncSetAttribute((const void*)attn_bwd_kernel<T, D, KV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return -3;
-        configured = true;
+        configured.mark();
     }
     dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B)), block(256);
     hipLaunchKernelGGL((attn_bwd_kernel<T, D, KV>), grid, block, LDS, st, p);

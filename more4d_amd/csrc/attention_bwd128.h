@@ -803,10 +803,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv128_kernel(BwdArgs p) {
 // its fragment waits, MFMAs and elementwise stream strictly one after the other.  Removed.)
 inline int launch_bwd_kv128(const BwdArgs& p, hipStream_t st) {
     constexpr int LDS = BKV_NST * (32768 + 512) + 16384 + 64;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.pending()) {
         if (hipFuncSetAttribute((const void*)attn_bwd_kv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        configured = true;
+        configured.mark();
     }
     dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B));
     hipLaunchKernelGGL(attn_bwd_kv128_kernel, grid, dim3(512), LDS, st, p);
@@ -817,12 +817,12 @@ template <int MODE>
 int launch_bwd128(const BwdArgs& p, hipStream_t st, int nsplit) {
     M4D_ENV_ONCE(smx, "M4D_ATTN_BWD_SMX", 1);
     constexpr int LDS = 4 * (32768 + (MODE == BWD_DQ ? 0 : 512));
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.pending()) {
         if (hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return -3;
         if (hipFuncSetAttribute((const void*)attn_bwd128_kernel<MODE, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        configured = true;
+        configured.mark();
     }
     dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B), (unsigned)nsplit), block(512);
     if (smx == 1) hipLaunchKernelGGL((attn_bwd128_kernel<MODE, 1>), grid, block, LDS, st, p);

@@ -471,10 +471,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kvp_kernel(BwdArgs p) {
 }
 
 inline int launch_bwd_kvp(const BwdArgs& p, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.pending()) {
         if (hipFuncSetAttribute((const void*)attn_bwd_kvp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kvp::LDS_BYTES) != hipSuccess) return -3;
-        configured = true;
+        configured.mark();
     }
     dim3 grid((unsigned)((int64_t)p.nx_tiles * p.heads * p.B));
     hipLaunchKernelGGL(attn_bwd_kvp_kernel, grid, dim3(512), kvp::LDS_BYTES, st, p);

@@ -382,13 +382,13 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
 template <int KT, int KH, int TH, int TW, int NT, int MT, int SD = 1>
 int launch_halo(ConvArgs& p, hipStream_t st) {
     constexpr int LDS = halo::Cfg<KT, KH, TH, TW, NT, MT, SD>::LDS_BYTES;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.pending()) {
         if (hipFuncSetAttribute((const void*)conv_halo_kernel<KT, KH, TH, TW, NT, MT, SD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             m4d_set_error("conv_cl: cannot enable %d bytes of LDS", LDS);
             return -3;
         }
-        configured = true;
+        configured.mark();
     }
     p.tiles_m = p.To * ((p.Ho + TH - 1) / TH) * ((p.Wo + TW - 1) / TW);
     p.tiles_n = (p.Cout + NT * 32 - 1) / (NT * 32);
@@ -538,13 +538,13 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
         return 0;
     }
     if (v2_shape && xbytes < (1ll << 30)) {
-        static bool configured = false;
-        if (!configured) {
+        static PerDeviceOnce configured;
+        if (configured.pending()) {
             if (hipFuncSetAttribute((const void*)conv_cl256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * ROWB) != hipSuccess) {
                 m4d_set_error("conv_cl: cannot enable 96 KiB LDS");
                 return -3;
             }
-            configured = true;
+            configured.mark();
         }
         p.tiles_m = (int)((p.M + 255) / 256); p.tiles_n = (Cout + 127) / 128;
         const int64_t nwg2 = (int64_t)p.tiles_m * p.tiles_n;

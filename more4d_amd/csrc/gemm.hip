@@ -589,8 +589,8 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
     int kclass = M4D_KC_GEMM_GENERIC;
     if (big) {
         const int variant = gemm_variant();
-        static bool configured = false;
-        if (!configured) {
+        static PerDeviceOnce configured;
+        if (configured.pending()) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)gemm_bt256pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SLOT_BYTES);
@@ -599,7 +599,7 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)gemm_bt256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_BUF);
             if (e != hipSuccess) { m4d_set_error("gemm_bt: cannot enable 128 KiB LDS: %s", hipGetErrorString(e)); return -3; }
-            configured = true;
+            configured.mark();
         }
         p.tiles_m = (int)((M + BM2 - 1) / BM2); p.tiles_n = (int)((N + BN2 - 1) / BN2);
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;

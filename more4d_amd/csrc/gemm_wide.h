@@ -598,11 +598,11 @@ template <int EPI>
 int launch_gemm_wide(const GemmArgs& p, unsigned nwg, hipStream_t st, unsigned nby = 1) {
 #define W_LAUNCH(A)                                                                                                    \
     do {                                                                                                               \
-        static bool configured = false;                                                                                \
-        if (!configured) {                                                                                             \
+        static PerDeviceOnce configured;                                                                                \
+        if (configured.pending()) {                                                                                             \
             if (hipFuncSetAttribute((const void*)gemm_bt256w_kernel<A, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W_BUF) != hipSuccess) \
                 return -3;                                                                                             \
-            configured = true;                                                                                         \
+            configured.mark();                                                                                         \
         }                                                                                                              \
         hipLaunchKernelGGL((gemm_bt256w_kernel<A, EPI>), dim3(nwg, nby), dim3(256), 2 * W_BUF, st, p);                  \
     } while (0)
@@ -638,10 +638,10 @@ int launch_gemm_wide(const GemmArgs& p, unsigned nwg, hipStream_t st, unsigned n
 template <int EPI>
 int launch_gemm_wide_persistent(const GemmArgs& p, unsigned nwg, unsigned ncu, hipStream_t st) {
     constexpr int LDS = 2 * W_BUF + 4 * 8192;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    if (configured.pending()) {
         if (hipFuncSetAttribute((const void*)gemm_bt256w_kernel<0, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        configured = true;
+        configured.mark();
     }
     const unsigned grid = nwg < ncu ? nwg : ncu;
     hipLaunchKernelGGL((gemm_bt256w_kernel<0, EPI, true>), dim3(grid), dim3(256), LDS, st, p);

@@ -426,6 +426,14 @@ __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
                 s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
             }
         }
+        if (w == nullptr) {      // qk_norm=False (reference :431-432: norm_q / norm_k are Identity): the forward only rotated -> dx = rot^T(dy)
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c4 = lt + i * 64;
+                if (FULL || c4 < nv) store4(dr + c4 * 4, g[i]);
+            }
+            continue;
+        }
         const float inv = rsqrtf(wave_sum(s) / C + p.eps);
         float m2 = 0.f;
 #pragma unroll
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void rms_bwd_kernel(RmsBwdArgs p) {
             if (FULL || c4 < nv) store4(dr + c4 * 4, (g[i] - v[i] * m2) * inv);
         }
     }
-    flush_partials<MAXV>(pw, red_lds, p.dw[which], nv, lt, wv);
+    if (w != nullptr) flush_partials<MAXV>(pw, red_lds, p.dw[which], nv, lt, wv);
 }
 
 // ------------------------------------------------------------------ sum of squares (global gradient norm)
@@ -679,8 +687,8 @@ extern "C" int m4d_rmsnorm_rope_bwd(m4d_dtype dt, void* dy0, void* dy1, int64_t 
                                     int C, int head_dim, float eps, const float* cos_t, const float* sin_t,
                                     int64_t rows_per_sample, int64_t rope_len, int64_t pos_offset, m4d_stream stream) {
     M4D_CHECK_ARG(DT_OK(dt), "rmsnorm_rope_bwd: bad dtype");
-    M4D_CHECK_ARG(dy0 && x0 && w0 && dw0 && rows > 0, "rmsnorm_rope_bwd: bad arguments");
-    M4D_CHECK_ARG((dy1 == nullptr) == (x1 == nullptr) && (!dy1 || (w1 && dw1)), "rmsnorm_rope_bwd: second tensor incomplete");
+    M4D_CHECK_ARG(dy0 && x0 && rows > 0 && (w0 == nullptr) == (dw0 == nullptr), "rmsnorm_rope_bwd: bad arguments");      // w == NULL: rotation only
+    M4D_CHECK_ARG((dy1 == nullptr) == (x1 == nullptr) && (!dy1 || ((w1 == nullptr) == (dw1 == nullptr))), "rmsnorm_rope_bwd: second tensor incomplete");
     M4D_CHECK_ARG(C % 4 == 0 && C <= 8192 && ld_dy % 4 == 0 && ld_x % 4 == 0, "rmsnorm_rope_bwd: C / leading dims must be multiples of 4, C <= 8192");
     M4D_CHECK_ARG(!cos_t || (head_dim % 4 == 0 && C % head_dim == 0 && sin_t), "rmsnorm_rope_bwd: bad rope configuration");
     RmsBwdArgs p;

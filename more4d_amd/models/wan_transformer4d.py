@@ -90,6 +90,9 @@ LOG2E = 1.4426950408889634
 # kernels are then called with scale = ln 2 (scale * log2(e) == 1): attn128q_kernel takes q' as its Q~ operand bit for bit instead of
 # rounding Q * c to bf16 a second time (csrc/attention_q64.h).  bf16 inference with qk_norm only; M4D_FOLD_QSCALE=0 = A/B.
 _FOLD_QSCALE = os.environ.get("M4D_FOLD_QSCALE", "1") != "0"
+# T-sharded self-attention: the gathered remote shards one call per shard (single-segment calls run on attn128q_kernel) + LSE merges,
+# instead of one multi-segment call on the phased kernel; M4D_SP_PER_SEGMENT=0 = A/B (tools/bench_shard.py)
+_SP_PER_SEGMENT = os.environ.get("M4D_SP_PER_SEGMENT", "1") != "0"
 
 
 def _folded_norm_weight(p, head_dim, cache):
@@ -144,16 +147,30 @@ class WanSelfAttention(nn.Module):
         return torch.ones(self.dim, device=ref.device, dtype=torch.float32)
 
     def _qk_weights(self):
-        """[Wq; Wk] [2C, C] and [bq; bk] for the fused q+k projection, rebuilt when either parameter changes (version / storage)."""
-        key = (self.q.weight._version, self.q.weight.data_ptr(), self.k.weight._version, self.k.weight.data_ptr(),
-               self.q.bias._version, self.k.bias._version, self.q.weight.dtype)
+        """[Wq; Wk] [2C, C] and [bq; bk] for the fused q+k projection.
+        No second resident copy (105 MB per layer at 14B width): the first call allocates ONE [2C, C] / [2C] storage and re-points
+        `q.weight` / `k.weight` / the biases at its two halves (`param.data = view`), so in-place updates of either parameter ARE updates of
+        the fused operand and nothing can go stale; a `.to()` / `load_state_dict(assign=True)` that gives the parameters new storage is
+        seen through the data pointers and re-fuses.  Parameters that already live inside someone else's buffer (the flat buckets of
+        dist/data_parallel.py) are left where they are: (None, None) — the caller then projects q and k with two launches (a cached
+        copy could go stale under raw-pointer writers that do not bump the version counter)."""
+        qw, kw, qb, kb = self.q.weight, self.k.weight, self.q.bias, self.k.bias
+        C, es = self.dim, qw.element_size()
         hit = self.__dict__.get("_qk_cache")
-        if hit is None or hit[0] != key:
+        if hit is not None and hit[0] == "view":
+            w, b = hit[1], hit[2]
+            if (w.dtype == qw.dtype and qw.data_ptr() == w.data_ptr() and kw.data_ptr() == w.data_ptr() + C * C * es and
+                    qb.data_ptr() == b.data_ptr() and kb.data_ptr() == b.data_ptr() + C * es):
+                return w, b
+        owned = all(t.is_contiguous() and t.untyped_storage().nbytes() == t.numel() * t.element_size() for t in (qw, kw, qb, kb))
+        if owned:
             with torch.no_grad():
-                hit = (key, torch.cat([self.q.weight.detach(), self.k.weight.detach()]).contiguous(),
-                       torch.cat([self.q.bias.detach(), self.k.bias.detach()]).contiguous())
-            self.__dict__["_qk_cache"] = hit
-        return hit[1], hit[2]
+                w = torch.cat([qw.detach(), kw.detach()]).contiguous()
+                b = torch.cat([qb.detach(), kb.detach()]).contiguous()
+                qw.data, kw.data, qb.data, kb.data = w[:C], w[C:], b[:C], b[C:]
+            self.__dict__["_qk_cache"] = ("view", w, b)
+            return w, b
+        return None, None
 
     def run(self, xn, xres, gate, gate_stride, c: _Ctx, gate_rows=None):
         """xn: T [B, Lp, C] modulated input; accumulates o-proj * gate into xres (float32) in place.  gate_rows: rows that share
@@ -172,11 +189,11 @@ class WanSelfAttention(nn.Module):
                     pos_offset=c.pos_offset)
         q_ls = C                         # row stride of q (2C when q and k share one [rows, 2C] projection buffer)
         if c.sp is None or c.sp.world_size == 1:
-            if _FUSE_QK:
+            wqk, bqk = self._qk_weights() if _FUSE_QK else (None, None)
+            if wqk is not None:
                 # ONE projection launch for q and k (N = 2C = 10 240: twice the tiles per launch for the persistent GEMM, one
                 # partial tile round and one launch less per layer); q / k are the two column halves of the [rows, 2C] result —
                 # the norm+rope kernel and the attention kernel take row strides
-                wqk, bqk = self._qk_weights()
                 qk = ops.gemm_bt(xn, wqk, bqk).view(B * Lp, 2 * C)
                 q, k = qk[:, :C], qk[:, C:]
                 q_ls = 2 * C
@@ -211,6 +228,13 @@ class WanSelfAttention(nn.Module):
                 rem = [s for i, s in enumerate(c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)) if i != r and s.len > 0]
                 if o is None:           # this rank holds only padding rows: nothing local to attend
                     o = ops.attention(q, rem, **kw)
+                elif rem and _SP_PER_SEGMENT and sm and len(rem) <= 3:      # (every merge rounds the running output to bf16 once more)
+                    # one call per remote shard, merged through the log-sum-exps as it completes: every call is a single K / V^T
+                    # segment, which is what attn128q_kernel (one wave per SIMD, +15 % over the multi-segment phased kernel) takes
+                    lse_r, o_r = torch.empty_like(lse), torch.empty_like(o)
+                    for seg in rem:
+                        ops.attention(q, [seg], lse=lse_r, out=o_r, **kw)
+                        ops.attn_merge_(o, lse, o_r, lse_r, B=B, L=Lp, heads=n, head_dim=d)
                 elif rem:
                     lse_r = torch.empty_like(lse)
                     o_r = ops.attention(q, rem, lse=lse_r, **kw)

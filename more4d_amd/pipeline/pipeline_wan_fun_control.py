@@ -172,15 +172,15 @@ class WanFunControlPipeline:
             ts, _ = retrieve_timesteps(sch, num_inference_steps, device, timesteps)
         return ts
 
-    @staticmethod
-    def _preprocess(video, height, width):
+    def _preprocess(self, video, height, width):
         """`self.image_processor.preprocess(...)` of the reference (:637-639, :681-683, :704-706) for float tensors: diffusers'
         VaeImageProcessor (third-party, restated — parity unpinned) resizes to (height, width) and maps [0, 1] -> [-1, 1]; a
         tensor that already holds negative values is taken to be normalised and passed through.
         Resize, as published: the target is rounded DOWN to a multiple of the VAE's spatial factor (`get_default_height_width`)
         and tensors go through `torch.nn.functional.interpolate(image, size=(h, w))` with its default mode, i.e. legacy NEAREST
         (source index = floor(dst * in / out)) — a pure row / column gather, done on whatever device the frames live on."""
-        height, width = height - height % 8, width - width % 8
+        f = int(getattr(self.vae, "spatial_compression_ratio", 8))      # the reference's vae_scale_factor (:185-186)
+        height, width = height - height % f, width - width % f
         hin, win = video.shape[-2:]
         if (hin, win) != (height, width):
             dev = video.device
@@ -189,7 +189,10 @@ class WanFunControlPipeline:
             iw = (torch.arange(width, device=dev, dtype=torch.float32) * (win / width)).floor().long().clamp_(max=win - 1)
             video = video.index_select(-2, ih).index_select(-1, iw)
         video = video.float()
-        return video if float(video.min()) < 0 else video * 2.0 - 1.0
+        # [0, 1] -> [-1, 1] unless the tensor already holds negative values; decided on the device (no host round trip):
+        # scale = 1 / offset = 0 when min < 0, else 2 / -1
+        neg = (video.amin() < 0).to(video.dtype)
+        return video * (2.0 - neg) - (1.0 - neg)
 
     def _encode_control(self, video, device):
         """vae.encode(x)[0].mode() (reference prepare_control_latents :343-374)."""
@@ -205,8 +208,14 @@ class WanFunControlPipeline:
                  callback_on_step_end_tensor_inputs=("latents",), clip_image=None, max_sequence_length: int = 512,
                  comfyui_progressbar: bool = False, shift: int = 5, first_frame=None, depth_image=None,
                  clip_context=None, first_frame_features=None) -> Union[WanPipelineOutput, tuple]:
-        if control_camera_video is not None or start_image is not None:
-            raise NotImplementedError("camera-control / start-image inputs are not part of the 4D-STraG path")
+        if control_camera_video is not None:
+            # the reference hands the camera latents to `transformer.control_adapter` (pipeline :611-626, :790-800), a SimpleAdapter that
+            # its own wan_transformer4d.py:941 never defines: the reference cannot run this input either
+            raise NotImplementedError("control_camera_video needs the control adapter the reference leaves undefined (wan_transformer4d.py:941)")
+        f = int(getattr(self.vae, "spatial_compression_ratio", 8))
+        if height % f or width % f:
+            # the latent shapes (height // f) and the resized control / reference frames (rounded down to a multiple of f) must agree
+            raise ValueError(f"height and width must be multiples of the VAE's spatial factor {f}, got {height} x {width}")
         self._guidance_scale = guidance_scale
         device = self._execution_device
         T = self.transformer.dtype
@@ -223,7 +232,13 @@ class WanFunControlPipeline:
             ctrl = self._encode_control(self._preprocess(control_video, height, width), device)
         else:
             ctrl = torch.zeros_like(lat)
-        parts = [ctrl, torch.zeros_like(lat)]
+        # start image (:664-685): encoded like a control video, its first latent frame goes into frame 0 of the second 16-channel group
+        start = torch.zeros_like(lat)
+        if start_image is not None:
+            sl = self._encode_control(self._preprocess(start_image, height, width), device)
+            if lat.size(2) != 1:
+                start[:, :, :1] = sl.to(start.dtype)
+        parts = [ctrl, start]
         if depth_image is not None:
             parts.append(self._encode_control(depth_image.repeat(1, 1, control_video.shape[2], 1, 1).float(), device))
         y = torch.cat([p.to(device=device, dtype=torch.float32) for p in parts], dim=1)

@@ -1,6 +1,6 @@
 """Round-5 fixtures, produced by RUNNING THE REFERENCE in the build container (needs /root/reference):
 
-    python tests/golden/make_golden_r5.py [stack40|all]
+    python tests/golden/make_golden_r5.py [stack40|noqknorm_grads|all]
 
 * dit_stack40_14b.npz + bf16_calibration.json["stack40_14b"] — FORTY stacked 14B-width WanAttentionBlocks (the depth of the
   Wan2.1-14B DiT, wan_transformer4d.py:633-688 forty times, each layer with its own weights) at L = 2080 tokens: the reference's fp32
@@ -9,6 +9,8 @@
   GEMM tiles and the self-attention on the production long-key kernel; intermediate depths (4, 10, 20, 40) are recorded so that
   error GROWTH over depth is visible, not only its end point.
   Weights: tests/golden/weights.py:fill_hash (device-agnostic integer-hash recipe — the GPU test builds the same bits on the device).
+* dit_block_noqknorm_grads.npz — gradients of the qk_norm=False block of dit_block_noqknorm.npz (same weights / inputs) for a seeded
+  cotangent, by torch autograd through the reference block (wan_transformer4d.py:431-432, 633-688): every parameter + dL/dx.
 Data only; no reference source is stored."""
 import json
 import os
@@ -68,8 +70,30 @@ def make_stack40(ref):
         json.dump(out, fh, indent=1, sort_keys=True)
 
 
+def make_noqknorm_grads(ref):
+    d = ref.dit
+    z = np.load(os.path.join(HERE, "dit_block_noqknorm.npz"))
+    blk = d.WanAttentionBlock("i2v_cross_attn", 128, 512, 4, (-1, -1), False, True, 1e-6, use_spatial_guidance=False).eval()
+    blk.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")})
+    x = torch.from_numpy(z["x"]).clone().requires_grad_(True)
+    e0, ctx, grid = torch.from_numpy(z["e0"]), torch.from_numpy(z["ctx"]), tuple(int(v) for v in z["grid"])
+    L, hd = x.shape[1], 32
+    freqs = torch.cat([d.rope_params(1024, hd - 4 * (hd // 6)), d.rope_params(1024, 2 * (hd // 6)), d.rope_params(1024, 2 * (hd // 6))], dim=1)
+    r = torch.randn(x.shape, generator=torch.Generator().manual_seed(77))
+    with torch.enable_grad():
+        y = blk(x, e0, torch.tensor([L]), torch.tensor([list(grid)]), freqs, ctx, None, dtype=torch.float32, t=0, dino_features=None)
+        (y * r).sum().backward()
+    arrs = {"cot": r, "grad/x": x.grad}
+    for n, p_ in blk.named_parameters():
+        arrs["grad/" + n] = p_.grad
+    assert not any("norm_q" in k or "norm_k" in k for k in arrs), "qk_norm=False: no norm weights"
+    npz_save("dit_block_noqknorm_grads.npz", **arrs)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref = _ref_import.load_reference()
     if what in ("stack40", "all"):
         make_stack40(ref)
+    if what in ("noqknorm_grads", "all"):
+        make_noqknorm_grads(ref)

@@ -315,18 +315,25 @@ def test_n_rank_schedule_full_size_bf16(mode, world):
     rec, tl = {}, threading.local()
     o_att, o_merge = ops.attention, ops.attn_merge_
 
+    import more4d_amd.models.wan_transformer4d as wt_
+    # layer 0 of a rank: one local call + one call over all remote shards, or (M4D_SP_PER_SEGMENT, <= 3 remote shards) one call per
+    # remote shard, each followed by a merge — the record is taken at the LAST merge of the layer
+    n_merges = (world - 1) if (wt_._SP_PER_SEGMENT and world - 1 <= 3) else 1
+
     def att(q, segs, **kk):
         out = o_att(q, segs, **kk)
         if kk.get("lse") is not None and not getattr(tl, "done", False):
-            tl.calls = getattr(tl, "calls", []) + [(q, list(segs), out)]
+            tl.segs = getattr(tl, "segs", []) + list(segs)
+            tl.q, tl.scale = q, kk.get("scale")      # (the DiT folds head_dim^-0.5 * log2(e) into q and calls with scale = ln 2)
         return out
 
     def merge(o_a, lse_a, o_b, lse_b, **kk):
         res = o_merge(o_a, lse_a, o_b, lse_b, **kk)
         if not getattr(tl, "done", False):
-            tl.done = True
-            (q, loc, _), (_, rem, _) = tl.calls[-2:]
-            rec[threading.get_ident()] = (q, loc + rem, o_a.clone(), kk)
+            tl.merges = getattr(tl, "merges", 0) + 1
+            if tl.merges == n_merges:
+                tl.done = True
+                rec[threading.get_ident()] = (tl.q, list(tl.segs), o_a.clone(), dict(kk, scale=tl.scale))
         return res
     ops.attention, ops.attn_merge_ = att, merge
     try:
@@ -344,14 +351,14 @@ def test_n_rank_schedule_full_size_bf16(mode, world):
             for row in (0, Lq // 2, Lq - 1):
                 for h in (0, n // 2, n - 1):
                     sl = slice(h * d, (h + 1) * d)
-                    sc = torch.cat([s_.k.reshape(-1, C_)[:s_.len, sl].float() @ qf[row, sl].float() for s_ in segs]) * d ** -0.5
+                    sc = torch.cat([s_.k.reshape(-1, C_)[:s_.len, sl].float() @ qf[row, sl].float() for s_ in segs]) * (kk["scale"] if kk["scale"] is not None else d ** -0.5)
                     p = torch.softmax(sc, dim=0)
                     vs = torch.cat([s_.vt[sl, :s_.len].float() for s_ in segs], dim=1)           # [d, keys]
                     want = vs @ p
                     got = merged.view(Lq, C_)[row, sl].float()
                     worst = max(worst, float((got - want).abs().max() / want.abs().max()))
         print(f"merged attention vs fp32 over all keys: worst sampled row {worst:.2e}")
-        assert worst < 1.5e-2          # two bf16 roundings (partial outputs, merged output) of a ~N(0, 1/sqrt(keys)) result
+        assert worst < (1.5e-2 if n_merges == 1 else 2.5e-2)          # two (per-shard merges: up to four) bf16 roundings (partial outputs, merged output) of a ~N(0, 1/sqrt(keys)) result
     for o in outs:
         assert torch.equal(o, outs[0])                                  # every rank ends with the same gathered output
     err = rms_rel_err(outs[0].float().cpu(), single.cpu())

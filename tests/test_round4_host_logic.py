@@ -112,13 +112,17 @@ def test_pipeline_preprocess_resizes_like_the_published_image_processor():
     """VaeImageProcessor.preprocess for tensors (diffusers, third-party: restated): target rounded down to a multiple of 8,
     F.interpolate's default (legacy nearest), [0, 1] -> [-1, 1] unless the tensor already holds negative values."""
     import torch.nn.functional as F
+    from types import SimpleNamespace
     from more4d_amd.pipeline.pipeline_wan_fun_control import WanFunControlPipeline as P
+    me = SimpleNamespace(vae=SimpleNamespace(spatial_compression_ratio=8))      # the factor comes from the VAE (reference :185-186)
     for hin, win, h, w in ((384, 512, 480, 832), (720, 960, 480, 832), (50, 70, 36, 52), (33, 47, 64, 96)):
         v = torch.rand(1, 3, 2, hin, win)
         want = F.interpolate(v[0].transpose(0, 1), size=(h - h % 8, w - w % 8)).transpose(0, 1)[None] * 2 - 1
-        assert torch.equal(P._preprocess(v, h, w), want)
+        assert torch.equal(P._preprocess(me, v, h, w), want)
     v = torch.rand(1, 3, 1, 16, 16) * 2 - 1
-    assert torch.equal(P._preprocess(v, 16, 16), v)
+    assert torch.equal(P._preprocess(me, v, 16, 16), v)
+    me16 = SimpleNamespace(vae=SimpleNamespace(spatial_compression_ratio=16))
+    assert P._preprocess(me16, torch.rand(1, 3, 1, 40, 40), 40, 40).shape[-2:] == (32, 32)
 
 
 # ------------------------------------------------------------------ TeaCache + cfg-skip under CFG-parallel ranks (gloo)

@@ -183,3 +183,27 @@ print("RES", c["attn_q64"], c["attn_phased"], float(o.float().abs().sum()), floa
     assert abs(res["0"][2] - res["1"][2]) < 2e-3 * abs(res["0"][2]), res
     for i in (3, 4):
         assert abs(res["0"][i] - res["1"][i]) < 2e-2 * max(abs(res["0"][i]), 0.05), res
+
+
+def test_block_without_qk_norm_backward_vs_reference_gradients():
+    """Training with qk_norm=False (VERDICT r4 missing #2; reference wan_transformer4d.py:431-432: norm_q / norm_k are nn.Identity):
+    forward + backward of the block of dit_block_noqknorm.npz through autograd.block_backward — m4d_rmsnorm_rope / _bwd with NULL
+    weights (rotation only), cross-attention q / k straight from their projections — against the gradients torch autograd produced
+    through the REFERENCE block (tests/golden/make_golden_r5.py), every parameter and dL/dx, fp32, 1e-3."""
+    import torch.nn as nn
+    from test_round4_gpu import _block_ctx, _small_block
+    z, gz = load_npz("dit_block_noqknorm.npz"), load_npz("dit_block_noqknorm_grads.npz")
+    blk = _small_block("i2v_cross_attn", True, False, z, "w/", torch.float32)
+    assert isinstance(blk.self_attn.norm_q, nn.Identity)
+    grid = tuple(int(v) for v in z["grid"])
+    out, G = _block_ctx(blk, z["x"], z["e0"], z["ctx"], grid, dres=gz["cot"])
+    assert rel_err(out.cpu(), z["out"]) < 1e-3
+    names = [k[5:] for k in gz if k.startswith("grad/")]
+    assert len(names) > 25 and not any("norm_q" in n or "norm_k" in n for n in names)
+    gmax = max(float(gz["grad/" + n].abs().max()) for n in names)
+    for n in names:
+        got = G[n].detach().float().cpu().reshape(gz["grad/" + n].shape) if n != "x" else G["x"].float().cpu()
+        ref = gz["grad/" + n]
+        err = float((got.double() - ref.double()).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
+        assert err < 1e-3, (n, err)
+    assert not any("norm_q" in k or "norm_k" in k for k in G)

@@ -33,6 +33,9 @@ ap.add_argument("--eb", type=int, default=10, help="softmax units (2 scores per 
 ap.add_argument("--stamps", action="store_true", help="s_memtime stamps of wave 0 of workgroup 1000 at the phase boundaries of tiles 100..107")
 ap.add_argument("--stop", type=int, default=0, help="debug: leave the kernel at checkpoint N (1 after the loads were requested and have landed, 2 after Q~, 3 after tile 0, 4 in front of the epilogue)")
 ap.add_argument("--dbg", type=int, default=0)
+ap.add_argument("--wait1", action="store_true", help="one s_waitcnt lgkmcnt per fragment instead of one per TWO fragments (A/B: +0.8 % time)")
+ap.add_argument("--first-gap", type=int, default=1, help="phase B: no fillers behind its first N MFMAs (0: -0.8 % time, but the first row-max "
+                "instructions would read accumulators one MFMA behind their last write)")
 ap.add_argument("-o", default="more4d_amd/csrc/attention_q64_gen.inc")
 args = ap.parse_args()
 
@@ -154,8 +157,8 @@ def max_list(buf):
     """row maximum of S'(buf) over the 64 keys of the tile, both query halves, compared with THR -> vcc"""
     ins = []
     for k in range(8):
-        for h in range(2):
-            for sub in range(2):
+        for sub in range(2):          # the order the QK chains finished in: (h0, sub0), (h1, sub0), (h0, sub1), (h1, sub1)
+            for h in range(2):
                 t, b = TM(h, sub), S(buf, h, sub)
                 if k == 0:
                     ins.append(f"v_max3_f32 v{t}, v{b}, v{b + 1}, v{b + 2}")
@@ -272,6 +275,13 @@ def wait_lgkm(n):
     return f"s_waitcnt lgkmcnt({n})"
 
 
+def frag_wait(n):
+    """wait in front of fragment n of the continuous stream (8 reads in flight, in-order returns)"""
+    if args.wait1:
+        return [wait_lgkm(7)]
+    return [wait_lgkm(6)] if n % 2 == 0 else []
+
+
 # ---------------- phases ----------------
 def phase_a(c, fillers):
     """QK(i+1) into S'(Y), i = c mod 4; reads K(i+1) fragments 8..15 (KA[4..7]) and V^T(i) fragments 0..7 (VA[0..1])"""
@@ -280,7 +290,7 @@ def phase_a(c, fillers):
     for f in range(16):
         for h in range(2):
             mf.append(mfma_qk(Y, h, f & 1, f >> 1, f % 8))
-            pre.append([wait_lgkm(7)] if h == 0 else [])
+            pre.append(frag_wait(f) if h == 0 else [])
             post.append([])
         k = 2 * f + 1
         post[k].append(read_k(f + 8, f % 8) if f < 8 else read_v(f - 8, f % 8))
@@ -298,7 +308,7 @@ def phase_b(c, fillers, last_barrier=True):
     for g in range(16):
         for h in range(2):
             mf.append(mfma_pv(h, g & 3, g >> 2, g % 8))
-            pre.append([wait_lgkm(7)] if h == 0 else [])
+            pre.append(frag_wait(g) if h == 0 else [])
             post.append([])
         k = 2 * g + 1
         post[k].append(read_v(g + 8, g % 8) if g < 8 else read_k(g - 8, g % 8))
@@ -411,6 +421,9 @@ emit(f"v_bfe_u32 v{t[3]}, %[tid], 6, 2")                    # (the upper bits of
 emit("s_nop 3")
 emit(f"v_readfirstlane_b32 s{WAVE}, v{t[3]}")
 emit("s_nop 3")
+if args.stamps:      # only wave 0 stamps
+    emit(f"s_cmp_lg_u32 s{WAVE}, 0")
+    emit(f"s_cselect_b32 s{STMP}, 0x80000000, s{STMP}")
 emit(f"s_lshl_b32 s{WB}, s{WAVE}, 12")
 emit(f"s_add_u32 s{WB}, s{WB}, s{LDS0}")
 # kr = perm23(li) = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1)
@@ -634,8 +647,9 @@ for c in range(4):
     stamp(1)
     cont = Cont()
     fb = max_list(Y) + ["BRANCH"] + exp_units(Y, 0, args.eb, cvt=False)
-    # the first fillers read S'(Y), whose last MFMA closed phase A: two MFMAs (>= 64 cycles) between that write and the first VALU read
-    emit_stream(*phase_b(c, fb), cont=cont, branch_label=label(f"slow{c}"), first_gap=2)
+    # the first fillers read S'(Y), whose last MFMA closed phase A: with first_gap = 1 and the row-max chains in the order the QK chains
+    # finished, every accumulator is read at least two MFMAs (>= 64 cycles) behind its last write
+    emit_stream(*phase_b(c, fb), cont=cont, branch_label=label(f"slow{c}"), first_gap=args.first_gap)
     stamp(2)
     if c == 3:
         emit(f"s_branch {label('copy0')}")
