@@ -811,7 +811,7 @@ def main():
                 out["roofline"]["traffic"], out["roofline"]["traffic_detail"] = measure_traffic()
             ak = ks.get("attention", {})
             out["roofline_attention"] = {
-                "kernel": "attn128p_kernel (self) + attn128x_kernel (cross) via m4d_attention", "bound": "mfma", "achieved": ak.get("tflops", 0.0),
+                "kernel": "attn128q_kernel (self) + attn128x_kernel (cross) via m4d_attention", "bound": "mfma", "achieved": ak.get("tflops", 0.0),
                 "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ak.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
                 "launches": ak.get("launches", 0), "share_of_step_time": ak.get("ms", 0.0) / (dt * 1e3),
                 "by_class": {c: {"achieved": ks.get(f"attention:{c}", {}).get("tflops", 0.0),

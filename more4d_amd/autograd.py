@@ -272,13 +272,21 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     rope = dict(head_dim=d, eps=sa.eps, cos=c.cos, sin=c.sin, rows_per_sample=Lp, rope_len=c.rope_len,
                 pos_offset=c.pos_offset)
-    ops.rmsnorm_rope(q, nw(sa.norm_q), k, nw(sa.norm_k), **rope)
+    # bf16 + qk_norm: the softmax scale (x log2 e) rides in q's RMSNorm weight, as in the inference path (models/wan_transformer4d.py:
+    # _FOLD_QSCALE) — the attention calls then take scale = ln 2, the forward runs on attn128q_kernel with an exact log-sum-exp, and the
+    # norm-weight gradient the backward kernel returns is d/d(w c): scaled back by c below
+    from .models.wan_transformer4d import LOG2E, _FOLD_QSCALE, _folded_norm_weight
+    fold = _FOLD_QSCALE and sa.qk_norm and T == torch.bfloat16
+    qc_ = d ** -0.5 * LOG2E
+    wq_self = _folded_norm_weight(sa.norm_q.weight, d, c.f32cache) if fold else nw(sa.norm_q)
+    sm = dict(scale=1.0 / LOG2E) if fold else {}
+    ops.rmsnorm_rope(q, wq_self, k, nw(sa.norm_k), **rope)
     o, lse1 = saved.get("o"), saved.get("lse1")
     if o is None:
         vt = ops.transpose(v)                                        # V^T [C, R]
         lse1 = torch.empty((B, n, Lp), device=dev, dtype=torch.float32)
         o = ops.attention(q, [KV(k, vt, Lp * 3 * C, 3 * C, Lp, R, c.key_len)], B=B, Lq=Lp, heads=n, head_dim=d,
-                          q_bs=Lp * 3 * C, q_ls=3 * C, lse=lse1).view(R, C)
+                          q_bs=Lp * 3 * C, q_ls=3 * C, lse=lse1, **sm).view(R, C)
     y1 = saved.get("y1")
     if y1 is None:
         y1 = ops.gemm_bt(o, sa.o.weight, sa.o.bias)
@@ -381,14 +389,16 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     do, G["self_attn.o.weight"], G["self_attn.o.bias"] = linear_bwd(o, sa.o.weight, dy1)
     dqkv = torch.empty((R, 3 * C), device=dev, dtype=T)
     ops.attention_bwd(q, k, v, o, do, lse1, B=B, Lq=Lp, Lk=c.key_len, Lk_rows=Lp, heads=n, head_dim=d,
-                      dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+                      dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:], **sm)
     if sa.qk_norm:
         dwq, dwk = zeros(C), zeros(C)
         G["self_attn.norm_q.weight"], G["self_attn.norm_k.weight"] = dwq, dwk
     else:
         dwq = dwk = None
-    ops.rmsnorm_rope_bwd_(dqkv[:, :C], qkv_pre[:, :C], nw(sa.norm_q), dwq, dqkv[:, C:2 * C], qkv_pre[:, C:2 * C], nw(sa.norm_k), dwk,
+    ops.rmsnorm_rope_bwd_(dqkv[:, :C], qkv_pre[:, :C], wq_self, dwq, dqkv[:, C:2 * C], qkv_pre[:, C:2 * C], nw(sa.norm_k), dwk,
                           **rope)
+    if fold:
+        dwq.mul_(qc_)
     wt = torch.empty((C, 3 * C), device=dev, dtype=T)               # [Wq^T | Wk^T | Wv^T]
     for j, lin in enumerate((sa.q, sa.k, sa.v)):
         ops.transpose(lin.weight, out=wt[:, j * C:(j + 1) * C])

@@ -586,7 +586,10 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         M4D_ENV_ONCE(q64_mode, "M4D_ATTN_Q64", 1);     // A/B: 0 = attn128p_kernel
         const bool folded = fabsf(p.sc - 1.f) < 1e-6f;
         if (folded) q.sc = 1.f;
-        if (w8 && q64_mode && p.kv.nseg == 1 && !p.kv.new_softmax && !p.accumulate && p.kv.len[0] >= 4 * 64 && (folded || !p.lse) &&
+        int q64_tiles = 0, q64_rag = 0;      // full 64-key tiles of all segments / segments with a ragged tail
+        for (int i = 0; i < p.kv.nseg; ++i)
+            if (p.kv.len[i] > 0) { q64_tiles += (int)(p.kv.len[i] / 64); q64_rag += (p.kv.len[i] % 64) != 0; }
+        if (w8 && q64_mode && same_strides && !p.kv.new_softmax && !p.accumulate && q64_tiles >= 4 && q64_rag <= 5 && (folded || !p.lse) &&
             p.kv.k_ls[0] < (1 << 20) && p.kv.vt_ls[0] < (1 << 23) && p.q_ls < (1 << 20) && p.o_ls < (1 << 20)) {
             static PerDeviceOnce configured_q;
             if (configured_q.pending()) {

@@ -90,9 +90,9 @@ LOG2E = 1.4426950408889634
 # kernels are then called with scale = ln 2 (scale * log2(e) == 1): attn128q_kernel takes q' as its Q~ operand bit for bit instead of
 # rounding Q * c to bf16 a second time (csrc/attention_q64.h).  bf16 inference with qk_norm only; M4D_FOLD_QSCALE=0 = A/B.
 _FOLD_QSCALE = os.environ.get("M4D_FOLD_QSCALE", "1") != "0"
-# T-sharded self-attention: the gathered remote shards one call per shard (single-segment calls run on attn128q_kernel) + LSE merges,
-# instead of one multi-segment call on the phased kernel; M4D_SP_PER_SEGMENT=0 = A/B (tools/bench_shard.py)
-_SP_PER_SEGMENT = os.environ.get("M4D_SP_PER_SEGMENT", "1") != "0"
+# T-sharded self-attention, A/B (tools/bench_shard.py): M4D_SP_PER_SEGMENT=1 = the gathered remote shards one call per shard + LSE merges
+# instead of one multi-segment call (attn128q_kernel takes up to 8 segments with up to 5 ragged tails itself, so this is off)
+_SP_PER_SEGMENT = os.environ.get("M4D_SP_PER_SEGMENT", "0") != "0"
 
 
 def _folded_norm_weight(p, head_dim, cache):
@@ -103,6 +103,21 @@ def _folded_norm_weight(p, head_dim, cache):
         hit = (key, (p.detach().float() * (head_dim ** -0.5 * LOG2E)).contiguous())
         cache[("fold", id(p))] = hit
     return hit[1]
+
+
+def _ragged_chunks(segs, max_ragged):
+    """consecutive runs of K / V^T segments with at most `max_ragged` lengths that are not a multiple of the 64-key tile"""
+    runs, cur, n = [], [], 0
+    for sg in segs:
+        rag = 1 if sg.len % 64 else 0
+        if cur and n + rag > max_ragged:
+            runs.append(cur)
+            cur, n = [], 0
+        cur.append(sg)
+        n += rag
+    if cur:
+        runs.append(cur)
+    return runs
 
 
 class WanRMSNorm(nn.Module):
@@ -229,16 +244,18 @@ class WanSelfAttention(nn.Module):
                 if o is None:           # this rank holds only padding rows: nothing local to attend
                     o = ops.attention(q, rem, **kw)
                 elif rem and _SP_PER_SEGMENT and sm and len(rem) <= 3:      # (every merge rounds the running output to bf16 once more)
-                    # one call per remote shard, merged through the log-sum-exps as it completes: every call is a single K / V^T
-                    # segment, which is what attn128q_kernel (one wave per SIMD, +15 % over the multi-segment phased kernel) takes
+                    # one call per remote shard, merged through the log-sum-exps as it completes
                     lse_r, o_r = torch.empty_like(lse), torch.empty_like(o)
                     for seg in rem:
                         ops.attention(q, [seg], lse=lse_r, out=o_r, **kw)
                         ops.attn_merge_(o, lse, o_r, lse_r, B=B, L=Lp, heads=n, head_dim=d)
                 elif rem:
-                    lse_r = torch.empty_like(lse)
-                    o_r = ops.attention(q, rem, lse=lse_r, **kw)
-                    ops.attn_merge_(o, lse, o_r, lse_r, B=B, L=Lp, heads=n, head_dim=d)
+                    # the remote shards in as few calls as attn128q_kernel allows (it stages at most five ragged tails per call: 7 remote
+                    # shards of 2 730 keys at sp8 = two calls); every call's partial softmax is merged through the log-sum-exps
+                    lse_r, o_r = torch.empty_like(lse), None
+                    for chunk in _ragged_chunks(rem, 5 if sm else len(rem)):
+                        o_r = ops.attention(q, chunk, lse=lse_r, out=o_r, **kw)
+                        ops.attn_merge_(o, lse, o_r, lse_r, B=B, L=Lp, heads=n, head_dim=d)
                 segs = None
             else:
                 segs = c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)

@@ -182,8 +182,8 @@ def test_phased_kernel_ragged_tail_with_poisoned_padding():
                     for off, L in zip((0, Lp[0]), lens)]
         ops.launch_counts(reset=True)
         out = ops.attention(q, segs, B=B, Lq=Lq, heads=n, head_dim=d)
-        c = ops.launch_counts()       # one long-key launch: attn128q (single segment) or attn128p (segments)
-        assert c["attn_phased"] + c["attn_q64"] == 1 and (c["attn_q64"] == 1) == (len(lens) == 1), c
+        c = ops.launch_counts()       # one long-key launch on attn128q_kernel (one or several segments, one ragged tail each)
+        assert c["attn_phased"] + c["attn_q64"] == 1 and c["attn_q64"] == 1, c
         assert torch.isfinite(out.float()).all()
         rows = torch.arange(0, Lq, 3).to(DEV)
         want = torch_groups(q, refs, [list(range(len(lens)))], B, Lq, n, d, rows)

@@ -316,9 +316,10 @@ def test_n_rank_schedule_full_size_bf16(mode, world):
     o_att, o_merge = ops.attention, ops.attn_merge_
 
     import more4d_amd.models.wan_transformer4d as wt_
-    # layer 0 of a rank: one local call + one call over all remote shards, or (M4D_SP_PER_SEGMENT, <= 3 remote shards) one call per
-    # remote shard, each followed by a merge — the record is taken at the LAST merge of the layer
-    n_merges = (world - 1) if (wt_._SP_PER_SEGMENT and world - 1 <= 3) else 1
+    # layer 0 of a rank: one local call + the remote shards in as few calls as attn128q_kernel allows (five ragged tails per call: 7
+    # remote shards = two calls), each followed by a merge — the record is taken at the LAST merge of the layer
+    shard = (kw["seq_len"] + H_ * W_ // 4) // world                  # keys per rank (21 840 / world)
+    n_merges = (world - 1) if (wt_._SP_PER_SEGMENT and world - 1 <= 3) else (1 if shard % 64 == 0 else -(-(world - 1) // 5))
 
     def att(q, segs, **kk):
         out = o_att(q, segs, **kk)

@@ -207,3 +207,51 @@ def test_block_without_qk_norm_backward_vs_reference_gradients():
         err = float((got.double() - ref.double()).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
         assert err < 1e-3, (n, err)
     assert not any("norm_q" in k or "norm_k" in k for k in G)
+
+
+@pytest.mark.parametrize("lens,lp", [((2730, 2736, 1000), 2736), ((5460, 5460, 5460), 5464), ((2112, 64, 2048), 2112),
+                                     ((700, 650, 1300, 90, 2100), 2104), ((40, 3000), 3000), ((300,) * 6, 304)])
+def test_attention_q64_kernel_segments(lens, lp):
+    """attn128q_kernel over SEVERAL K / V^T segments (the gathered shards of the T-sharded loop, csrc/attention_q64.h): the full tiles
+    of all segments form one pipelined list (scalar tile iterators switch segments through the kernel-argument table), every segment's
+    ragged tail is staged and processed first (up to five; slots 1..4 sit in the pipeline stages, so the first tile requests wait for
+    them).  Garbage / NaN padding behind every segment, score spikes at segment seams, log-sum-exp with the folded scale.  Six ragged
+    tails fall back to the phased kernel."""
+    from more4d_amd import ops
+    B, n, D, Lq = 1, 3, 128, 1290
+    C = n * D
+    g = torch.Generator().manual_seed(len(lens) * 7 + lens[0])
+    c = D ** -0.5 * 1.4426950408889634
+    qq = torch.randn(B, Lq, n, D, generator=g)
+    ks = [torch.randn(B, l, n, D, generator=g) for l in lens]
+    vs = [torch.randn(B, l, n, D, generator=g) for l in lens]
+    ks[0][0, lens[0] - 1, 0] = qq[0, 5, 0] * 5.0             # last key of segment 0 (its ragged tail, if any)
+    ks[-1][0, 0, n - 1] = qq[0, 700, n - 1] * 6.0            # first key of the last segment
+    qs = (qq.reshape(B, Lq, C) * c).to(DEV, BF).contiguous()
+    segs = []
+    for k_, v_ in zip(ks, vs):
+        l = k_.shape[1]
+        kd = torch.full((B, lp, C), 7.0, dtype=BF)
+        kd[:, :l] = k_.reshape(B, l, C).to(BF)
+        vt = torch.full((C, B * lp), float("nan"), dtype=BF)
+        for b in range(B):
+            vt[:, b * lp:b * lp + l] = v_[b].reshape(l, C).t().to(BF)
+        segs.append(ops.KV(kd.to(DEV), vt.to(DEV), lp * C, C, lp, B * lp, l))
+    qf = qs.float().view(B, Lq, n, D).permute(0, 2, 1, 3)
+    kf = torch.cat(ks, 1).to(BF).float().to(DEV).permute(0, 2, 1, 3)
+    vf = torch.cat(vs, 1).to(BF).float().to(DEV).permute(0, 2, 1, 3)
+    s = (qf @ kf.transpose(-1, -2)) * 0.6931471805599453
+    ref = (torch.softmax(s, -1) @ vf).permute(0, 2, 1, 3).reshape(B, Lq, C)
+    lse = torch.zeros(B, n, Lq, device=DEV)
+    ops.launch_counts(reset=True)
+    out = ops.attention(qs, segs, B=B, Lq=Lq, heads=n, head_dim=D, scale=0.6931471805599453, lse=lse)
+    cnt = ops.launch_counts()
+    nrag = sum(1 for l in lens if l % 64)
+    if sum(l // 64 for l in lens) >= 4 and nrag <= 5 and sum(lens) >= 2048:
+        assert cnt["attn_q64"] == 1, cnt
+    else:
+        assert cnt["attn_q64"] == 0, cnt
+    assert bool(torch.isfinite(out.float()).all())
+    assert rel_err(out.float(), ref) < 6e-3
+    assert float((lse - torch.logsumexp(s, -1) * 1.4426950408889634).abs().max()) < 1e-3
+    assert torch.equal(out, ops.attention(qs, segs, B=B, Lq=Lq, heads=n, head_dim=D, scale=0.6931471805599453))

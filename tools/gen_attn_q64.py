@@ -31,8 +31,6 @@ ap.add_argument("--plain", action="store_true", help="debug: no interleaving (MF
 ap.add_argument("--cap", type=int, default=5, help="instructions per MFMA gap besides the MFMA")
 ap.add_argument("--eb", type=int, default=10, help="softmax units (2 scores per query half) exponentiated in phase B")
 ap.add_argument("--stamps", action="store_true", help="s_memtime stamps of wave 0 of workgroup 1000 at the phase boundaries of tiles 100..107")
-ap.add_argument("--stop", type=int, default=0, help="debug: leave the kernel at checkpoint N (1 after the loads were requested and have landed, 2 after Q~, 3 after tile 0, 4 in front of the epilogue)")
-ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--wait1", action="store_true", help="one s_waitcnt lgkmcnt per fragment instead of one per TWO fragments (A/B: +0.8 % time)")
 ap.add_argument("--first-gap", type=int, default=1, help="phase B: no fillers behind its first N MFMAs (0: -0.8 % time, but the first row-max "
                 "instructions would read accumulators one MFMA behind their last write)")
@@ -89,7 +87,7 @@ def RING(slot):
 
 
 # SGPRs
-KP, VP, KTS, NT1, JK = 40, 42, 44, 45, 46
+KP, VP, KTS, KSTEP, VSTEP, KCNT = 40, 42, 44, 45, 46, 47
 WB, REM, THR, SC = 48, 49, 50, 51
 QP, OP, LP = 52, 54, 56
 QLS, OLS, NROWS, RAG, LDS0, WAVE = 58, 59, 60, 61, 62, 63
@@ -97,6 +95,12 @@ ST = list(range(64, 80))          # scalar temps
 RET, TGT, EXS = 80, 82, 84
 KLS, VLS = 86, 87
 DBG, STMP = 88, 90
+VCNT, RET2, KSEG, VSEG = 91, 92, 94, 95
+KARG, BIDX, HIDX, NSEG, NRAG = 96, 98, 99, 100, 101
+RAGLO, RAGHI = 78, 79      # (= ST[14], ST[15]; prologue only) k_lim of ragged slots 0..3 / 4, one byte each; RAG = k_lim of the tile in flight
+# byte offsets inside the kernel-argument segment (AttnArgs: q, out, kv{k[8], vt[8], k_bs[8], k_ls[8], vt_bs[8], vt_ls[8], len[8], ...};
+# static_asserts in attention_q64.h)
+KA_K, KA_VT, KA_KBS, KA_VTBS, KA_LEN = 16, 80, 144, 272, 400
 
 
 def vr(a, n):
@@ -116,7 +120,15 @@ _uid = [0]
 
 
 def emit(s):
-    out.append(s)
+    """a line, a list of lines, or a callable that returns either (items that carry labels are generated afresh per emission: the
+    skeleton of phase B is emitted twice, in the loop and in the rare path)"""
+    if callable(s):
+        s = s()
+    if isinstance(s, (list, tuple)):
+        for x in s:
+            emit(x)
+    else:
+        out.append(s)
 
 
 def label(name):
@@ -254,7 +266,7 @@ def emit_stream(mfmas, pre, post, fillers, cont=None, branch_label=None, first_g
         used = len(pre[k + 1]) if k + 1 < n else 0
         for s in post[k]:
             emit(s)
-            used += 1
+            used += 4 if callable(s) else 1
         room = args.cap - used if k >= first_gap else 0
         if k == n - 1:
             room = len(fl)          # whatever is left goes behind the last MFMA
@@ -323,12 +335,10 @@ def phase_b(c, fillers, last_barrier=True):
         post[2 + 2 * p] += [f"s_add_u32 m0, s{WB}, 0x{ks + p * 1024:x}", f"global_load_lds_dwordx4 v{DK[p]}, {sr(KP)}"]
     for p in range(4):
         post[10 + 2 * p] += [f"s_add_u32 m0, s{WB}, 0x{vs + p * 1024:x}", f"global_load_lds_dwordx4 v{DV[p]}, {sr(VP)}"]
-    t = ST[0]
-    post[18] += [f"s_cmp_lt_u32 s{JK}, s{NT1}", f"s_cselect_b32 s{t}, s{KTS}, 0"]
-    post[20] += [f"s_add_u32 s{KP}, s{KP}, s{t}", f"s_addc_u32 s{KP + 1}, s{KP + 1}, 0"]
-    post[22] += [f"s_cmp_le_u32 s{JK}, s{NT1}", f"s_cselect_b32 s{t}, 128, 0"]
-    post[24] += [f"s_add_u32 s{VP}, s{VP}, s{t}", f"s_addc_u32 s{VP + 1}, s{VP + 1}, 0"]
-    post[26] += [f"s_add_u32 s{JK}, s{JK}, 1"]
+    post[18].append(adv_test("k"))
+    post[20] += adv_step("k")
+    post[22].append(adv_test("v"))
+    post[24] += adv_step("v")
     if last_barrier:
         post[31] += ["s_waitcnt vmcnt(12)", "s_barrier"]
     return mf, pre, post, fillers
@@ -357,28 +367,45 @@ def plain_pv():
             emit(read_v(g + 8, g % 8))
 
 
-def checkpoint(n):
-    if args.stop == n:
-        emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
-        emit(f"s_branch {label('end')}")
+_calls = [0]
 
 
-def call(name, n):
-    """s_swappc to a subroutine placed BEHIND every call site (positive offset)"""
+def call(name, ret=None):
+    """s_swappc to a subroutine placed BEHIND every call site (positive offset); ret = SGPR pair that takes the return address"""
+    _calls[0] += 1
+    n = _calls[0]
     here = label(f"pc{n}")
     emit(f"s_getpc_b64 {sr(TGT)}")
     put_label(f"pc{n}")
     emit(f"s_add_u32 s{TGT}, s{TGT}, {label(name)}-{here}")
     emit(f"s_addc_u32 s{TGT + 1}, s{TGT + 1}, 0")
-    emit(f"s_swappc_b64 {sr(RET)}, {sr(TGT)}")
-
-
-_calls = [0]
+    emit(f"s_swappc_b64 {sr(RET if ret is None else ret)}, {sr(TGT)}")
 
 
 def call_fix(buf):
-    _calls[0] += 1
-    call(f"fix{buf}", _calls[0])
+    call(f"fix{buf}")
+
+
+# K / V^T tile iterators over the segment list (SGPRs: pointer of the NEXT request, tiles left in its segment, step).  The fast path of an
+# advance is five scalar instructions; the end of a segment branches to an out-of-line block that calls the segment routine.
+_sites = []
+
+
+def adv_test(kind):
+    """first half of an advance (a callable: fresh labels per emission): count down, leave for the segment switch at zero"""
+    def gen():
+        _calls[0] += 1
+        n = _calls[0]
+        cnt = KCNT if kind == "k" else VCNT
+        site, back = label(f"sw{kind}{n}"), label(f"bk{kind}{n}")
+        _sites.append((site, back, kind))
+        return [f"s_sub_u32 s{cnt}, s{cnt}, 1", f"s_cmp_eq_u32 s{cnt}, 0", f"s_cbranch_scc1 {site}", back + ":"]
+    return gen
+
+
+def adv_step(kind):
+    ptr, step = (KP, KSTEP) if kind == "k" else (VP, VSTEP)
+    return [f"s_add_u32 s{ptr}, s{ptr}, s{step}", f"s_addc_u32 s{ptr + 1}, s{ptr + 1}, 0"]
 
 
 def stamp(slot):
@@ -404,12 +431,11 @@ def stamp(slot):
 # =====================================================================================================================
 t = TMP
 emit("; ---- inputs -> fixed registers ----")
-for dst, src in ((KP, "kp_lo"), (KP + 1, "kp_hi"), (VP, "vp_lo"), (VP + 1, "vp_hi"), (QP, "qp_lo"), (QP + 1, "qp_hi"),
-                 (OP, "op_lo"), (OP + 1, "op_hi"), (LP, "lp_lo"), (LP + 1, "lp_hi"), (KLS, "klsb"), (VLS, "vlsb"), (QLS, "qlsb"),
-                 (OLS, "olsb"), (NT1, "nt"), (RAG, "rag"), (NROWS, "nrows"), (SC, "sc"), (LDS0, "lds0"), (DBG, "dbg_lo"),
-                 (DBG + 1, "dbg_hi"), (STMP, "stamp")):
+for dst, src in ((KARG, "ka_lo"), (KARG + 1, "ka_hi"), (BIDX, "b"), (HIDX, "h"), (NSEG, "nseg"), (NRAG, "nrag"), (RAGLO, "rag_lo"),
+                 (RAGHI, "rag_hi"), (QP, "qp_lo"), (QP + 1, "qp_hi"), (OP, "op_lo"), (OP + 1, "op_hi"), (LP, "lp_lo"), (LP + 1, "lp_hi"),
+                 (KLS, "klsb"), (VLS, "vlsb"), (QLS, "qlsb"), (OLS, "olsb"), (NROWS, "nrows"), (SC, "sc"), (LDS0, "lds0"),
+                 (DBG, "dbg_lo"), (DBG + 1, "dbg_hi"), (STMP, "stamp")):
     emit(f"s_mov_b32 s{dst}, %[{src}]")
-emit(f"s_sub_u32 s{NT1}, s{NT1}, 1")                       # NT - 1
 emit(f"s_lshl_b32 s{KTS}, s{KLS}, 6")                      # bytes per 64-key K tile
 # lane constants: t0 = lane, t1 = li, t2 = hi, t3 = wave
 emit(f"v_and_b32 v{t[0]}, 63, %[tid]")
@@ -474,17 +500,6 @@ for p in range(4):
     emit(f"v_lshlrev_b32 v{t[7]}, 4, v{t[7]}")
     emit(f"v_mul_lo_u32 v{t[6]}, v{t[6]}, s{VLS}")
     emit(f"v_add_u32 v{DV[p]}, v{t[6]}, v{t[7]}")
-if args.dbg >= 5:      # dump the DMA lane offsets and a few scalars: 16 dwords per thread at out + tid * 64
-    emit(f"v_and_b32 v{t[9]}, 0xff, %[tid]")
-    emit(f"v_lshlrev_b32 v{t[9]}, 6, v{t[9]}")
-    for i, r in enumerate(DK + DV):
-        emit(f"global_store_dword v{t[9]}, v{r}, {sr(OP)} offset:{i * 4}")
-    for i, sreg in enumerate((KLS, VLS, WAVE, WB, KTS, NT1, QLS, OLS)):
-        emit(f"v_mov_b32 v{t[10]}, s{sreg}")
-        emit(f"global_store_dword v{t[9]}, v{t[10]}, {sr(OP)} offset:{32 + i * 4}")
-    emit("s_waitcnt vmcnt(0)")
-    emit(f"s_branch {label('end')}")
-checkpoint(5)
 # ---- Q rows: row = 64 w + 32 h + li (clamped to nrows - 1), 16 loads of 16 bytes per lane into v32..v95 ----
 emit(f"s_sub_u32 s{ST[1]}, s{NROWS}, 1")
 for h in range(2):
@@ -498,64 +513,34 @@ for h in range(2):
     emit(f"v_add_u32 v{t[8 + h]}, v{t[6]}, v{t[7]}")
     for kk in range(8):
         emit(f"global_load_dwordx4 {vr(32 + (h * 8 + kk) * 4, 4)}, v{t[8 + h]}, {sr(QP)} offset:{kk * 32}")
-checkpoint(6)
-# ---- DMA prologue: K0 V0 K1 K2 V1 K3 V2 (NT >= 4: the host only selects this kernel for long key ranges) ----
-kb, vb = ST[2], ST[4]        # running tile pointers (64-bit)
-emit(f"s_mov_b64 {sr(kb)}, {sr(KP)}")
-emit(f"s_mov_b64 {sr(vb)}, {sr(VP)}")
 
 
-def dma_k(tile):
-    if args.dbg and tile == 0:
-        if args.dbg == 1:      # nops between the pointer / m0 writes and the request
-            emit(f"s_mov_b64 {sr(kb)}, {sr(KP)}")
-            for p in range(4):
-                emit(f"s_add_u32 m0, s{WB}, 0x{p * 1024:x}")
-                emit("s_nop 7")
-                emit(f"global_load_lds_dwordx4 v{DK[p]}, {sr(kb)}")
-        elif args.dbg == 2:    # zero lane offsets
-            emit(f"v_mov_b32 v{t[9]}, 0")
-            emit(f"s_mov_b32 m0, s{WB}")
-            emit("s_nop 7")
-            emit(f"global_load_lds_dwordx4 v{t[9]}, {sr(KP)}")
-        elif args.dbg == 3:    # a plain load through the same address
-            emit(f"global_load_dwordx4 {vr(96, 4)}, v{DK[0]}, {sr(KP)}")
-        elif args.dbg == 4:    # plain load with zero offset
-            emit(f"v_mov_b32 v{t[9]}, 0")
-            emit(f"global_load_dwordx4 {vr(96, 4)}, v{t[9]}, {sr(KP)}")
-        return
-    emit(f"s_mul_i32 s{ST[6]}, s{KTS}, {tile}")
-    emit(f"s_mul_hi_u32 s{ST[7]}, s{KTS}, {tile}")
-    emit(f"s_add_u32 s{kb}, s{KP}, s{ST[6]}")
-    emit(f"s_addc_u32 s{kb + 1}, s{KP + 1}, s{ST[7]}")
-    for p in range(4):
-        emit(f"s_add_u32 m0, s{WB}, 0x{(tile & 3) * STAGE + p * 1024:x}")
-        emit(f"global_load_lds_dwordx4 v{DK[p]}, {sr(kb)}")
+def dma_prologue():
+    """iterators to the first tile, then the requests K0 V0 K1 K2 V1 K3 V2 (>= 4 full tiles: host-checked); what the loop expects: the next
+    K request is tile 4, the next V^T request tile 3"""
+    emit(f"s_mov_b32 s{KSEG}, -1")
+    emit(f"s_mov_b32 s{VSEG}, -1")
+    emit(f"s_mov_b32 s{KSTEP}, s{KTS}")
+    emit(f"s_mov_b32 s{VSTEP}, 128")
+    call("kseg_next")
+    call("vseg_next")
+    for kind, tile in (("k", 0), ("v", 0), ("k", 1), ("k", 2), ("v", 1), ("k", 3), ("v", 2)):
+        for p in range(4):
+            if kind == "k":
+                emit(f"s_add_u32 m0, s{WB}, 0x{(tile & 3) * STAGE + p * 1024:x}")
+                emit(f"global_load_lds_dwordx4 v{DK[p]}, {sr(KP)}")
+            else:
+                emit(f"s_add_u32 m0, s{WB}, 0x{(tile & 3) * STAGE + VOFF + p * 1024:x}")
+                emit(f"global_load_lds_dwordx4 v{DV[p]}, {sr(VP)}")
+        emit(adv_test(kind))
+        emit(adv_step(kind))
 
 
-def dma_v(tile):
-    emit(f"s_add_u32 s{vb}, s{VP}, {tile * 128}")
-    emit(f"s_addc_u32 s{vb + 1}, s{VP + 1}, 0")
-    for p in range(4):
-        emit(f"s_add_u32 m0, s{WB}, 0x{(tile & 3) * STAGE + VOFF + p * 1024:x}")
-        emit(f"global_load_lds_dwordx4 v{DV[p]}, {sr(vb)}")
-
-
-dma_k(0)
-checkpoint(7)
-dma_v(0)
-checkpoint(8)
-dma_k(1); dma_k(2); dma_v(1); dma_k(3); dma_v(2)
-# running pointers of the loop: the next K request is tile min(4, NT-1), the next V^T request tile 3
-emit(f"s_min_u32 s{ST[6]}, s{NT1}, 4")
-emit(f"s_mul_hi_u32 s{ST[7]}, s{KTS}, s{ST[6]}")
-emit(f"s_mul_i32 s{ST[6]}, s{KTS}, s{ST[6]}")
-emit(f"s_add_u32 s{KP}, s{KP}, s{ST[6]}")
-emit(f"s_addc_u32 s{KP + 1}, s{KP + 1}, s{ST[7]}")
-emit(f"s_add_u32 s{VP}, s{VP}, {3 * 128}")
-emit(f"s_addc_u32 s{VP + 1}, s{VP + 1}, 0")
-emit(f"s_mov_b32 s{JK}, 4")
-checkpoint(1)
+# ---- DMA prologue right away unless ragged tails sit in the pipeline stages (more than one ragged tail: slots 1..4 = stages 0..3) ----
+emit(f"s_cmp_gt_u32 s{NRAG}, 1")
+emit(f"s_cbranch_scc1 {label('nodma0')}")
+dma_prologue()
+put_label("nodma0")
 # ---- state: O = 0, l = 0, -R tuples = 0, R = 0, THR = -inf ----
 emit(f"v_mov_b32 v{t[0]}, 0")
 for r in range(128):
@@ -568,7 +553,14 @@ for h in range(2):
         emit(f"v_mov_b32 v{NM(h, r)}, 0")
 emit(f"s_mov_b32 s{THR}, 0xff800000")
 # ---- Q~ = bf16(Q * sc) -> a128..a191 ----
-emit("s_waitcnt vmcnt(28)")
+emit(f"s_cmp_gt_u32 s{NRAG}, 1")
+emit(f"s_cbranch_scc1 {label('qwait0')}")
+emit("s_waitcnt vmcnt(28)")                                  # the 28 DMA pieces behind the Q loads may stay in flight
+put_label("qwait0")
+emit(f"s_cmp_le_u32 s{NRAG}, 1")
+emit(f"s_cbranch_scc1 {label('qwait1')}")
+emit("s_waitcnt vmcnt(0)")
+put_label("qwait1")
 for d in range(64):
     src = 32 + d
     emit(f"v_lshlrev_b32 v{t[0]}, 16, v{src}")
@@ -578,37 +570,34 @@ for d in range(64):
     emit(f"v_cvt_pk_bf16_f32 v{t[2]}, v{t[0]}, v{t[1]}")
     emit(f"v_accvgpr_write_b32 a{128 + d}, v{t[2]}")
 emit("s_nop 7")
-checkpoint(2)
-# ---- ragged tail (rag = 1..63 valid keys, staged by the wrapper behind the four stages): a complete tile in plain order ----
-emit(f"s_cmp_eq_u32 s{RAG}, 0")
-emit(f"s_cbranch_scc1 {label('norag')}")
+# ---- ragged tails (one per K / V^T segment whose length is not a multiple of 64; staged by the wrapper: slot 0 behind the four stages,
+# slots 1..4 in stages 0..3): complete tiles in plain order, subroutine rag_tile ----
+emit(f"s_mov_b32 s{REM}, 0")
+put_label("ragloop")
+emit(f"s_cmp_ge_u32 s{REM}, s{NRAG}")
+emit(f"s_cbranch_scc1 {label('ragdone')}")
+emit(f"s_lshl_b32 s{ST[1]}, s{REM}, 3")
+emit(f"s_lshr_b32 s{RAG}, s{RAGLO}, s{ST[1]}")
+emit(f"s_cmp_eq_u32 s{REM}, 4")
+emit(f"s_cselect_b32 s{RAG}, s{RAGHI}, s{RAG}")
+emit(f"s_and_b32 s{RAG}, s{RAG}, 0xff")                      # k_lim of this slot
+emit(f"s_sub_u32 s{ST[1]}, s{REM}, 1")
+emit(f"s_lshl_b32 s{ST[1]}, s{ST[1]}, 15")
+emit(f"s_cmp_eq_u32 s{REM}, 0")
+emit(f"s_cselect_b32 s{ST[1]}, 0x{RAGOFF:x}, s{ST[1]}")     # LDS offset of the slot
 for a_ in KA + VA:
-    emit(vadd_imm(a_, RAGOFF))
-plain_qk(1)
-emit("s_nop 15")
-emit("s_nop 15")
-emit(f"v_bfe_u32 v{t[0]}, %[tid], 5, 1")
-emit(f"v_lshlrev_b32 v{t[0]}, 3, v{t[0]}")                 # 8 * hi
-emit(f"v_mov_b32 v{t[1]}, 0xff800000")
-for sub in range(2):
-    for r in range(16):
-        kb_ = sub * 32 + 16 * (r >> 3) + (r & 7)            # key of this register for hi = 0
-        emit(f"s_sub_i32 s{ST[0]}, s{RAG}, {kb_}")
-        emit(f"v_cmp_gt_i32 vcc, s{ST[0]}, v{t[0]}")        # key < rag
-        for h in range(2):
-            emit(f"v_cndmask_b32 v{S(1, h, sub, r)}, v{t[1]}, v{S(1, h, sub, r)}, vcc")
-for s_ in max_list(1):
-    emit(s_)
-emit(f"s_cbranch_vccz {label('ragnofix')}")
-call_fix(1)
-put_label("ragnofix")
-for s_ in exp_units(1, 0, 32):
-    emit(s_)
-emit("s_nop 1")
-plain_pv()
+    emit(f"v_add_u32 v{a_}, s{ST[1]}, v{a_}")
+call("rag_tile", RET2)
 for a_ in KA + VA:
-    emit(vadd_imm(a_, -RAGOFF))
-put_label("norag")
+    emit(f"v_subrev_u32 v{a_}, s{ST[1]}, v{a_}")
+emit(f"s_add_u32 s{REM}, s{REM}, 1")
+emit(f"s_branch {label('ragloop')}")
+put_label("ragdone")
+emit(f"s_cmp_le_u32 s{NRAG}, 1")
+emit(f"s_cbranch_scc1 {label('nodma1')}")
+emit("s_barrier")                                            # every wave has read the ragged slots in stages 0..3
+dma_prologue()
+put_label("nodma1")
 # ---- tile 0: S'(0) in lock step, start of its softmax, K(1) fragments 0..7 on their way ----
 emit("s_waitcnt vmcnt(12)")
 emit("s_barrier")
@@ -629,8 +618,7 @@ for f in range(8):
     emit(read_k(f, f))
 for j in range(4):
     emit(vadd_imm(KA[j], STAGE))                            # KA[0..3] -> tile 2
-checkpoint(3)
-emit(f"s_mov_b32 s{REM}, s{NT1}")                           # NT - 1 full iterations, then the tail
+emit(f"s_sub_u32 s{REM}, %[nt], 1")                         # NT - 1 full iterations, then the tail
 # ---- the loop: four copies (stage constants), S buffers alternate ----
 slow = []
 for c in range(4):
@@ -674,7 +662,6 @@ for c, Y, items in slow:
     emit(f"s_branch {label(f'copy{(c + 1) & 3}')}")
 # ---- epilogue ----
 put_label("epilogue")
-checkpoint(4)
 emit("s_nop 15")
 emit("s_nop 15")
 # t0 = li, t1 = hi, t2/t3 = row of half 0 / 1 (unclamped)
@@ -729,6 +716,78 @@ for h in range(2):
             emit("s_nop 0")
     emit(f"s_mov_b64 exec, {sr(EXS)}")
 emit(f"s_branch {label('end')}")
+# ---- out-of-line blocks: a tile iterator reached the end of its segment ----
+for site, back, kind in list(_sites):
+    emit(site + ":")
+    call("kseg_next" if kind == "k" else "vseg_next")
+    ptr, step = (KP, KSTEP) if kind == "k" else (VP, VSTEP)
+    emit(f"s_sub_u32 s{ptr}, s{ptr}, s{step}")               # (the unconditional step behind `back` puts it back)
+    emit(f"s_subb_u32 s{ptr + 1}, s{ptr + 1}, 0")
+    emit(f"s_branch {back}")
+# ---- ragged tile (subroutine, return address in RET2): a whole tile in plain order from the slot KA[] / VA[] point at, RAG valid keys ----
+put_label("rag_tile")
+plain_qk(1)
+emit("s_nop 15")
+emit("s_nop 15")
+emit(f"v_bfe_u32 v{t[0]}, %[tid], 5, 1")
+emit(f"v_lshlrev_b32 v{t[0]}, 3, v{t[0]}")                 # 8 * hi
+emit(f"v_mov_b32 v{t[1]}, 0xff800000")
+for sub in range(2):
+    for r in range(16):
+        kb_ = sub * 32 + 16 * (r >> 3) + (r & 7)            # key of this register for hi = 0
+        emit(f"s_sub_i32 s{ST[0]}, s{RAG}, {kb_}")
+        emit(f"v_cmp_gt_i32 vcc, s{ST[0]}, v{t[0]}")        # key < rag
+        for h in range(2):
+            emit(f"v_cndmask_b32 v{S(1, h, sub, r)}, v{t[1]}, v{S(1, h, sub, r)}, vcc")
+for s_ in max_list(1):
+    emit(s_)
+emit(f"s_cbranch_vccz {label('ragnofix')}")
+call_fix(1)
+put_label("ragnofix")
+for s_ in exp_units(1, 0, 32):
+    emit(s_)
+emit("s_nop 1")
+plain_pv()
+emit(f"s_setpc_b64 {sr(RET2)}")
+# ---- segment routines (return address in RET): move a tile iterator to the next K / V^T segment that has a full tile, or park it ----
+for kind in ("k", "v"):
+    seg, cnt, ptr, step = (KSEG, KCNT, KP, KSTEP) if kind == "k" else (VSEG, VCNT, VP, VSTEP)
+    o_ptr, o_bs = (KA_K, KA_KBS) if kind == "k" else (KA_VT, KA_VTBS)
+    T_ = ST[2:14]
+    put_label(f"{kind}seg_next")
+    emit(f"s_add_u32 s{seg}, s{seg}, 1")
+    emit(f"s_cmp_ge_u32 s{seg}, s{NSEG}")
+    emit(f"s_cbranch_scc1 {label(kind + 'park')}")
+    emit(f"s_lshl_b32 s{T_[0]}, s{seg}, 3")
+    emit(f"s_add_u32 s{T_[0]}, s{KARG}, s{T_[0]}")
+    emit(f"s_addc_u32 s{T_[1]}, s{KARG + 1}, 0")
+    emit(f"s_load_dwordx2 {sr(T_[2])}, {sr(T_[0])}, 0x{o_ptr:x}")
+    emit(f"s_load_dwordx2 {sr(T_[4])}, {sr(T_[0])}, 0x{o_bs:x}")
+    emit(f"s_load_dwordx2 {sr(T_[6])}, {sr(T_[0])}, 0x{KA_LEN:x}")
+    emit("s_waitcnt lgkmcnt(0)")                             # (drains the fragment reads in flight as well: harmless, the counted waits stay valid)
+    emit(f"s_ashr_i32 s{cnt}, s{T_[6]}, 6")                  # full tiles of the segment (lengths below 2^31)
+    emit(f"s_cmp_le_i32 s{cnt}, 0")
+    emit(f"s_cbranch_scc1 {label(kind + 'seg_next')}")
+    # byte offset of (batch b, head h) inside the segment: K: (b * k_bs + h * 128) * 2;  V^T: (b * vt_bs) * 2 + h * 128 * vls_bytes
+    emit(f"s_mul_hi_u32 s{T_[9]}, s{BIDX}, s{T_[4]}")
+    emit(f"s_mul_i32 s{T_[8]}, s{BIDX}, s{T_[4]}")
+    emit(f"s_lshl_b64 {sr(T_[8])}, {sr(T_[8])}, 1")
+    if kind == "k":
+        emit(f"s_lshl_b32 s{T_[10]}, s{HIDX}, 8")
+        emit(f"s_mov_b32 s{T_[11]}, 0")
+    else:
+        emit(f"s_lshl_b32 s{T_[10]}, s{HIDX}, 7")
+        emit(f"s_mul_hi_u32 s{T_[11]}, s{T_[10]}, s{VLS}")
+        emit(f"s_mul_i32 s{T_[10]}, s{T_[10]}, s{VLS}")
+    emit(f"s_add_u32 s{T_[8]}, s{T_[8]}, s{T_[10]}")
+    emit(f"s_addc_u32 s{T_[9]}, s{T_[9]}, s{T_[11]}")
+    emit(f"s_add_u32 s{ptr}, s{T_[2]}, s{T_[8]}")
+    emit(f"s_addc_u32 s{ptr + 1}, s{T_[3]}, s{T_[9]}")
+    emit(f"s_setpc_b64 {sr(RET)}")
+    put_label(kind + "park")                                 # no tile left: the requests that still follow re-fetch the last one
+    emit(f"s_mov_b32 s{cnt}, 0x7fffffff")
+    emit(f"s_mov_b32 s{step}, 0")
+    emit(f"s_setpc_b64 {sr(RET)}")
 # ---- fix-up subroutines (behind every call site): the reference maximum of some rows moves ----
 for Y in range(2):
     put_label(f"fix{Y}")

@@ -23,7 +23,7 @@ for line in open(os.path.join(src, "trace_bench.log")):
 
 def short(n):
     for k in ("gemm_bt256w_kernel", "gemm_bt256p_kernel", "gemm_bt256_kernel", "gemm_bt256pp_kernel", "gemm_packed_kernel", "gemm_bt_kernelIDF16b", "gemm_bt_kernelIfE",
-              "attn128p_kernel", "attn128_kernel<8>", "attn128_kernel<4>", "attn128_kernelILi8", "attn128_kernelILi4", "attn_kernelIDF16bLi128",
+              "attn128q_kernel", "attn128x_kernel", "attn128p_kernel", "attn128_kernel<8>", "attn128_kernel<4>", "attn128_kernelILi8", "attn128_kernelILi4", "attn_kernelIDF16bLi128",
               "ln_modulate_kernelIfDF16b", "rmsnorm_rope_kernelIDF16b", "conv_cl_kernel"):
         if k in n:
             return k
