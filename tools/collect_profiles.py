@@ -38,6 +38,10 @@ cp(f"{src}/bw_probe.log", "bw_probe.log")
 cp(f"{src}/ab_attn_bwd.log", "ab_attn_bwd_final.log")
 cp(f"{src}/vae_train_bench.json", "vae_train_bench.json")
 cp(f"{src}/bench_gn_planar.log", "bench_gn_planar.log")
+cp(f"{src}/ab_q64_bench.log", "ab_q64_bench.log")
+cp(f"{src}/q64_check_time.log", "q64_check_time.log")
+cp(f"{src}/q64_stamps.log", "q64_stamps.log")
+cp(f"{src}/launch_check_8.log", "launch_check_8.log")
 for f in glob.glob(f"{src}/vae_train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "vae_train_kernel_stats.csv")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):
