@@ -386,6 +386,9 @@ def standin_group(spw):
             buf = torch.empty((self.world_size,) + tuple(x.shape), device=x.device, dtype=x.dtype)
             buf.copy_(x.unsqueeze(0).expand_as(buf))     # every peer slot = a copy of the local shard (real values: power)
             return buf, None, x
+
+        def all_to_all(self, x):                          # Ulysses (M4D_SP_MODE=ulysses): chunk j would go to rank j — keep the local copy
+            return x.contiguous().clone()
     return _StandIn()
 
 

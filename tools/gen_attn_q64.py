@@ -34,6 +34,9 @@ ap.add_argument("--stamps", action="store_true", help="s_memtime stamps of wave 
 ap.add_argument("--wait1", action="store_true", help="one s_waitcnt lgkmcnt per fragment instead of one per TWO fragments (A/B: +0.8 % time)")
 ap.add_argument("--first-gap", type=int, default=1, help="phase B: no fillers behind its first N MFMAs (0: -0.8 % time, but the first row-max "
                 "instructions would read accumulators one MFMA behind their last write)")
+ap.add_argument("--dma-m0", action="store_true", help="A/B: one m0 write per DMA piece instead of one per K / V^T request of four pieces with the pieces' LDS steps in the "
+                "instruction offset (which moves the global address too: cancelled in the lane offsets); -0.6 % time for the default")
+ap.add_argument("--exp-alt", action="store_true", help="A/B: exp / add alternating instead of exp exp add add")
 ap.add_argument("-o", default="more4d_amd/csrc/attention_q64_gen.inc")
 args = ap.parse_args()
 
@@ -211,6 +214,11 @@ def exp_units(buf, u0, u1, cvt=True, lead_cvt=()):
     prev = None
     for u in range(u0, u1):
         h, c, j, b = unit_regs(buf, u)
+        if args.exp_alt and prev is not None:
+            tl = tail_of_unit(buf, prev, cvt)
+            ins += [f"v_exp_f32 v{b}, v{b}", tl[0], f"v_exp_f32 v{b + 1}, v{b + 1}"] + tl[1:]
+            prev = u
+            continue
         ins.append(f"v_exp_f32 v{b}, v{b}")
         ins.append(f"v_exp_f32 v{b + 1}, v{b + 1}")
         if prev is not None:
@@ -314,6 +322,14 @@ def phase_a(c, fillers):
     return mf, pre, post, fillers
 
 
+def dma_piece(kind, lds_off, p):
+    """piece p (1 KiB per wave) of a K / V^T tile request into LDS offset lds_off (+ the wave's 4 KiB)"""
+    reg, ptr = (DK[p], KP) if kind == "k" else (DV[p], VP)
+    if not args.dma_m0:      # (the lane offsets were reduced by p KiB in the prologue)
+        return ([f"s_add_u32 m0, s{WB}, 0x{lds_off:x}"] if p == 0 else []) + [f"global_load_lds_dwordx4 v{reg}, {sr(ptr)} offset:{p * 1024}"]
+    return [f"s_add_u32 m0, s{WB}, 0x{lds_off + p * 1024:x}", f"global_load_lds_dwordx4 v{reg}, {sr(ptr)}"]
+
+
 def phase_b(c, fillers, last_barrier=True):
     """O += V^T(i) P(i); reads V^T(i) fragments 8..15 (VA[2..3]) and K(i+2) fragments 0..7 (KA[0..3]); requests K(i+4), V^T(i+3)"""
     mf, pre, post = [], [], []
@@ -332,9 +348,9 @@ def phase_b(c, fillers, last_barrier=True):
     # DMA: K(i+4) -> K half of stage c, V^T(i+3) -> V half of stage (c+3)&3; one piece behind every second MFMA, then the pointers move on
     ks, vs = c * STAGE, ((c + 3) & 3) * STAGE + VOFF
     for p in range(4):
-        post[2 + 2 * p] += [f"s_add_u32 m0, s{WB}, 0x{ks + p * 1024:x}", f"global_load_lds_dwordx4 v{DK[p]}, {sr(KP)}"]
+        post[2 + 2 * p] += dma_piece("k", ks, p)
     for p in range(4):
-        post[10 + 2 * p] += [f"s_add_u32 m0, s{WB}, 0x{vs + p * 1024:x}", f"global_load_lds_dwordx4 v{DV[p]}, {sr(VP)}"]
+        post[10 + 2 * p] += dma_piece("v", vs, p)
     post[18].append(adv_test("k"))
     post[20] += adv_step("k")
     post[22].append(adv_test("v"))
@@ -488,6 +504,8 @@ for p in range(4):
     emit(f"v_add_u32 v{t[6]}, s{ST[0]}, v{t[6]}")          # row
     emit(f"v_mul_lo_u32 v{t[6]}, v{t[6]}, s{KLS}")
     emit(f"v_add_u32 v{DK[p]}, v{t[6]}, v{t[7]}")
+    if not args.dma_m0 and p:
+        emit(f"v_subrev_u32 v{DK[p]}, {p * 1024}, v{DK[p]}")
 # V^T piece p of wave w: row = 32w + 8p + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
 emit(f"v_lshrrev_b32 v{t[4]}, 3, v{t[0]}")
 emit(f"v_and_b32 v{t[5]}, 7, v{t[0]}")
@@ -500,6 +518,8 @@ for p in range(4):
     emit(f"v_lshlrev_b32 v{t[7]}, 4, v{t[7]}")
     emit(f"v_mul_lo_u32 v{t[6]}, v{t[6]}, s{VLS}")
     emit(f"v_add_u32 v{DV[p]}, v{t[6]}, v{t[7]}")
+    if not args.dma_m0 and p:
+        emit(f"v_subrev_u32 v{DV[p]}, {p * 1024}, v{DV[p]}")
 # ---- Q rows: row = 64 w + 32 h + li (clamped to nrows - 1), 16 loads of 16 bytes per lane into v32..v95 ----
 emit(f"s_sub_u32 s{ST[1]}, s{NROWS}, 1")
 for h in range(2):
@@ -526,12 +546,7 @@ def dma_prologue():
     call("vseg_next")
     for kind, tile in (("k", 0), ("v", 0), ("k", 1), ("k", 2), ("v", 1), ("k", 3), ("v", 2)):
         for p in range(4):
-            if kind == "k":
-                emit(f"s_add_u32 m0, s{WB}, 0x{(tile & 3) * STAGE + p * 1024:x}")
-                emit(f"global_load_lds_dwordx4 v{DK[p]}, {sr(KP)}")
-            else:
-                emit(f"s_add_u32 m0, s{WB}, 0x{(tile & 3) * STAGE + VOFF + p * 1024:x}")
-                emit(f"global_load_lds_dwordx4 v{DV[p]}, {sr(VP)}")
+            emit(dma_piece(kind, (tile & 3) * STAGE + (0 if kind == "k" else VOFF), p))
         emit(adv_test(kind))
         emit(adv_step(kind))
 
