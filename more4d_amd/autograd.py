@@ -96,7 +96,8 @@ class ActFn(Function):
 
 
 class LayerNormFn(Function):
-    """ln_modulate on a float32 [B, n, C] input: affine (ln_w, ln_b [C]) or modulated (shift, scale [B, C])."""
+    """ln_modulate on a float32 [B, n, C] input: affine (ln_w, ln_b [C]) or modulated (shift, scale [B, C]; [B, n, C] = one modulation
+    vector per TOKEN: per-token timesteps, reference wan_transformer4d.py:713-715)."""
 
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, shift, scale, eps, out_dtype):
@@ -106,7 +107,9 @@ class LayerNormFn(Function):
         b32 = ln_b.detach().float().contiguous() if ln_b is not None else None
         sh = shift.detach().contiguous() if shift is not None else None
         sc = scale.detach().contiguous() if scale is not None else None
-        y = ops.ln_modulate(x, out_dtype, shift=sh, scale=sc, mod_stride=C, rows_per_sample=n, ln_w=w32, ln_b=b32, eps=eps)
+        per_token = sh is not None and sh.dim() == 3
+        y = ops.ln_modulate(x, out_dtype, shift=sh, scale=sc, mod_stride=C, rows_per_sample=1 if per_token else n, ln_w=w32, ln_b=b32,
+                            eps=eps)
         ctx.save_for_backward(x, w32, sc)
         ctx.meta = (eps, ln_w.dtype if ln_w is not None else None)
         return y
@@ -118,13 +121,16 @@ class LayerNormFn(Function):
         B, n, C = x.shape
         dy = dy.contiguous()
         dx = torch.zeros_like(x)
-        G = 1 if w32 is not None else B
+        per_token = sc is not None and sc.dim() == 3
+        G = 1 if w32 is not None else (B * n if per_token else B)
         d1 = torch.zeros((G, C), device=x.device, dtype=torch.float32)
         d2 = torch.zeros((G, C), device=x.device, dtype=torch.float32)
-        ops.ln_modulate_bwd(x, dy, dx, B=B, rows_per_sample=n, scale=sc, mod_stride=C, ln_w=w32, eps=eps, dshift=d1,
-                            dscale=d2, red_stride=0 if w32 is not None else C)
+        ops.ln_modulate_bwd(x, dy, dx, B=B * n if per_token else B, rows_per_sample=1 if per_token else n, scale=sc, mod_stride=C,
+                            ln_w=w32, eps=eps, dshift=d1, dscale=d2, red_stride=0 if w32 is not None else C)
         if w32 is not None:
             return dx, d2[0].to(wdt), d1[0].to(wdt), None, None, None, None
+        if per_token:
+            return dx, None, None, d1.view(B, n, C), d2.view(B, n, C), None, None
         return dx, None, None, d1, d2, None, None
 
 
@@ -251,8 +257,15 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     def zeros(*shape):
         return torch.zeros(shape, device=dev, dtype=torch.float32)
 
-    e = ops.add_bcast(e0, f32(blk.modulation))                      # [B,6,C]: shift1 scale1 gate1 shift2 scale2 gate2
-    de = zeros(B, 6, C)
+    # per-token timesteps (reference :655-657, `e.dim() > 3`): e0 [B, Lp, 6, C] — one modulation / gate vector per ROW.  The kernels take
+    # "rows per modulation vector" (rps) and the number of vectors (nG), so the same calls serve both forms; the gradients of the vectors
+    # come back per row (the reductions over a sample's rows degenerate) and are summed over ALL rows for the shared `modulation`
+    per_token = e0.dim() == 4
+    rps, nG = (1, R) if per_token else (Lp, B)
+    if per_token and guid is not None:
+        raise NotImplementedError("spatial guidance with per-token timesteps in training")
+    e = ops.add_bcast(e0, f32(blk.modulation)).view(nG, 6, C)      # shift1 scale1 gate1 shift2 scale2 gate2
+    de = zeros(nG, 6, C)
     g1, g2, gfeat2 = {}, {}, None
     if guid is not None and blk.spatial_guidance_self is not None:  # (SiLU'd features T [B, P, 768], period, length)
         gfeat, period, glen = guid
@@ -262,7 +275,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     dres2 = dres.view(R, C) if dres is not None else None
 
     # ================= recompute (reference :659-684) =================
-    xn1 = ops.ln_modulate(x0, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=Lp, eps=eps, **g1).view(R, C)
+    xn1 = ops.ln_modulate(x0, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=rps, eps=eps, **g1).view(R, C)
     qkv_pre = saved.get("qkv_pre")
     if qkv_pre is None:
         qkv_pre = torch.empty((R, 3 * C), device=dev, dtype=T)
@@ -290,7 +303,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     y1 = saved.get("y1")
     if y1 is None:
         y1 = ops.gemm_bt(o, sa.o.weight, sa.o.bias)
-    x1 = ops.resid_gate(x0, y1, gate=e[:, 2], gate_stride=st, rows_per_sample=Lp)
+    x1 = ops.resid_gate(x0, y1, gate=e[:, 2], gate_stride=st, rows_per_sample=rps)
     if blk.cross_attn_norm:
         xn3 = ops.ln_modulate(x1, T, ln_w=f32(blk.norm3.weight), ln_b=f32(blk.norm3.bias), eps=eps).view(R, C)
     else:
@@ -324,7 +337,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     if yc is None:
         yc = ops.gemm_bt(oc, ca.o.weight, ca.o.bias)
     x2 = ops.resid_gate(x1, yc)
-    xn2 = ops.ln_modulate(x2, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=Lp, eps=eps, **g2).view(R, C)
+    xn2 = ops.ln_modulate(x2, T, shift=e[:, 3], scale=e[:, 4], mod_stride=st, rows_per_sample=rps, eps=eps, **g2).view(R, C)
     pre = saved.get("pre")
     if pre is None:
         pre = ops.gemm_bt(xn2, blk.ffn[0].weight, blk.ffn[0].bias)
@@ -333,13 +346,13 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     if y2 is None:
         y2 = ops.gemm_bt(h, blk.ffn[2].weight, blk.ffn[2].bias)
     if forward_only:
-        x3 = ops.resid_gate(x2, y2, gate=e[:, 5], gate_stride=st, rows_per_sample=Lp)
+        x3 = ops.resid_gate(x2, y2, gate=e[:, 5], gate_stride=st, rows_per_sample=rps)
         return x3, dict(qkv_pre=qkv_pre, o=o, lse1=lse1, y1=y1, qc_pre=qc_pre, yc=yc, pre=pre, y2=y2)
 
     # ================= backward =================
     # ---- ffn: x3 = x2 + y2 * gate2
-    de[:, 5].copy_(ops.colsum(dres2, y2, rows_per_group=Lp))
-    dy2 = ops.scale_cast(dres2, T, gate=e[:, 5], gate_stride=st, rows_per_sample=Lp)
+    de[:, 5].copy_(ops.colsum(dres2, y2, rows_per_group=rps))
+    dy2 = ops.scale_cast(dres2, T, gate=e[:, 5], gate_stride=st, rows_per_sample=rps)
     del y2
     dh, G["ffn.2.weight"], G["ffn.2.bias"] = linear_bwd(h, blk.ffn[2].weight, dy2)
     del h, dy2
@@ -351,7 +364,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     if g2:
         dgf = _guidance_site_bwd(x2, dxn2, e[:, 3], e[:, 4], st, Lp, eps, g2, blk.spatial_guidance_ffn, gfeat2, G,
                                  "spatial_guidance_ffn")
-    ops.ln_modulate_bwd(x2, dxn2, dres, B=B, rows_per_sample=Lp, scale=e[:, 4], mod_stride=st, eps=eps,
+    ops.ln_modulate_bwd(x2, dxn2, dres, B=nG, rows_per_sample=rps, scale=e[:, 4], mod_stride=st, eps=eps,
                         dshift=de[:, 3], dscale=de[:, 4], red_stride=st)
     # ---- cross attention: x2 = x1 + yc
     dyc = ops.scale_cast(dres2, T)
@@ -384,8 +397,8 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     else:
         ops.resid_gate(dres, dxn3, out=dres)
     # ---- self attention: x1 = x0 + y1 * gate1
-    de[:, 2].copy_(ops.colsum(dres2, y1, rows_per_group=Lp))
-    dy1 = ops.scale_cast(dres2, T, gate=e[:, 2], gate_stride=st, rows_per_sample=Lp)
+    de[:, 2].copy_(ops.colsum(dres2, y1, rows_per_group=rps))
+    dy1 = ops.scale_cast(dres2, T, gate=e[:, 2], gate_stride=st, rows_per_sample=rps)
     do, G["self_attn.o.weight"], G["self_attn.o.bias"] = linear_bwd(o, sa.o.weight, dy1)
     dqkv = torch.empty((R, 3 * C), device=dev, dtype=T)
     ops.attention_bwd(q, k, v, o, do, lse1, B=B, Lq=Lp, Lk=c.key_len, Lk_rows=Lp, heads=n, head_dim=d,
@@ -411,9 +424,11 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     if g1:
         dgf = ops.add(dgf, _guidance_site_bwd(x0, dxn1, e[:, 0], e[:, 1], st, Lp, eps, g1, blk.spatial_guidance_self, gfeat2,
                                               G, "spatial_guidance_self"))
-    ops.ln_modulate_bwd(x0, dxn1, dres, B=B, rows_per_sample=Lp, scale=e[:, 1], mod_stride=st, eps=eps,
+    ops.ln_modulate_bwd(x0, dxn1, dres, B=nG, rows_per_sample=rps, scale=e[:, 1], mod_stride=st, eps=eps,
                         dshift=de[:, 0], dscale=de[:, 1], red_stride=st)
-    G["modulation"] = ops.colsum(de.view(B, 6 * C))[0].view(1, 6, C)
+    G["modulation"] = ops.colsum(de.view(nG, 6 * C))[0].view(1, 6, C)
+    if per_token:
+        de = de.view(e0.shape)
     if guid is not None:
         return de, dctx.get("txt"), dctx.get("img"), G, (dgf.view(guid[0].shape) if dgf is not None else None)
     return de, dctx.get("txt"), dctx.get("img"), G

@@ -937,8 +937,8 @@ class WanTransformer4DModel(nn.Module):
             raise NotImplementedError("TeaCache is an inference-time approximation")
         if isinstance(context, ContextCache):
             raise ValueError("training needs the raw text embeddings (the context projections are trainable)")
-        if t.dim() != 1:
-            raise NotImplementedError("per-token timesteps (ti2v) are not part of the 4D-STraG path")
+        if t.dim() != 1 and self.use_omnimae_guidance and first_frame_features is not None:
+            raise NotImplementedError("spatial guidance with per-token timesteps in training")
         T, dev, C = self.dtype, self.device, self.dim
         f32 = torch.float32
         B = x.shape[0]
@@ -967,9 +967,21 @@ class WanTransformer4DModel(nn.Module):
         xres = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
         # ---- conditioning (float32 like the inference path, :1160-1171)
         te0, te2, tp = self.time_embedding[0], self.time_embedding[2], self.time_projection[1]
-        s = sinusoidal_embedding_1d(self.freq_dim, t.to(dev)).float().contiguous()
+        per_token = t.dim() != 1
+        if per_token and (t.shape[0] != B or t.shape[1] != seq_len):
+            # (:1161-1167) t [B, seq_len], seq_len AFTER the reference row was added (:1088)
+            raise ValueError(f"per-token t must be [B, seq_len] = [{B}, {seq_len}], got {tuple(t.shape)}")
+        s = sinusoidal_embedding_1d(self.freq_dim, t.reshape(-1).to(dev)).float().contiguous()
         e = LinearFn.apply(LinearFn.apply(s, te0.weight, te0.bias, ACT_SILU, f32, True), te2.weight, te2.bias, 0, f32, True)
-        e0 = LinearFn.apply(ActFn.apply(e, ACT_SILU, f32), tp.weight, tp.bias, 0, f32, True).view(B, 6, C)
+        e0 = LinearFn.apply(ActFn.apply(e, ACT_SILU, f32), tp.weight, tp.bias, 0, f32, True)
+        if per_token:      # e [B, Lp, C], e0 [B, Lp, 6, C]: one vector per token, rows beyond seq_len exist only as padding (zero modulation)
+            e, e0 = e.view(B, seq_len, C), e0.view(B, seq_len, 6, C)
+            if Lp > seq_len:
+                e = torch.cat([e, e.new_zeros(B, Lp - seq_len, C)], dim=1)
+                e0 = torch.cat([e0, e0.new_zeros(B, Lp - seq_len, 6, C)], dim=1)
+            e0 = e0.contiguous()
+        else:
+            e0 = e0.view(B, 6, C)
         Tp = _round8(self.text_len)
         txt = torch.zeros((B, Tp, self.text_dim), device=dev, dtype=T)
         for i, u in enumerate(context):
@@ -1023,8 +1035,12 @@ class WanTransformer4DModel(nn.Module):
             xres = BlockFn.apply(xres, e0, ctx_txt, ctx_img, gfeat, blk, c, self.text_len, img_len, store, gmeta,
                                  *blk.parameters())
         # ---- head (:708-721) + unpatchify (:1343-1366)
-        m = e.view(B, 1, C) + self.head.modulation.float()
-        xn = LayerNormFn.apply(xres, None, None, m[:, 0], m[:, 1], self.head.eps, T)
+        if per_token:      # (:713-715) [B, Lp, 2, C]
+            m = e.unsqueeze(2) + self.head.modulation.float().unsqueeze(0)
+            xn = LayerNormFn.apply(xres, None, None, m[:, :, 0], m[:, :, 1], self.head.eps, T)
+        else:
+            m = e.view(B, 1, C) + self.head.modulation.float()
+            xn = LayerNormFn.apply(xres, None, None, m[:, 0], m[:, 1], self.head.eps, T)
         out = LinearFn.apply(xn, self.head.head.weight, self.head.head.bias, 0, T, True)
         u = out[:, n_ref:n_ref + Lv].reshape(B, f, h, w, pt, ph, pw, self.out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
         return u.reshape(B, self.out_dim, f * pt, h * ph, w * pw).to(T)

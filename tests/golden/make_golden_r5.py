@@ -1,6 +1,6 @@
 """Round-5 fixtures, produced by RUNNING THE REFERENCE in the build container (needs /root/reference):
 
-    python tests/golden/make_golden_r5.py [stack40|noqknorm_grads|all]
+    python tests/golden/make_golden_r5.py [stack40|noqknorm_grads|pertoken_grads|all]
 
 * dit_stack40_14b.npz + bf16_calibration.json["stack40_14b"] — FORTY stacked 14B-width WanAttentionBlocks (the depth of the
   Wan2.1-14B DiT, wan_transformer4d.py:633-688 forty times, each layer with its own weights) at L = 2080 tokens: the reference's fp32
@@ -11,6 +11,8 @@
   Weights: tests/golden/weights.py:fill_hash (device-agnostic integer-hash recipe — the GPU test builds the same bits on the device).
 * dit_block_noqknorm_grads.npz — gradients of the qk_norm=False block of dit_block_noqknorm.npz (same weights / inputs) for a seeded
   cotangent, by torch autograd through the reference block (wan_transformer4d.py:431-432, 633-688): every parameter + dL/dx.
+* dit_tiny_pertoken_grads.npz — training with PER-TOKEN timesteps (t [B, seq_len], wan_transformer4d.py:655-657, 713-715, 1161-1167): the
+  reference's loss.backward() on the dit_tiny.npz inputs with the t_tok of dit_tiny_pertoken.npz; norms + sampled values of every gradient.
 Data only; no reference source is stored."""
 import json
 import os
@@ -90,6 +92,30 @@ def make_noqknorm_grads(ref):
     npz_save("dit_block_noqknorm_grads.npz", **arrs)
 
 
+def make_pertoken_grads(ref):
+    from make_golden import TINY_DIT, grad_sample, load_recipe
+    z = {k: torch.from_numpy(v) for k, v in dict(np.load(os.path.join(HERE, "dit_tiny.npz"))).items()}
+    pz = np.load(os.path.join(HERE, "dit_tiny_pertoken.npz"))
+    t_tok = torch.from_numpy(pz["t_tok"])
+    with torch.enable_grad():
+        m = ref.dit.WanTransformer4DModel(**TINY_DIT).train()
+        load_recipe(m, None, seed=1234)
+        target = torch.randn(z["out_ref"].shape, generator=torch.Generator().manual_seed(23))
+        pred = m(x=z["x"], t=t_tok, context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"], y=z["y"],
+                 full_ref=z["full_ref"])
+        diff = pred.float() - target
+        loss = (torch.nn.functional.mse_loss(pred.float(), target, reduction="none") * (diff.abs() <= 50).float()).mean()
+        loss.backward()
+    assert float((pred.detach() - torch.from_numpy(pz["out_ref"])).abs().max()) < 1e-5
+    out = {"target": target, "loss": loss.detach(), "pred": pred.detach()}
+    for name, p_ in m.named_parameters():
+        if p_.grad is None:
+            continue
+        out["norm/" + name] = p_.grad.norm()
+        out["grad/" + name] = grad_sample(p_.grad)
+    npz_save("dit_tiny_pertoken_grads.npz", **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref = _ref_import.load_reference()
@@ -97,3 +123,5 @@ if __name__ == "__main__":
         make_stack40(ref)
     if what in ("noqknorm_grads", "all"):
         make_noqknorm_grads(ref)
+    if what in ("pertoken_grads", "all"):
+        make_pertoken_grads(ref)

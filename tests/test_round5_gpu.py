@@ -255,3 +255,27 @@ def test_attention_q64_kernel_segments(lens, lp):
     assert rel_err(out.float(), ref) < 6e-3
     assert float((lse - torch.logsumexp(s, -1) * 1.4426950408889634).abs().max()) < 1e-3
     assert torch.equal(out, ops.attention(qs, segs, B=B, Lq=Lq, heads=n, head_dim=D, scale=0.6931471805599453))
+
+
+def test_tiny_dit_per_token_timestep_gradients_fp32():
+    """Training with PER-TOKEN timesteps (VERDICT r4 missing #2; reference wan_transformer4d.py:655-657, 713-715, 1161-1167: t [B, seq_len]
+    -> one modulation / gate vector per token in every block and in the head): loss.backward() through the HIP kernels == the reference's
+    gradients for every parameter (1e-3), with stored activations and with plain per-block recompute."""
+    from test_train_gpu import TOL, check_grads, same_grads, tiny_model
+    from util import custom_mse_loss
+    z, pz, zg = load_npz("dit_tiny.npz"), load_npz("dit_tiny_pertoken.npz"), load_npz("dit_tiny_pertoken_grads.npz")
+    m = tiny_model(torch.float32)
+    kw = dict(x=z["x"].to(DEV), t=pz["t_tok"].to(DEV), context=[z["ctx0"].to(DEV), z["ctx1"].to(DEV)], seq_len=int(z["seq_len_pad"]),
+              clip_fea=z["clip"].to(DEV), y=z["y"].to(DEV), full_ref=z["full_ref"].to(DEV))
+    pred = m(**kw)
+    assert rel_err(pred.detach().cpu(), zg["pred"]) < TOL
+    loss = custom_mse_loss(pred, zg["target"].to(DEV))
+    assert abs(float(loss.detach()) - float(zg["loss"])) < 1e-4 * float(zg["loss"])
+    loss.backward()
+    print("worst gradient error", check_grads({n: p.grad for n, p in m.named_parameters()}, zg, TOL))
+    ref_grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    m.activation_budget_gb = 0
+    custom_mse_loss(m(**kw), zg["target"].to(DEV)).backward()
+    assert m.last_stored_blocks == 0
+    same_grads({n: p.grad for n, p in m.named_parameters()}, ref_grads)
