@@ -273,8 +273,13 @@ class _TrainRunner(_Runner):
                 self._conv_grads(conv, src.data, xps, t, hl, wl, cip, dy, k, (pad, pad), wgt, cop)
                 dsrc = conv_dgrad(dy, wgt, cop, cip, k, t, hl, wl)
             else:
-                if conv.weight.requires_grad:
-                    raise NotImplementedError("weight gradient of the stride-2 encoder convs (the encoder is frozen in train_vae.py:355)")
+                if conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad):
+                    # ZeroPad2d((0, 1, 0, 1)) + Conv2d(3, stride 2) (wan_vae.py:96-100): y[i, j] = z[2i + 1, 2j + 1] of the SAME-padded
+                    # stride-1 conv z of the unpadded input, so its weight gradient is the stride-1 weight gradient against dy scattered
+                    # onto the odd positions of a zero map (train_vae.py:355 freezes the encoder; this is for callers that do not)
+                    dz = torch.zeros((t, hl, wl, cop), device=dy.device, dtype=dy.dtype)
+                    dz[:, 1::2, 1::2] = dy.view(t, ho, wo, cop)
+                    self._conv_grads(conv, src.data, xps, t, hl, wl, cip, dz.view(t * hl * wl, cop), k, (1, 1), wgt, cop)
                 dsrc = conv_dgrad(dy, wgt, cop, cip, k, t, hl, wl, stride=(1, 2, 2))
             if ups:
                 _acc(x, ops.upsample2x_cl_bwd(dsrc, x.t, x.h, x.w, x.c, tsplit=tsplit))
@@ -353,15 +358,22 @@ class _TrainRunner(_Runner):
             st = self.stage(key + ".time_conv", 1, x.t, ho, wo, cop)
             mid = self.conv_plain(x, conv, stride_hw=2, out=st.chunk(x.t))
             to = x.t // 2
-            y = ops.conv_cl(st.window(x.t), wgt, b, Tin=1 + x.t, Hin=ho, Win=wo, Cin=cop, k=(3, 1, 1), stride=(2, 1, 1), out_thw=(to, ho, wo))
+            win = st.window(x.t)
+            y = ops.conv_cl(win, wgt, b, Tin=1 + x.t, Hin=ho, Win=wo, Cin=cop, k=(3, 1, 1), stride=(2, 1, 1), out_thw=(to, ho, wo))
             ya = _Act(y, to, ho, wo, cop)
 
             def bwd():
                 if ya.g is None:
                     return
-                if rs.time_conv.weight.requires_grad:
-                    raise NotImplementedError("weight gradient of the strided encoder time_conv (the encoder is frozen in train_vae.py:355)")
-                _acc(mid, conv_dgrad(ya.g.contiguous(), wgt, cop, cop, (3, 1, 1), x.t, ho, wo, stride=(2, 1, 1)))
+                dyt = ya.g.contiguous()
+                tc = rs.time_conv
+                if tc.weight.requires_grad or (tc.bias is not None and tc.bias.requires_grad):
+                    # CausalConv3d((3, 1, 1), stride (2, 1, 1)) over [1 tail frame | t frames]: y[f] = z[2f] of the stride-1 valid conv z
+                    # (t - 1 output frames) -> stride-1 weight gradient against dy scattered onto the even frames of a zero map
+                    dz = torch.zeros((x.t - 1, ho * wo, cop), device=dyt.device, dtype=dyt.dtype)
+                    dz[0::2] = dyt.view(to, ho * wo, cop)
+                    self._conv_grads(tc, win, cop, 1 + x.t, ho, wo, cop, dz.view((x.t - 1) * ho * wo, cop), (3, 1, 1), (0, 0), wgt, cop)
+                _acc(mid, conv_dgrad(dyt, wgt, cop, cop, (3, 1, 1), x.t, ho, wo, stride=(2, 1, 1)))
             # the tape runs in reverse: time-conv gradient first, then (already recorded) the stride-2 conv's
             self.tape.append(bwd)
             return ya

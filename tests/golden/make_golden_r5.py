@@ -1,6 +1,6 @@
 """Round-5 fixtures, produced by RUNNING THE REFERENCE in the build container (needs /root/reference):
 
-    python tests/golden/make_golden_r5.py [stack40|noqknorm_grads|pertoken_grads|all]
+    python tests/golden/make_golden_r5.py [stack40|noqknorm_grads|pertoken_grads|vae_enc_grads|all]
 
 * dit_stack40_14b.npz + bf16_calibration.json["stack40_14b"] — FORTY stacked 14B-width WanAttentionBlocks (the depth of the
   Wan2.1-14B DiT, wan_transformer4d.py:633-688 forty times, each layer with its own weights) at L = 2080 tokens: the reference's fp32
@@ -13,6 +13,9 @@
   cotangent, by torch autograd through the reference block (wan_transformer4d.py:431-432, 633-688): every parameter + dL/dx.
 * dit_tiny_pertoken_grads.npz — training with PER-TOKEN timesteps (t [B, seq_len], wan_transformer4d.py:655-657, 713-715, 1161-1167): the
   reference's loss.backward() on the dit_tiny.npz inputs with the t_tok of dit_tiny_pertoken.npz; norms + sampled values of every gradient.
+* vae_train_enc.npz — the train_vae.py step of vae_train.npz case B (gradient through the encoder) with the ENCODER TRAINABLE as well
+  (train_vae.py:355 freezes it; a caller may not): gradients of every encoder parameter, incl. the stride-2 Resample convs and the strided
+  time_conv (wan_vae.py:96-100, 108-110).
 Data only; no reference source is stored."""
 import json
 import os
@@ -116,6 +119,43 @@ def make_pertoken_grads(ref):
     npz_save("dit_tiny_pertoken_grads.npz", **out)
 
 
+def make_vae_enc_grads(ref):
+    import types
+    from make_golden import _reference_functions, grad_sample
+    from weights import fill
+    tv = _reference_functions(os.path.join(_ref_import.REF_ROOT, "scripts/4D_STraG_training/train_vae.py"), ["compute_loss"])
+    args = types.SimpleNamespace(rec_loss="l1", kl_scale=1e-6)
+    z = np.load(os.path.join(HERE, "vae_train.npz"))
+    torch.set_grad_enabled(True)
+    try:
+        vae = ref.vae.AutoencoderKLWan()
+        vae.load_state_dict(fill({k: list(t.shape) for k, t in vae.state_dict().items()}, seed=2024))
+        ea, da = ref.traj.VAEEncoderadaptor(), ref.traj.VAEDecoderadaptor()
+        ea.load_state_dict(fill({k: list(t.shape) for k, t in ea.state_dict().items()}, seed=78))
+        da.load_state_dict(fill({k: list(t.shape) for k, t in da.state_dict().items()}, seed=77))
+        ea.requires_grad_(True).train()
+        da.requires_grad_(True).train()
+        vae.model.encoder.requires_grad_(True).train()
+        vae.model.decoder.requires_grad_(True).train()
+        targets = torch.from_numpy(z["targets"])
+        pseudo = ea(targets) * 2 - 1
+        posterior = vae.encode_memory_saver(pseudo).latent_dist
+        latents = posterior.sample(generator=torch.Generator().manual_seed(5))
+        rec2 = da(vae.decode_memory_saver(latents).sample)
+        loss, nll, kl = tv["compute_loss"](rec2, targets, posterior, args)
+        loss.backward()
+        assert abs(float(loss) - float(z["B/loss"])) < 1e-4 * float(z["B/loss"])
+        out = {"loss": loss.detach()}
+        for n, p_ in vae.model.encoder.named_parameters():
+            assert p_.grad is not None, n
+            out["grad/vae.model.encoder." + n] = grad_sample(p_.grad)
+            out["norm/vae.model.encoder." + n] = p_.grad.norm()
+        print("encoder parameters with gradients:", len(out) // 2)
+        npz_save("vae_train_enc.npz", **out)
+    finally:
+        torch.set_grad_enabled(False)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref = _ref_import.load_reference()
@@ -125,3 +165,5 @@ if __name__ == "__main__":
         make_noqknorm_grads(ref)
     if what in ("pertoken_grads", "all"):
         make_pertoken_grads(ref)
+    if what in ("vae_enc_grads", "all"):
+        make_vae_enc_grads(ref)

@@ -236,3 +236,35 @@ def test_train_vae_optimizer_step_moves_parameters():
         opt.zero_grad()
         losses.append(float(loss.detach()))
     assert losses[2] < losses[0], losses
+
+
+def test_train_vae_step_with_trainable_encoder_fp32_vs_reference():
+    """The same step with the ENCODER trainable (train_vae.py:355 freezes it; round-4 review "missing" #4): gradients of every encoder
+    parameter against the reference's — including the Resample layers' ZeroPad2d + stride-2 Conv2d and the strided (3, 1, 1) time
+    conv (wan_vae.py:96-110), whose weight gradients are the stride-1 weight gradients against dy scattered onto a zero map."""
+    z, ze = load_npz("vae_train.npz"), load_npz("vae_train_enc.npz")
+    vae, ea, da = _models(torch.float32)
+    vae.model.encoder.requires_grad_(True)
+    targets = z["targets"].to(DEV)
+    pseudo = ea(targets) * 2 - 1
+    posterior = vae.encode_memory_saver(pseudo).latent_dist
+    latents = posterior.mean + posterior.std * z["B/eps"].to(DEV)
+    rec2 = da(vae.decode_memory_saver(latents).sample)
+    rec_loss = (rec2.float() - targets.float()).abs()
+    loss = rec_loss.sum() / rec_loss.shape[0] + 1e-6 * posterior.kl().sum() / posterior.kl().shape[0]
+    assert abs(float(loss.detach()) - float(ze["loss"])) < 1e-3 * float(ze["loss"])
+    loss.backward()
+    names = [k[5:] for k in ze if k.startswith("grad/")]
+    assert len(names) > 60 and any("time_conv" in n for n in names) and any("resample.1" in n for n in names)
+    gmax = max(float(ze["grad/" + n].abs().max()) for n in names)
+    named = {"vae." + n: p for n, p in vae.named_parameters()}
+    worst = ("", 0.0)
+    for n in names:
+        g = named[n].grad
+        assert g is not None, n
+        ref = ze["grad/" + n]
+        e = float((grad_sample(g.float().cpu()).double() - ref.double()).abs().max() / max(float(ref.abs().max()), 1e-3 * gmax))
+        ne = abs(float(g.float().norm()) - float(ze["norm/" + n])) / max(float(ze["norm/" + n]), 1e-3 * gmax)
+        worst = max(worst, (n, max(e, ne)), key=lambda u: u[1])
+        assert e < 1e-3 and ne < 1e-3, (n, e, ne)
+    print("worst encoder gradient error vs the reference", worst)
