@@ -37,6 +37,8 @@ ap.add_argument("--first-gap", type=int, default=1, help="phase B: no fillers be
 ap.add_argument("--dma-m0", action="store_true", help="A/B: one m0 write per DMA piece instead of one per K / V^T request of four pieces with the pieces' LDS steps in the "
                 "instruction offset (which moves the global address too: cancelled in the lane offsets); -0.6 % time for the default")
 ap.add_argument("--exp-alt", action="store_true", help="A/B: exp / add alternating instead of exp exp add add")
+ap.add_argument("--abl", default="", help="timing ablations for the stamps build (results WRONG): letters e = no exp / add / pack fillers, m = no row-max list, "
+                "d = no DMA requests, r = no fragment reads, w = no lgkm waits, a = no address updates, b = no barrier / vmcnt")
 ap.add_argument("-o", default="more4d_amd/csrc/attention_q64_gen.inc")
 args = ap.parse_args()
 
@@ -245,7 +247,29 @@ class Cont:
         self.items = None
 
 
+def _abl_keep(item):
+    if callable(item):
+        return "d" not in args.abl
+    t_ = item.split()[0]
+    if t_ == "ds_read_b128":
+        return "r" not in args.abl
+    if t_ == "s_waitcnt":
+        return ("b" not in args.abl) if "vmcnt" in item else ("w" not in args.abl)
+    if t_ == "s_barrier":
+        return "b" not in args.abl
+    if t_ in ("global_load_lds_dwordx4",) or (t_ == "s_add_u32" and " m0," in item):
+        return "d" not in args.abl
+    if t_ == "v_add_u32":
+        return "a" not in args.abl
+    if t_ in ("s_add_u32", "s_addc_u32") and "d" in args.abl:
+        return False
+    return True
+
+
 def emit_stream(mfmas, pre, post, fillers, cont=None, branch_label=None, first_gap=0):
+    if args.abl:
+        pre = [[x for x in l if _abl_keep(x)] for l in pre]
+        post = [[x for x in l if _abl_keep(x)] for l in post]
     """mfmas[k]; pre[k] = instructions right in front of MFMA k; post[k] = pinned instructions behind it; fillers = ordered list
     placed into what the cap leaves of every gap.  The item "BRANCH" in the fillers becomes s_cbranch_vccnz branch_label and records
     the remainder of the skeleton in cont.items."""
@@ -278,8 +302,11 @@ def emit_stream(mfmas, pre, post, fillers, cont=None, branch_label=None, first_g
         room = args.cap - used if k >= first_gap else 0
         if k == n - 1:
             room = len(fl)          # whatever is left goes behind the last MFMA
+        gap = []
         while room > 0 and fl:
-            f = fl.pop(0)
+            gap.append(fl.pop(0))
+            room -= 1
+        for f in gap:
             if f == "BRANCH":
                 emit(f"s_cbranch_vccnz {branch_label}")
                 cont.items = []
@@ -287,7 +314,6 @@ def emit_stream(mfmas, pre, post, fillers, cont=None, branch_label=None, first_g
                     cont.items += list(pre[kk]) + [mfmas[kk]] + list(post[kk])
             else:
                 emit(f)
-            room -= 1
     assert not fl
 
 
@@ -645,18 +671,19 @@ for c in range(4):
     if args.stamps:
         emit(f"s_add_u32 s{STMP}, s{STMP}, 1")
     stamp(0)
-    fa = exp_units(X, args.eb, 32, lead_cvt=range(args.eb))
+    fa = [] if "e" in args.abl else exp_units(X, args.eb, 32, lead_cvt=range(args.eb))
     emit_stream(*phase_a(c, fa))
     stamp(1)
     cont = Cont()
-    fb = max_list(Y) + ["BRANCH"] + exp_units(Y, 0, args.eb, cvt=False)
+    fb = ([] if "m" in args.abl else max_list(Y) + ["BRANCH"]) + ([] if "e" in args.abl else exp_units(Y, 0, args.eb, cvt=False))
     # the first fillers read S'(Y), whose last MFMA closed phase A: with first_gap = 1 and the row-max chains in the order the QK chains
     # finished, every accumulator is read at least two MFMAs (>= 64 cycles) behind its last write
     emit_stream(*phase_b(c, fb), cont=cont, branch_label=label(f"slow{c}"), first_gap=args.first_gap)
     stamp(2)
     if c == 3:
         emit(f"s_branch {label('copy0')}")
-    slow.append((c, Y, cont.items))
+    if cont.items is not None:      # (None: a timing-ablation build without the row-max check has no rare path)
+        slow.append((c, Y, cont.items))
 # ---- tails: the last tile (finish its softmax, PV), X = its S buffer ----
 for X in range(2):
     put_label(f"tail{X}")
