@@ -638,7 +638,7 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
         }
         else if (variant == 5) {
             kclass = M4D_KC_GEMM_WIDE;
-            // persistent form (M4D_GEMM_PERSIST, default on): bf16 epilogues, bias along n, K/64 even and >= 4, operands below 4 GiB,
+            // persistent form (M4D_GEMM_PERSIST, default on): bf16 epilogues, K/64 even and >= 4, operands below 4 GiB,
             // more tiles than CUs
             M4D_ENV_ONCE(persist, "M4D_GEMM_PERSIST", 1);
             const int64_t nkt = K / 64;
@@ -649,7 +649,8 @@ static int gemm_bt_impl(m4d_dtype dt, const void* A, int64_t lda, const void* W,
             const int ncu_p = ncu;
 #endif
             // (tool builds: the timing ablations / timeline stamps exist for the one-tile form only; 128.. = persistent epilogue debug bits)
-            const bool pers_ok = persist && (p.abl & 127) == 0 && (epilogue == M4D_EPI_STORE || epilogue == M4D_EPI_GELU_TANH) && !(bias && bias_on_m) &&
+            M4D_ENV_ONCE(persist_bm, "M4D_GEMM_PERSIST_BIAS_M", 1);      // A/B: 0 = the V^T projection (bias along m) on the one-tile form (rounds 3-4)
+            const bool pers_ok = persist && (p.abl & 127) == 0 && (epilogue == M4D_EPI_STORE || epilogue == M4D_EPI_GELU_TANH) && (!(bias && bias_on_m) || (persist_bm && M % 2 == 0)) &&
                                  nkt >= 4 && (nkt & 1) == 0 && M * lda * 2 < (1ll << 32) && N * ldw * 2 < (1ll << 32) && nwg > ncu_p;
             // XCD-wide tile rounds of the persistent kernel (M4D_GEMM_SYNC): 8 arrival counters in a library-owned buffer, zeroed in front
             // of every launch (two persistent GEMMs running at once on different streams would only lose the hint)

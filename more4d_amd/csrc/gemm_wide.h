@@ -183,7 +183,7 @@ M4D_DEV void epilogue_block64(const GemmArgs& p, char* wl, const f32x16& a00, co
 // tile's stores out of the tile loop and spills inside the K loop.
 template <typename T, int EPI>
 M4D_DEV void epilogue_block32(const GemmArgs& p, char* wl, const f32x16& a0, const f32x16& a1, int64_t m_base, int64_t n_base,
-                              int lane, unsigned voff, bool has_bias, const u32x4& bias8) {
+                              int lane, unsigned voff, bool has_bias, const u32x4& bias8, bool bias_m, const f32x4& bm) {
     static_assert(EPI == M4D_EPI_STORE || EPI == M4D_EPI_GELU_TANH, "bf16 outputs only");
     f32x4 b0, b1;
     {
@@ -210,7 +210,8 @@ M4D_DEV void epilogue_block32(const GemmArgs& p, char* wl, const f32x16& a0, con
         const int r = it * 8 + (lane >> 3);
         f32x4 v0 = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
         f32x4 v1 = *reinterpret_cast<const f32x4*>(wl + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
-        if (has_bias) { v0 += b0; v1 += b1; }
+        if (bias_m) { v0 += bm[it]; v1 += bm[it]; }      // bias along m (the V^T projection): this iteration's row, wave-uniform branch
+        else if (has_bias) { v0 += b0; v1 += b1; }
         if constexpr (EPI == M4D_EPI_GELU_TANH) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = gelu_tanh_f(v0[e]); v1[e] = gelu_tanh_f(v1[e]); }
@@ -238,7 +239,7 @@ M4D_DEV void epilogue_block32(const GemmArgs& p, char* wl, const f32x16& a0, con
 // fragments in registers when the epilogue of the current one ends — no prologue, no launch gap.  The epilogue runs beside the live
 // ring in 32 KiB of extra LDS (8 KiB per wave) and only ISSUES its stores (every tile issues all 32: edge tiles rewrite their
 // neighbour's identical values instead of masking).
-// Requirements (host-checked): K/64 even and >= 4, both operands below 4 GiB, bias along n, bf16 output.
+// Requirements (host-checked): K/64 even and >= 4, both operands below 4 GiB, bf16 output (bias along n or along m).
 template <int ABL, int EPI, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
     typedef bf16_t T;
@@ -421,7 +422,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
     // ALWAYS issued (without a bias: the first weights, unused) so that the waits do not depend on it.
     const unsigned lds_bias = __builtin_amdgcn_readfirstlane(lds_base + 2 * W_BUF + wave * 8192);
     auto request_bias = [&]() {
-        const char* src = uniform_ptr(bias ? (const char*)(bias + n0 + wn * 128) : (const char*)p.W);
+        // (bias along m: the 128 ROWS of the wave instead of its 128 columns)
+        const char* src = uniform_ptr(bias ? (const char*)(p.bias_on_m ? bias + m0 + wm * 128 : bias + n0 + wn * 128) : (const char*)p.W);
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_bias), "v"(lane * 4), "s"(src) : "memory", "m0");
     };
     if constexpr (PERSIST) request_bias();          // (first tile: older than every DMA of the prologue, retired by the first counted wait)
@@ -490,13 +492,20 @@ __global__ __launch_bounds__(256, 1) void gemm_bt256w_kernel(GemmArgs p) {
             u32x4 bz[2];            // this lane's 2 x 8 bias values, out of the block before the first accumulators go in
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh) bz[nh] = *reinterpret_cast<const u32x4*>(wl8 + (nh * 64 + (lane_e & 7) * 8) * 2);
+            const bool bias_m = __builtin_amdgcn_readfirstlane((int)(bias != nullptr && p.bias_on_m)) != 0;
+            f32x4 bmr[4];            // bias along m: the lane's row of every (block mi, iteration it): rows mi * 32 + it * 8 + (lane >> 3) of the wave's 128
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    bmr[mi][it] = bias_m ? (float)reinterpret_cast<const T*>(wl8)[mi * 32 + it * 8 + (lane_e >> 3)] : 0.f;
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                 {
                     epilogue_block32<T, EPI>(p, wl8, acc[nh * 2][mi], acc[nh * 2 + 1][mi], m0 + wm * 128 + mi * 32, n0 + wn * 128 + nh * 64,
-                                             lane_e, evoff, bias != nullptr, bz[nh]);
+                                             lane_e, evoff, bias != nullptr, bz[nh], bias_m, bmr[mi]);
                     __builtin_amdgcn_sched_barrier(0);       // one block at a time: interleaved blocks cost registers the K loop then spills
                 }
             bid += (int)gridDim.x;
