@@ -1,6 +1,6 @@
 """Round-5 fixtures, produced by RUNNING THE REFERENCE in the build container (needs /root/reference):
 
-    python tests/golden/make_golden_r5.py [stack40|noqknorm_grads|pertoken_grads|vae_enc_grads|all]
+    python tests/golden/make_golden_r5.py [stack40|noqknorm_grads|pertoken_grads|vae_enc_grads|block14_pertoken|all]
 
 * dit_stack40_14b.npz + bf16_calibration.json["stack40_14b"] — FORTY stacked 14B-width WanAttentionBlocks (the depth of the
   Wan2.1-14B DiT, wan_transformer4d.py:633-688 forty times, each layer with its own weights) at L = 2080 tokens: the reference's fp32
@@ -16,6 +16,8 @@
 * vae_train_enc.npz — the train_vae.py step of vae_train.npz case B (gradient through the encoder) with the ENCODER TRAINABLE as well
   (train_vae.py:355 freezes it; a caller may not): gradients of every encoder parameter, incl. the stride-2 Resample convs and the strided
   time_conv (wan_vae.py:96-100, 108-110).
+* dit_block_14b_pertoken.npz + bf16_calibration.json["block_14b_pertoken"] — one 14B-width block at L = 2080 with a PER-TOKEN modulation
+  e [1, L, 6, 5120] (:655-657): the production GEMM's gated-residual epilogue with one gate row per token.
 Data only; no reference source is stored."""
 import json
 import os
@@ -156,6 +158,27 @@ def make_vae_enc_grads(ref):
         torch.set_grad_enabled(False)
 
 
+def make_block14_pertoken(ref):
+    from weights import randn_named
+    L, grid, x, e0, ctx, freqs = _long_inputs(ref)
+    e_tok = randn_named("in.e0tok", (1, L, 6, 5120), 6, 0.2)
+    args = (torch.tensor([L]), torch.tensor([list(grid)]), freqs, ctx, None)
+    blk = _block14_hash(ref, 0)
+    y32 = blk(x, e_tok, *args, dtype=torch.float32, t=0, dino_features=None)
+    with ref_bf16(ref):
+        y16 = blk(x, e_tok, *args, dtype=torch.bfloat16, t=0, dino_features=None).float()
+    rows = torch.cat([torch.arange(0, L, 32), torch.tensor([L - 1])])
+    cal = _block_metrics(y16, y32, x)
+    print("block_14b_pertoken", cal)
+    npz_save("dit_block_14b_pertoken.npz", grid=np.array(grid), rows=rows, out_rows=y32[0, rows], row_norm=y32[0].norm(dim=-1),
+             delta_rows=(y32 - x)[0, rows], delta_norm=(y32 - x)[0].norm(dim=-1))
+    path = os.path.join(HERE, "bf16_calibration.json")
+    out = json.load(open(path))
+    out["block_14b_pertoken"] = cal
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref = _ref_import.load_reference()
@@ -167,3 +190,5 @@ if __name__ == "__main__":
         make_pertoken_grads(ref)
     if what in ("vae_enc_grads", "all"):
         make_vae_enc_grads(ref)
+    if what in ("block14_pertoken", "all"):
+        make_block14_pertoken(ref)

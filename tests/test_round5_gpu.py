@@ -279,3 +279,34 @@ def test_tiny_dit_per_token_timestep_gradients_fp32():
     custom_mse_loss(m(**kw), zg["target"].to(DEV)).backward()
     assert m.last_stored_blocks == 0
     same_grads({n: p.grad for n, p in m.named_parameters()}, ref_grads)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["fp32", "bf16"])
+def test_block_14b_per_token_modulation_vs_reference(dtype):
+    """Per-token modulation at PRODUCTION width (reference wan_transformer4d.py:655-657: e [B, L, 6, C]): one 14B-width
+    block at L = 2080 — LN-modulate with one shift / scale row per token, the production GEMM's gated-residual epilogue with one gate row
+    per token (rows_per_sample = 1) — against the reference's fp32 output; bf16 budget = 1.5 x the reference's own bf16-autocast error."""
+    from more4d_amd import ops
+    z = load_npz("dit_block_14b_pertoken.npz")
+    L, grid = 2080, (4, 20, 26)
+    x = randn_named("in.x", (1, L, 5120), 6)
+    e_tok = randn_named("in.e0tok", (1, L, 6, 5120), 6, 0.2)
+    ctx = randn_named("in.ctx", (1, 257 + 512, 5120), 6).to(DEV, dtype)
+    blk = _block_from_hash(dtype, 0)
+    ops.launch_counts(reset=True)
+    with torch.no_grad():
+        y = blk(x.to(DEV), e_tok.to(DEV), torch.tensor([L]), torch.tensor([list(grid)]), _freqs(), ctx, None, dtype=torch.float32, t=0)
+    counts = ops.launch_counts()
+    out = y.float().cpu()[0]
+    rows = z["rows"].long()
+    delta = out - x[0]
+    got = dict(delta_max=float((delta[rows] - z["delta_rows"]).abs().max() / z["delta_rows"].abs().max()),
+               delta_rms=rms_rel_err(delta[rows], z["delta_rows"]), delta_norm=rel_err(delta.norm(dim=-1), z["delta_norm"]),
+               out_rms=rms_rel_err(out[rows], z["out_rows"]))
+    print("block_14b_pertoken", dtype, got)
+    if dtype == torch.float32:
+        assert rel_err(out[rows], z["out_rows"]) < 1e-3 and rel_err(out.norm(dim=-1), z["row_norm"]) < 1e-3
+    else:
+        assert counts["gemm_wide"] + counts["gemm_phased"] >= 8, counts
+        for k, v in got.items():
+            assert v <= bf16_budget("block_14b_pertoken", k), (k, v, bf16_budget("block_14b_pertoken", k))
