@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(BwdArgs p) {
 #include "attention_bwd128.h"
 #include "attention_bwd_kvp.h"
 #include "attention_bwd_dqp.h"
+#include "attention_bwd64.h"
 
 // float workspace [B, rows, C] -> T output rows (b, l) at out + b*bs + l*ls (+= when accumulate)
 struct WsArgs { const float* ws; void* out; int64_t bs, ls, rows; int C, B, accumulate; };
@@ -361,9 +362,15 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         p.LX = p.LXs = a->Lq; p.LY = a->Lk; p.nx_tiles = (int)((a->Lq + 255) / 256); p.accumulate = a->accumulate_dq;
         // M4D_ATTN_BWD_DQ_PHASED=1 (default): attn_bwd_dqp_kernel (attention_bwd_dqp.h, the forward kernel's phased schedule); 0: lock-step
         M4D_ENV_ONCE(dq_phased, "M4D_ATTN_BWD_DQ_PHASED", 1);
-        if (dq_phased ? launch_bwd_dqp(p, st) : launch_bwd128<BWD_DQ>(p, st, 1)) { m4d_set_error("attention_bwd: cannot configure the dq kernel"); return -3; }
+        // M4D_ATTN_BWD64=1 (default): attn_bwd_dq64_kernel (attention_bwd64.h: one wave per SIMD, generated stream) where eligible; 0: A/B
+        M4D_ENV_ONCE(bwd64_on, "M4D_ATTN_BWD64", 1);
+        const bool dq64 = bwd64_on && bwd_dq64_ok(p);
+        if (dq64 ? launch_bwd_dq64(p, st) : dq_phased ? launch_bwd_dqp(p, st) : launch_bwd128<BWD_DQ>(p, st, 1)) {
+            m4d_set_error("attention_bwd: cannot configure the dq kernel");
+            return -3;
+        }
         M4D_CHECK_LAUNCH("attention_bwd(dq128)");
-        m4d_count_launch(M4D_KC_ATTN_BWD128);
+        m4d_count_launch(dq64 ? M4D_KC_ATTN_BWD64 : M4D_KC_ATTN_BWD128);
         // dK: X = (K, V), Y = (Q, dO)
         p.xa = a->k; p.xa_bs = a->k_bs; p.xa_ls = a->k_ls; p.xb = a->v; p.xb_bs = a->v_bs; p.xb_ls = a->v_ls;
         p.ya = a->q; p.ya_bs = a->q_bs; p.ya_ls = a->q_ls; p.yb = a->d_o; p.yb_bs = a->do_bs; p.yb_ls = a->do_ls;
