@@ -362,9 +362,9 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         p.LX = p.LXs = a->Lq; p.LY = a->Lk; p.nx_tiles = (int)((a->Lq + 255) / 256); p.accumulate = a->accumulate_dq;
         // M4D_ATTN_BWD_DQ_PHASED=1 (default): attn_bwd_dqp_kernel (attention_bwd_dqp.h, the forward kernel's phased schedule); 0: lock-step
         M4D_ENV_ONCE(dq_phased, "M4D_ATTN_BWD_DQ_PHASED", 1);
-        // M4D_ATTN_BWD64=1 (default): attn_bwd_dq64_kernel (attention_bwd64.h: one wave per SIMD, generated stream) where eligible; 0: A/B
-        M4D_ENV_ONCE(bwd64_on, "M4D_ATTN_BWD64", 1);
-        const bool dq64 = bwd64_on && bwd_dq64_ok(p);
+        // M4D_ATTN_BWD64 (default 3): attn_bwd_dq64_kernel / attn_bwd_kv64_kernel (attention_bwd64.h: one wave per SIMD, generated streams) where eligible; 0: A/B
+        M4D_ENV_ONCE(bwd64_on, "M4D_ATTN_BWD64", 3);      // bit 0: the dQ pass, bit 1: the dK / dV pass
+        const bool dq64 = (bwd64_on & 1) && bwd_dq64_ok(p);
         if (dq64 ? launch_bwd_dq64(p, st) : dq_phased ? launch_bwd_dqp(p, st) : launch_bwd128<BWD_DQ>(p, st, 1)) {
             m4d_set_error("attention_bwd: cannot configure the dq kernel");
             return -3;
@@ -395,6 +395,13 @@ extern "C" int m4d_attention_bwd(m4d_dtype dt, const m4d_attn_bwd_args* a, m4d_s
         M4D_ENV_ONCE(bwd_fused_short, "M4D_ATTN_BWD_FUSED_SHORT", 1);
         if (bwd_fused && (nsplit == 1 || (bwd_fused == 2 && bwd_fused_short))) {
             p.out_b = a->dv; p.ob_bs = a->dv_bs; p.ob_ls = a->dv_ls;
+            // M4D_ATTN_BWD64 & 2 (default on): attn_bwd_kv64_kernel (attention_bwd64.h: role-split, one wave per SIMD) where eligible
+            if ((bwd64_on & 2) && nsplit == 1 && bwd_kv64_ok(p)) {
+                if (launch_bwd_kv64(p, st)) { m4d_set_error("attention_bwd: cannot configure the dk/dv kernel"); return -3; }
+                M4D_CHECK_LAUNCH("attention_bwd(dkv64)");
+                m4d_count_launch(M4D_KC_ATTN_BWD64);
+                return 0;
+            }
             p.nx_tiles = (int)((a->Lk_rows + 127) / 128);
             if (bwd_fused == 2 ? launch_bwd_kvp(p, st) : launch_bwd_kv128(p, st)) { m4d_set_error("attention_bwd: cannot configure the fused dk/dv kernel"); return -3; }
             M4D_CHECK_LAUNCH("attention_bwd(dkv128 fused)");

@@ -40,7 +40,7 @@ def case(B, n, Lq, Lk, seed=0, spikes=False):
     lse = torch.empty(B, n, Lq, device=DEV)
     o = ops.attention(q, [ops.KV(k, vt, Lkp * C, C, Lkp, B * Lkp, Lk)], B=B, Lq=Lq, heads=n, head_dim=D, q_bs=Lq * C, q_ls=C,
                       lse=lse, scale=LN2).view(B * Lq, C)
-    dq, dk, dv = torch.full_like(q, float("nan")), torch.empty_like(k), torch.empty_like(v)
+    dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
     ops.launch_counts(reset=True)
     ops.attention_bwd(q, k, v, o, d_o, lse, B=B, Lq=Lq, Lk=Lk, Lk_rows=Lkp, heads=n, head_dim=D, dq=dq, dk=dk,
                       dv=dv, scale=LN2)
@@ -48,20 +48,28 @@ def case(B, n, Lq, Lk, seed=0, spikes=False):
     cnt = {a: b for a, b in ops.launch_counts().items() if b}
     # fp32 reference on the bf16-rounded operands
     qf = q.float().view(B, Lq, n, D).permute(0, 2, 1, 3).requires_grad_(True)
-    kf = k.float().view(B, Lkp, n, D)[:, :Lk].permute(0, 2, 1, 3)
-    vf = torch.nan_to_num(v.float()).view(B, Lkp, n, D)[:, :Lk].permute(0, 2, 1, 3)
+    kf = k.float().view(B, Lkp, n, D)[:, :Lk].permute(0, 2, 1, 3).requires_grad_(True)
+    vf = torch.nan_to_num(v.float()).view(B, Lkp, n, D)[:, :Lk].permute(0, 2, 1, 3).requires_grad_(True)
     s = (qf @ kf.transpose(-1, -2)) * LN2
     ref = torch.softmax(s, -1) @ vf
-    (gq,) = torch.autograd.grad(ref, (qf,), d_o.float().view(B, Lq, n, D).permute(0, 2, 1, 3))
+    gq, gk, gv = torch.autograd.grad(ref, (qf, kf, vf), d_o.float().view(B, Lq, n, D).permute(0, 2, 1, 3))
     gq = gq.permute(0, 2, 1, 3).reshape(B * Lq, C)
-    fin = bool(torch.isfinite(dq.float()).all())
-    e = float((dq.float() - gq).abs().max() / gq.abs().max())
-    digest = float(dq.float().abs().double().sum())
-    bad = not fin or not e < 1.2e-2
-    print(f"B={B} n={n} Lq={Lq} Lk={Lk} spikes={spikes}: dq err {e:.3e} finite {fin} digest {digest:.9e}", cnt, "FAIL" if bad else "ok", flush=True)
-    return bad, dq
+    gk, gv = (x.permute(0, 2, 1, 3).reshape(B, Lk, C) for x in (gk, gv))
+    bad = False
+    msg = []
+    for nm, got, want in (("dq", dq, gq), ("dk", dk.view(B, Lkp, C)[:, :Lk], gk), ("dv", dv.view(B, Lkp, C)[:, :Lk], gv)):
+        fin = bool(torch.isfinite(got.float()).all())
+        e = float((got.float() - want).abs().max() / want.abs().max())
+        bad |= not fin or not e < 1.5e-2
+        msg.append(f"{nm} err {e:.3e}{'' if fin else ' NONFINITE'}")
+    pad = float(dk.view(B, Lkp, C)[:, Lk:].float().abs().sum() + dv.view(B, Lkp, C)[:, Lk:].float().abs().sum()) if Lkp > Lk else 0.0
+    bad |= pad != 0.0
+    digest = " ".join(f"{float(x.float().abs().double().nan_to_num().sum()):.9e}" for x in (dq, dk.view(B, Lkp, C)[:, :Lk], dv.view(B, Lkp, C)[:, :Lk]))
+    print(f"B={B} n={n} Lq={Lq} Lk={Lk} spikes={spikes}: {', '.join(msg)} pad {pad} digest {digest}", cnt, "FAIL" if bad else "ok", flush=True)
+    return bad, torch.cat([dq.float().flatten(), dk.view(B, Lkp, C)[:, :Lk].float().flatten(), dv.view(B, Lkp, C)[:, :Lk].float().flatten()])
 
 
+MODES = ("0", "3")       # M4D_ATTN_BWD64: 0 = the two-waves-per-SIMD kernels, 1 = dq64 only, 3 = dq64 + kv64 (default)
 CASES = ((1, 8, 1280, 2048), (1, 8, 1100, 2080), (2, 3, 700, 2300, 1, True), (2, 4, 2080, 2080), (1, 16, 4100, 4099, 2, True),
          (1, 2, 256, 21840))
 
@@ -95,7 +103,7 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / reps * 1e3
             tf = 10 * B * L * L * C / ms / 1e9
-            print(f"mode {mode}: bwd {ms:.3f} ms  {tf:.0f} TF  frac {tf / 2500:.3f}  dq digest {float(dqkv[:, :C].float().abs().double().sum()):.9e}",
+            print(f"mode {mode}: bwd {ms:.3f} ms  {tf:.0f} TF  frac {tf / 2500:.3f}  dqkv digest {float(dqkv.float().abs().double().sum()):.9e}",
                   flush=True)
             return
         bad = False
@@ -108,10 +116,10 @@ def main():
         print("RESULT mode", mode, "FAIL" if bad else "PASS", flush=True)
         sys.exit(1 if bad else 0)
     rc = 0
-    for mode in ("0", "1"):
+    for mode in MODES:
         rc |= subprocess.run([sys.executable, __file__, "--child", mode, "check"]).returncode
     try:
-        a, b = torch.load("/tmp/bwd64_mode0.pt"), torch.load("/tmp/bwd64_mode1.pt")
+        a, b = torch.load("/tmp/bwd64_mode0.pt"), torch.load(f"/tmp/bwd64_mode{MODES[-1]}.pt")
         for i, (x, y) in enumerate(zip(a, b)):
             d = float((x.float() - y.float()).abs().max() / x.float().abs().max())
             print(f"case {i}: new vs old kernel max rel diff {d:.3e}", "FAIL" if not d < 1.2e-2 else "ok")
@@ -121,7 +129,7 @@ def main():
         rc |= 1
     if "--time" in sys.argv:
         for rnd in range(2):
-            for mode in ("0", "1"):
+            for mode in MODES + ("1",):
                 subprocess.run([sys.executable, __file__, "--child", mode, "time"])
     sys.exit(rc)
 
