@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColArgs p) {
     __shared__ f32x4 part[4][64];
     const int t = threadIdx.x, lx = t & 63, ly = t >> 6;
     const int64_t c = ((int64_t)blockIdx.x * 64 + lx) * 4;
-    const int64_t g = blockIdx.y / p.chunks, ch = blockIdx.y % p.chunks;
+    const int64_t by = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;      // (group, chunk) pairs beyond 65 535 continue in grid.z
+    const int64_t g = by / p.chunks, ch = by % p.chunks;
+    if (g * p.rows_per_group >= p.R) return;
     const int64_t rbeg = g * p.rows_per_group + ch * RC;
     int64_t rend = rbeg + RC;
     const int64_t gend = (g + 1) * p.rows_per_group < p.R ? (g + 1) * p.rows_per_group : p.R;
@@ -109,6 +111,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColArgs p) {
         float* o = p.out + g * p.C + c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(o + e, acc[e]);
+    }
+}
+
+// rows_per_group == 1 (per-token modulation, autograd.py: one gate / modulation vector per row): the "sum" is the row itself —
+// out[r, c] += a[r, c] (* b[r, c]), every element owned by one thread: no grid.y of R groups, no atomics
+template <typename TA, typename TB, bool HASB>
+__global__ __launch_bounds__(256) void rowprod_kernel(ColArgs p) {
+    const int64_t nv = p.C >> 2, total = p.R * nv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nv, c = (i % nv) * 4;
+        f32x4 v = load4((const TA*)p.a + r * p.lda + c);
+        if constexpr (HASB) v = v * load4((const TB*)p.b + r * p.ldb + c);
+        float* o = p.out + r * p.C + c;
+        store4(o, load4(o) + v);
     }
 }
 
@@ -219,19 +235,29 @@ M4D_DEV void flush_partials(const f32x4 (&part)[MAXV], float* lds, float* out, i
 // FULL: C == MAXV * 256 (host-checked) — every lane owns all MAXV pieces of its row, no per-piece lane predicates.  With them each piece
 // sits in a basic block of its own and hipcc waits for its loads before it requests the next piece's (elementwise.hip: the same finding
 // on the forward kernels); the wave index is made scalar so that rows are addressed as scalar base + lane offset.
-template <typename TD, int MAXV, bool FULL = false>
+// PERROW: rows_per_sample == 1 (per-token modulation: every row has its own scale vector and its own dshift / dscale rows) — the waves
+// of a persistent grid walk ROWS, the "column partials" of a row are its own values and are added to dshift / dscale directly: no
+// grid.y of B * Lp samples (which overflows 65 535 at B * Lp beyond that, e.g. a 720p clip), no one-row workgroups, no atomics
+template <typename TD, int MAXV, bool FULL = false, bool PERROW = false>
 __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
     constexpr int G = 64;
     extern __shared__ __attribute__((aligned(16))) float red_lds[];   // C floats
     const int lt = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sample = blockIdx.y;
+    const int64_t sample0 = PERROW ? 0 : (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+    if (!PERROW && sample0 >= p.B) return;
     const int C = p.C, nv = C >> 2;
-    const float* sc = p.scale ? p.scale + (int64_t)sample * p.mod_stride : nullptr;
+    const float* sc0 = p.scale ? p.scale + sample0 * p.mod_stride : nullptr;
     f32x4 ps[MAXV], pq[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) { ps[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pq[i] = ps[i]; }
-    for (int64_t l = (int64_t)blockIdx.x * 4 + wv; l < p.rows_per_sample; l += (int64_t)gridDim.x * 4) {
-        const int64_t row = (int64_t)sample * p.rows_per_sample + l;
+    const int64_t l_end = PERROW ? (int64_t)p.B : p.rows_per_sample;
+    for (int64_t l = (int64_t)blockIdx.x * 4 + wv; l < l_end; l += (int64_t)gridDim.x * 4) {
+        const int64_t row = PERROW ? l : sample0 * p.rows_per_sample + l;
+        const float* sc = PERROW ? (p.scale ? p.scale + row * p.mod_stride : nullptr) : sc0;
+        if (PERROW) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) { ps[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pq[i] = ps[i]; }
+        }
         const float* xr = p.x + row * C;
         const TD* dr = (const TD*)p.dy + row * C;
         float* dxr = p.dx + row * C;
@@ -281,10 +307,22 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
             const int c4 = lt + i * G;
             if (FULL || c4 < nv) store4(dxr + c4 * 4, dxo[i] + (g[i] - m1 - v[i] * m2) * rstd);
         }
+        if (PERROW && p.dshift) {
+            float* ds = p.dshift + row * p.red_stride;
+            float* dq = p.dscale + row * p.red_stride;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c4 = lt + i * G;
+                if (FULL || c4 < nv) {
+                    store4(ds + c4 * 4, load4(ds + c4 * 4) + ps[i]);
+                    store4(dq + c4 * 4, load4(dq + c4 * 4) + pq[i]);
+                }
+            }
+        }
     }
-    if (p.dshift) {
-        flush_partials<MAXV>(ps, red_lds, p.dshift + (int64_t)sample * p.red_stride, nv, lt, wv);
-        flush_partials<MAXV>(pq, red_lds, p.dscale + (int64_t)sample * p.red_stride, nv, lt, wv);
+    if (!PERROW && p.dshift) {
+        flush_partials<MAXV>(ps, red_lds, p.dshift + sample0 * p.red_stride, nv, lt, wv);
+        flush_partials<MAXV>(pq, red_lds, p.dscale + sample0 * p.red_stride, nv, lt, wv);
     }
 }
 
@@ -577,9 +615,22 @@ extern "C" int m4d_colsum(m4d_dtype a_dt, const void* a, int64_t lda, m4d_dtype 
     M4D_CHECK_ARG(C % 4 == 0 && lda % 4 == 0 && (!b || ldb % 4 == 0), "colsum: C and leading dims must be multiples of 4");
     const int64_t G = (R + rows_per_group - 1) / rows_per_group;
     ColArgs p{a, b, out, R, C, lda, ldb, rows_per_group, (int)((rows_per_group + 255) / 256)};
-    dim3 grid((unsigned)((C + 255) / 256), (unsigned)(G * p.chunks)), block(256);
-    M4D_CHECK_ARG((int64_t)G * p.chunks <= 65535, "colsum: too many row chunks");
+    const int64_t gy = G * p.chunks;
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)(gy < 65535 ? gy : 65535), (unsigned)((gy + 65534) / 65535)), block(256);
+    M4D_CHECK_ARG(grid.z <= 65535u, "colsum: too many row chunks");
     hipStream_t st = (hipStream_t)stream;
+    if (rows_per_group == 1) {      // one group per row: elementwise
+        dim3 g1(grid_for(R * (C / 4), 256, 16384));
+#define ROWPROD(TA, TB, HB) hipLaunchKernelGGL((rowprod_kernel<TA, TB, HB>), g1, block, 0, st, p)
+        if (!b) { if (a_dt == M4D_BF16) ROWPROD(bf16_t, bf16_t, false); else ROWPROD(float, float, false); }
+        else if (a_dt == M4D_BF16 && b_dt == M4D_BF16) ROWPROD(bf16_t, bf16_t, true);
+        else if (a_dt == M4D_F32 && b_dt == M4D_BF16) ROWPROD(float, bf16_t, true);
+        else if (a_dt == M4D_BF16 && b_dt == M4D_F32) ROWPROD(bf16_t, float, true);
+        else ROWPROD(float, float, true);
+#undef ROWPROD
+        M4D_CHECK_LAUNCH("colsum(rows)");
+        return 0;
+    }
 #define COLSUM(TA, TB, HB) hipLaunchKernelGGL((colsum_kernel<TA, TB, HB>), grid, block, 0, st, p)
     if (!b) { if (a_dt == M4D_BF16) COLSUM(bf16_t, bf16_t, false); else COLSUM(float, float, false); }
     else if (a_dt == M4D_BF16 && b_dt == M4D_BF16) COLSUM(bf16_t, bf16_t, true);
@@ -647,11 +698,22 @@ extern "C" int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* 
     int64_t nb = (rows_per_sample + 3) / 4;
     const int64_t cap = (512 + B - 1) / B;      // two workgroups per CU chip-wide; more only adds atomics
     if (nb > cap) nb = cap;
-    dim3 grid((unsigned)nb, (unsigned)B), block(256);
+    dim3 grid((unsigned)nb, (unsigned)(B < 65535 ? B : 65535), (unsigned)((B + 65534) / 65535)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)C * sizeof(float);
-#define LNB(TD, MV) hipLaunchKernelGGL((ln_bwd_kernel<TD, MV>), grid, block, lds, st, p)
     const bool bf = dy_dt == M4D_BF16;
+    if (rows_per_sample == 1 && red_stride != 0) {      // one modulation vector per row (and per-row dshift / dscale): the per-row form
+        dim3 gr((unsigned)((B + 3) / 4 < 1024 ? (B + 3) / 4 : 1024));
+#define LNR(TD, MV, FL) hipLaunchKernelGGL((ln_bwd_kernel<TD, MV, FL, true>), gr, block, lds, st, p)
+        if (C == 5120) { if (bf) LNR(bf16_t, 20, true); else LNR(float, 20, true); }
+        else if (C <= 2048) { if (bf) LNR(bf16_t, 8, false); else LNR(float, 8, false); }
+        else if (C <= 5120) { if (bf) LNR(bf16_t, 20, false); else LNR(float, 20, false); }
+        else { if (bf) LNR(bf16_t, 32, false); else LNR(float, 32, false); }
+#undef LNR
+        M4D_CHECK_LAUNCH("ln_modulate_bwd(rows)");
+        return 0;
+    }
+#define LNB(TD, MV) hipLaunchKernelGGL((ln_bwd_kernel<TD, MV>), grid, block, lds, st, p)
     M4D_ENV_ONCE(full_ok, "M4D_TRAIN_ROWS_FULL", 1);      // 0: the predicated kernels (A/B)
     if (C == 5120 && full_ok) { if (bf) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 20, true>), grid, block, lds, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<float, 20, true>), grid, block, lds, st, p); }
     else if (C <= 2048) { if (bf) LNB(bf16_t, 8); else LNB(float, 8); }

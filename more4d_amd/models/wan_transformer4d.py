@@ -179,13 +179,21 @@ class WanSelfAttention(nn.Module):
                 return w, b
         owned = all(t.is_contiguous() and t.untyped_storage().nbytes() == t.numel() * t.element_size() for t in (qw, kw, qb, kb))
         if owned:
-            with torch.no_grad():
+            # inference_mode(False): a first call under torch.inference_mode() would otherwise turn the four Parameters into inference
+            # tensors, which a later optimizer step cannot update in place; call fuse_qk_() after loading to do this eagerly
+            with torch.inference_mode(False), torch.no_grad():
                 w = torch.cat([qw.detach(), kw.detach()]).contiguous()
                 b = torch.cat([qb.detach(), kb.detach()]).contiguous()
                 qw.data, kw.data, qb.data, kb.data = w[:C], w[C:], b[:C], b[C:]
             self.__dict__["_qk_cache"] = ("view", w, b)
             return w, b
         return None, None
+
+    def fuse_qk_(self):
+        """Explicit form of the storage fusing `_qk_weights()` otherwise does on the first forward: afterwards q.weight / k.weight (and the
+        biases) are the two halves of ONE storage.  Call it after `load_state_dict` / `.to()` (WanTransformer4DModel.fuse_qk_() does it for
+        every block) when something is about to capture parameter storages or data pointers (HIP graphs, flat-parameter wrappers)."""
+        return self._qk_weights()[0] is not None
 
     def run(self, xn, xres, gate, gate_stride, c: _Ctx, gate_rows=None):
         """xn: T [B, Lp, C] modulated input; accumulates o-proj * gate into xres (float32) in place.  gate_rows: rows that share
@@ -700,6 +708,11 @@ class WanTransformer4DModel(nn.Module):
     def enable_gradient_checkpointing(self):
         self.gradient_checkpointing = True
 
+    def fuse_qk_(self):
+        """q / k projection parameters of every block become halves of one storage NOW instead of on the first forward
+        (WanSelfAttention.fuse_qk_); returns the number of blocks fused."""
+        return sum(int(blk.self_attn.fuse_qk_()) for blk in self.blocks)
+
     def enable_teacache(self, coefficients, num_steps: int, rel_l1_thresh: float, num_skip_start_steps: int = 0,
                         offload: bool = True):
         self.teacache = TeaCache(coefficients, num_steps, rel_l1_thresh=rel_l1_thresh,
@@ -801,12 +814,12 @@ class WanTransformer4DModel(nn.Module):
         features directly as first_frame_features = (patch_feats [B,196,768], cls [B,768]).  Returns
         [B, out_dim, F, H, W] in T.
         """
-        if y_camera is not None or subject_ref is not None:
-            raise NotImplementedError("y_camera / subject_ref are not part of the 4D-STraG path")
+        if y_camera is not None:      # (the reference's camera adapter class is undefined, :941 — SURVEY appendix E.2)
+            raise NotImplementedError("y_camera: the reference's control adapter (SimpleAdapter) does not exist")
         if first_frame is not None and self.use_omnimae_guidance and first_frame_features is None:
             first_frame_features = self.omnimae_extractor.trunk.forward_patch_features(first_frame, None, normalize=True)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return self._forward_train(x, t, context, seq_len, clip_fea, y, full_ref, first_frame_features)
+            return self._forward_train(x, t, context, seq_len, clip_fea, y, full_ref, first_frame_features, subject_ref)
         T, dev = self.dtype, self.device
         B = x.shape[0]
         x = x.to(dev)
@@ -821,7 +834,19 @@ class WanTransformer4DModel(nn.Module):
             n_ref = h * w
             grid = (f + 1, h, w)
             seq_len = seq_len + n_ref
-        L = Lv + n_ref
+        # subject_ref (:1092-1097): extra frames [B, in_dim, Fs, H, W] through the SAME patch embedding, appended BEHIND the video tokens (their
+        # RoPE frame index continues) and cut off again after the head (:1328-1331).  (The reference cuts `subject_ref[0].size(1)` tokens
+        # there, which is the model width, not the token count; its unpatchify then takes the first prod(grid) tokens, so its result is
+        # the one below whenever it runs at all — tests/golden/make_golden_r6.py.)
+        n_sub = 0
+        if subject_ref is not None:
+            if subject_ref.shape[3] // ph != h or subject_ref.shape[4] // pw != w:
+                raise ValueError("subject_ref must have the video's spatial size")
+            fs = subject_ref.shape[2] // pt
+            n_sub = fs * h * w
+            grid = (grid[0] + fs, h, w)
+            seq_len = seq_len + n_sub
+        L = Lv + n_ref + n_sub
         sp = self._sp if self.sp_world_size > 1 else None
         # keys: the reference's SDPA branch attends the zero rows up to seq_len (:222-226); rows added only to
         # make the sequence divisible by the SP world (:1100-1101) are masked so N ranks == 1 rank.
@@ -842,6 +867,10 @@ class WanTransformer4DModel(nn.Module):
             wr = self.ref_conv.weight.view(self.dim, -1)
             for b in range(B):
                 ops.gemm_bt(rt[b], wr, self.ref_conv.bias, out=xres[b, :n_ref], epilogue=EPI_STORE_F32)
+        if n_sub:
+            stok = ops.patchify(subject_ref.to(device=dev, dtype=x.dtype), None, self.patch_size, T)
+            for b in range(B):
+                ops.gemm_bt(stok[b], wpe, self.patch_embedding.bias, out=xres[b, n_ref + Lv:n_ref + Lv + n_sub], epilogue=EPI_STORE_F32)
         # ---- conditioning
         if t.dim() != 1:
             # per-token timesteps (:1161-1167): t [B, seq_len] (seq_len AFTER the ref row was added, :1088) -> e [B, Lp, C],
@@ -925,7 +954,7 @@ class WanTransformer4DModel(nn.Module):
         return res
 
     # ------------------------------------------------------------------ training forward (autograd tape over HIP kernels)
-    def _forward_train(self, x, t, context, seq_len, clip_fea=None, y=None, full_ref=None, first_frame_features=None):
+    def _forward_train(self, x, t, context, seq_len, clip_fea=None, y=None, full_ref=None, first_frame_features=None, subject_ref=None):
         """Differentiable forward for `train_wan.py:1939-1951` (same arguments, same result as `forward`): every node
         is a `more4d_amd.autograd` Function whose forward AND backward run in the HIP kernels; one recomputing node per
         block (the reference trains with gradient checkpointing, :1273-1291).  Data parallel only."""
@@ -951,7 +980,14 @@ class WanTransformer4DModel(nn.Module):
         if self.ref_conv is not None and full_ref is not None:
             n_ref, grid = h * w, (f + 1, h, w)
             seq_len = seq_len + n_ref
-        L = Lv + n_ref
+        n_sub = 0
+        if subject_ref is not None:      # (:1092-1097, see forward)
+            if subject_ref.shape[3] // ph != h or subject_ref.shape[4] // pw != w:
+                raise ValueError("subject_ref must have the video's spatial size")
+            fs = subject_ref.shape[2] // pt
+            n_sub, grid = fs * h * w, (grid[0] + fs, h, w)
+            seq_len = seq_len + n_sub
+        L = Lv + n_ref + n_sub
         key_len = L if self.mask_padding_keys else seq_len
         assert L <= seq_len, f"sequence of {L} tokens exceeds seq_len={seq_len}"
         Lp = _round8(seq_len)
@@ -962,6 +998,9 @@ class WanTransformer4DModel(nn.Module):
             parts.append(LinearFn.apply(rt, self.ref_conv.weight, self.ref_conv.bias, 0, T, True))
         parts.append(LinearFn.apply(ops.patchify(x, y, self.patch_size, T), self.patch_embedding.weight,
                                     self.patch_embedding.bias, 0, T, True))
+        if n_sub:
+            parts.append(LinearFn.apply(ops.patchify(subject_ref.to(device=dev, dtype=x.dtype), None, self.patch_size, T),
+                                        self.patch_embedding.weight, self.patch_embedding.bias, 0, T, True))
         if Lp > L:
             parts.append(torch.zeros((B, Lp - L, C), device=dev, dtype=f32))
         xres = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]

@@ -31,11 +31,11 @@ ap.add_argument("--plain", action="store_true", help="debug: no interleaving (MF
 ap.add_argument("--cap", type=int, default=5, help="instructions per MFMA gap besides the MFMA")
 ap.add_argument("--eb", type=int, default=10, help="softmax units (2 scores per query half) exponentiated in phase B")
 ap.add_argument("--stamps", action="store_true", help="s_memtime stamps of wave 0 of workgroup 1000 at the phase boundaries of tiles 100..107")
-ap.add_argument("--wait1", action="store_true", help="one s_waitcnt lgkmcnt per fragment instead of one per TWO fragments (A/B: +0.8 % time)")
-ap.add_argument("--first-gap", type=int, default=1, help="phase B: no fillers behind its first N MFMAs (0: -0.8 % time, but the first row-max "
+ap.add_argument("--wait1", action="store_true", help="one s_waitcnt lgkmcnt per fragment instead of one per TWO fragments (A/B: +0.8 %% time)")
+ap.add_argument("--first-gap", type=int, default=1, help="phase B: no fillers behind its first N MFMAs (0: -0.8 %% time, but the first row-max "
                 "instructions would read accumulators one MFMA behind their last write)")
 ap.add_argument("--dma-m0", action="store_true", help="A/B: one m0 write per DMA piece instead of one per K / V^T request of four pieces with the pieces' LDS steps in the "
-                "instruction offset (which moves the global address too: cancelled in the lane offsets); -0.6 % time for the default")
+                "instruction offset (which moves the global address too: cancelled in the lane offsets); -0.6 %% time for the default")
 ap.add_argument("--exp-alt", action="store_true", help="A/B: exp / add alternating instead of exp exp add add")
 ap.add_argument("--abl", default="", help="timing ablations for the stamps build (results WRONG): letters e = no exp / add / pack fillers, m = no row-max list, "
                 "d = no DMA requests, r = no fragment reads, w = no lgkm waits, a = no address updates, b = no barrier / vmcnt")
