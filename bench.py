@@ -236,8 +236,13 @@ def secondary_figures(model, cfg, dev):
     out = {}
     try:
         import bench_vae
-        r = bench_vae.run(49, 480, 832, iters=2, dev=dev, verbose=False)
+        vmon = ClockMonitor(dev.index or 0).start()
+        try:
+            r = bench_vae.run(49, 480, 832, iters=2, dev=dev, verbose=False)
+        finally:
+            vmon.stop()
         out["vae_roundtrip"] = {"ms": r["roundtrip_ms"], "parts_ms": r["ms"], "tflops": r["tflops"], "finite": r["finite"],
+                                "clock": vmon.region(),
                                 "workload": "enc-adaptor + encode + decode + dec-adaptor, 49x480x832x3 trajectories, bf16"}
         px = 480 * 832
         fl = px * (6.657e6 + 48 * 5.003e6) + px * (10.748e6 + 48 * 8.445e6)
@@ -259,13 +264,15 @@ def secondary_figures(model, cfg, dev):
         orig = kt.wrap(ops, "attention_bwd", bwd_flops)
         mon = ClockMonitor(dev.index or 0).start()
         try:
-            r = bench_train.run_train(model, cfg, dev, steps=3, warmup=1)
+            r = bench_train.run_train(model, cfg, dev, steps=3, warmup=2)      # (two warm-up steps: a fresh box's first step pays for allocator growth)
         finally:
             ops.attention_bwd = orig
             mon.stop()
         ab = kt.summary().get("attention_bwd", {})
         out["roofline_attention_bwd"] = {
-            "kernel": "attn_bwd_kvp_kernel (fused dK / dV) + attn_bwd_dqp_kernel (dQ) via m4d_attention_bwd (self + cross, 4 train steps incl. warm-up)", "bound": "mfma",
+            "kernel": "attn_bwd_kv64_kernel (fused dK / dV, role-split) + attn_bwd_dq64_kernel (dQ), one wave per SIMD, for the self-attention; "
+                      "attn_bwd_kvp_kernel + attn_bwd_dqp_kernel for the cross-attention calls; via m4d_attention_bwd (self + cross, 5 train steps "
+                      "incl. warm-up)", "bound": "mfma",
             "achieved": ab.get("tflops", 0.0), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": ab.get("tflops", 0.0) / MFMA_BF16_PEAK_TF,
             "launches": ab.get("launches", 0), "flops_convention": "10 B Lq Lk heads head_dim per call"}
         del ag

@@ -32,6 +32,7 @@ ap.add_argument("--plain", action="store_true", help="debug: no interleaving (MF
 ap.add_argument("--cap", type=int, default=5, help="instructions per MFMA gap besides the MFMA")
 ap.add_argument("--first-gap", type=int, default=1, help="dQ phase: no fillers behind its first N MFMAs (the first exps read S' accumulators)")
 ap.add_argument("--greedy", action="store_true", help="A/B: pour the fillers into the first gaps up to the cap instead of spreading them over the phase")
+ap.add_argument("--ahead", type=int, default=8, help="fragments in flight (ring slots: 8)")
 ap.add_argument("-o", default="more4d_amd/csrc/attention_bwd64_dq_gen.inc")
 args = ap.parse_args()
 
@@ -200,7 +201,7 @@ def dq_frags(X, half):
     return fr
 
 
-AHEAD = 8
+AHEAD = args.ahead
 
 
 def emit_phase(frags, nxt, fillers, extra_post=None, first_gap=0, tail=None):
@@ -213,7 +214,7 @@ def emit_phase(frags, nxt, fillers, extra_post=None, first_gap=0, tail=None):
     post = [[] for _ in range(n_m)]
     for n, f in enumerate(frags):
         behind = sum(len(allf[j].reads) for j in range(n + 1, n + AHEAD))
-        pre[2 * n].append(f"s_waitcnt lgkmcnt({behind})")
+        pre[2 * n].append(f"s_waitcnt lgkmcnt({min(behind, 15)})")
         post[2 * n + 1] += allf[n + AHEAD].reads
     for k, ins in (extra_post or {}).items():
         post[k] += ins

@@ -29,14 +29,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--plain", action="store_true", help="debug: no interleaving (the MFMAs of a phase, then its fillers)")
 ap.add_argument("--cap", type=int, default=5, help="instructions per MFMA gap besides the MFMA")
 ap.add_argument("--first-gap", type=int, default=1, help="no fillers behind the first N MFMAs of a phase whose fillers read fresh accumulators")
+ap.add_argument("--ahead", type=int, default=6, help="fragments in flight (the ring has 8 slots; lgkmcnt counts to 15)")
 ap.add_argument("-o", default="more4d_amd/csrc/attention_bwd64_kv_gen.inc")
 args = ap.parse_args()
 
+AHEAD = args.ahead
 STAGE, VOFF, STOFF = 32768 + 512, 16384, 32768          # stage: Q tile, dO tile, lse[64], delta[64] (accumulator-register order)
 NSTG = 4
 MAILOFF = NSTG * STAGE                                  # 2 pairs x 2 slots x 4 KiB
 TABSTAGE = 2                                            # the lane table travels in stage 2 (tile 2 is requested in the loop)
-AHEAD = 6                                               # fragments in flight (the ring has 8 slots; lgkmcnt counts to 15)
 
 # ---------------- register map ----------------
 RA = [4 + i for i in range(8)]                  # row-fragment addresses (stage base + row * 256 + swizzled k-step chunk)
