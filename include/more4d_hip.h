@@ -57,7 +57,8 @@ typedef enum {
     M4D_KC_ATTN_XP = 14,           /* attn128x_kernel: persistent pipeline over (query tile, key tile) pairs for short key lists (cross-attention) */
     M4D_KC_ATTN_Q64 = 15,          /* attn128q_kernel: one wave per SIMD, 4 x 64 query rows, generated instruction stream (long self-attention) */
     M4D_KC_ATTN_BWD64 = 16,        /* attn_bwd_*64_kernel: one pass of the attention backward as one wave per SIMD, generated instruction stream */
-    M4D_KC_COUNT = 17
+    M4D_KC_CONV_HALO64 = 17,       /* conv_halo64_kernel: the 3x3x3 conv of 96-channel tiles as one wave per SIMD, generated main loop */
+    M4D_KC_COUNT = 18
 } m4d_kernel_class;
 /* launches of `kernel_class` since process start (or the last reset); reset != 0 clears that counter after reading it;
  * kernel_class < 0 with reset != 0 clears all counters and returns 0. */

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv_cl256_kernel(ConvArgs p) {
 }
 
 #include "conv_halo.h"
+#include "conv_halo64.h"
 
 template <int KT, int KH, int TH, int TW, int NT, int MT, int SD = 1>
 int launch_halo(ConvArgs& p, hipStream_t st) {
@@ -396,6 +397,24 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
     if (p.post_out) m4d_count_launch(p.resid ? M4D_KC_CONV_FUSED_NORM_RESID : M4D_KC_CONV_FUSED_NORM);
     if (p.gn_partial) m4d_count_launch(M4D_KC_CONV_GNSTATS);
     hipLaunchKernelGGL((conv_halo_kernel<KT, KH, TH, TW, NT, MT, SD>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(64 * halo::Cfg<KT, KH, TH, TW, NT, MT, SD>::NWAVE), LDS, st, p);
+    return 0;
+}
+
+// one wave per SIMD, 10 x 32 patches, 96-channel tiles (conv_halo64.h)
+int launch_halo64(ConvArgs& p, hipStream_t st) {
+    static PerDeviceOnce configured;
+    if (configured.pending()) {
+        if (hipFuncSetAttribute((const void*)conv_halo64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, halo64::LDS_BYTES) != hipSuccess) {
+            m4d_set_error("conv_cl: cannot enable %d bytes of LDS", halo64::LDS_BYTES);
+            return -3;
+        }
+        configured.mark();
+    }
+    p.tiles_m = p.To * ((p.Ho + halo64::TH - 1) / halo64::TH) * ((p.Wo + 31) / 32);
+    p.tiles_n = p.Cout / 96;
+    m4d_count_launch(M4D_KC_CONV_HALO64);
+    if (p.post_out) m4d_count_launch(p.resid ? M4D_KC_CONV_FUSED_NORM_RESID : M4D_KC_CONV_FUSED_NORM);
+    hipLaunchKernelGGL(conv_halo64_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(128), halo64::LDS_BYTES, st, p);
     return 0;
 }
 
@@ -435,6 +454,13 @@ int launch_halo_auto(ConvArgs& p, hipStream_t st) {
         const int64_t patches = (int64_t)p.To * nh * ((p.Wo + tw - 1) / tw);
         const bool fits = (nh * th - p.Ho) * 20 <= p.Ho;      // at most 5 % of the rows are padding
         if (fits && (p.post_out || patches * ((p.Cout + 95) / 96) > 256)) {      // (small maps: launch_halo_nt's 32-channel tiles)
+            // M4D_CONV_HALO64=1 (default): the one-wave-per-SIMD kernel (conv_halo64.h) on 32-column maps whose rows divide into 10-row patches
+            M4D_ENV_ONCE(h64, "M4D_CONV_HALO64", 1);
+            // (planar-16 inputs only — what the residual blocks' fused norms write: + 5 % there; on channels-last inputs, whose halo pieces
+            //  are 32 bytes out of every Cin * 2, it measured 5 % SLOWER than the 12 x 32 kernel: tools/check_conv64.py --time.  h64 = 2: both)
+            if (h64 && (p.xplane || h64 == 2) && p.kt == 3 && wide && !p.ups && !p.tsplit && p.Cout % 96 == 0 &&
+                (((p.Ho + 9) / 10) * 10 - p.Ho) * 20 <= p.Ho)
+                return launch_halo64(p, st);
             if (p.kt == 3) return wide ? launch_halo<3, 3, 12, 32, 3, 3>(p, st) : launch_halo<3, 3, 24, 16, 3, 3>(p, st);
             return wide ? launch_halo<1, 3, 12, 32, 3, 3>(p, st) : launch_halo<1, 3, 24, 16, 3, 3>(p, st);
         }

@@ -262,234 +262,6 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         }
     }
 
-    // ---- epilogue through LDS: each wave parks its 32 pixels x NB channels (+bias, rounded to T) in its own block of the (now free)
-    // buffers, pixel-major with an XOR swizzle of the 16-byte chunks, and writes them back out as contiguous row segments ----
-    const T* bias = (const T*)p.bias;
-    const T* resid = (const T*)p.resid;
-    if (M4D_ABL(p) & 64) ts[2] = __builtin_readcyclecounter();
-    // the bias of this lane's NT x 4 channel quads: the same for every pixel tile, loaded ONCE and before the barrier (the loads were
-    // inside the mi / ni / rq loops: MT x NT x 4 dependent L2 round trips in front of the first store)
-    bf16x4 bv[NT][4];                                      // (kept packed: 2 registers per quad)
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int nb = n0 + ni * 32 + rq * 8 + hi * 4;
-            bv[ni][rq] = (bias && nb < p.Cout) ? *reinterpret_cast<const bf16x4*>(bias + nb) : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-        }
-    __syncthreads();                                       // all fragment reads of the last step are done
-    if (M4D_ABL(p) & 32) return;                           // ablation: no epilogue
-    char* blk = conv_dyn_smem + wave * (32 * EROW);        // [32 pixels][NB channels] bf16; chunk c of pixel px at c ^ (px & ESW)
-    float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};       // GroupNorm statistics of the result (p.gn_partial): this lane's two 4-channel groups
-    // fused next-layer norm: 16 lanes per pixel, lane & 15 = this lane's 8-channel chunk in EVERY read-back iteration, so its gamma
-    // is loaded once (it was two dependent loads per iteration behind a branch)
-    f32x4 pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0;
-    constexpr bool GAMMA_ONCE = NT < 4;       // (the 128-channel kernels are at the register limit with the shortcut prefetch: they load it per stage)
-    if (GAMMA_ONCE && p.post_out && (lane & 15) < NT * 4) { pg0 = load4(p.post_gamma + (lane & 15) * 8); pg1 = load4(p.post_gamma + (lane & 15) * 8 + 4); }
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {                      // (a wave's LDS operations execute in order: round mi+1 may overwrite the block)
-        // shortcut / residual rows of this round's pixels: requested BEFORE the accumulators go through LDS, so that the L2 round
-        // trip overlaps the conversion + LDS transposition instead of sitting between the read-back and the store
-        constexpr int NJ = (32 * NT * 4 + 63) / 64;
-        uint4 rpre[NJ];
-        // (MT = 3 kernels sit at the 256-register limit: the prefetch would spill)
-        const bool rwide = MT < 3 && resid && !p.post_out && ((p.ldo | p.ldr) & 7) == 0 && (p.Cout & 7) == 0;
-        if (rwide) {
-            const int mt_ = wave * MT + mi;
-            const int row0_ = TW == 32 ? mt_ : mt_ * ROWS_PER_MT;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int q = j * 64 + lane;
-                const int pl = q / (NT * 4), ch = q % (NT * 4);
-                const int row = TW == 32 ? row0_ : row0_ + pl / TW;
-                const int col = TW == 32 ? pl : pl % TW;
-                const int ho = h0 + row, wo = w0 + col;
-                const int nb = n0 + ch * 8;
-                rpre[j] = make_uint4(0, 0, 0, 0);
-                if (pl < 32 && ho < p.Ho && wo < p.Wo && nb < p.Cout)
-                    rpre[j] = *reinterpret_cast<const uint4*>(resid + (((int64_t)to * p.Ho + ho) * p.Wo + wo) * p.ldr + nb);
-            }
-        }
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int nl = ni * 32 + rq * 8 + hi * 4;              // channel inside the workgroup's NB
-                const int nb = n0 + nl;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][rq * 4 + e];
-                if (bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)bv[ni][rq][e];
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-                const int ch = nl >> 3;
-                *reinterpret_cast<bf16x4*>(blk + li * EROW + ((ch ^ (li & ESW)) << 4) + (nl & 7) * 2) = o;
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave reads back only its own block
-        constexpr int CPP = NT * 4;                        // 16-byte chunks per pixel
-        const int mt = wave * MT + mi;
-        const int row0 = TW == 32 ? mt : mt * ROWS_PER_MT;
-        if (p.post_out) {
-            // fused RMS_norm (+SiLU) of the NEXT layer (wan_vae.py:199-201: norm -> SiLU -> conv): the workgroup owns all Cout = NB
-            // channels of its pixels, so the normalised result goes straight into the next conv's planar-16 staging buffer and the raw
-            // output is written only if somebody else reads it (p.out).  16 lanes per pixel and the reduction order of
-            // rmsnorm_silu_cl_kernel<T, 16, 1>: bit-identical to the separate kernel.
-            // Staged four iterations at a time so that the L2 round trips of the shortcut rows, the LDS reads and the dependent
-            // reduce -> sqrt -> divide -> SiLU chains of different pixels overlap (one iteration at a time, behind branches, the
-            // fused-norm epilogue took 29 us of a 100 us workgroup, 44 us with a shortcut: tools/conv_timeline.py); the 16-lane sum
-            // uses DPP row rotations by 8, 4, 2, 1 — the same operands per step as the xor butterfly of the separate kernel (after a
-            // step the values repeat with that period), so the bits are unchanged — instead of four LDS permutes.
-            const int ch = lane & 15;
-            const bool act = ch < CPP;
-            const float root_c = sqrtf((float)p.Cout);
-            constexpr int JG = NT == 4 ? 1 : 4;        // (the 128-channel kernels also carry the shortcut prefetch: fewer rows in flight)
-#pragma unroll
-            for (int jb = 0; jb < 8; jb += JG) {
-                uint4 raw[JG], rr[JG];
-                int64_t mrow[JG];
-                bool inside[JG];
-#pragma unroll
-                for (int jj = 0; jj < JG; ++jj) {
-                    const int pl = ((jb + jj) * 64 + lane) >> 4;
-                    const int row = TW == 32 ? row0 : row0 + pl / TW;
-                    const int col = TW == 32 ? pl : pl % TW;
-                    const int ho = h0 + row, wo = w0 + col;
-                    inside[jj] = ho < p.Ho && wo < p.Wo;
-                    mrow[jj] = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
-                    raw[jj] = make_uint4(0, 0, 0, 0);
-                    rr[jj] = make_uint4(0, 0, 0, 0);
-                    if (act) raw[jj] = *reinterpret_cast<const uint4*>(blk + pl * EROW + ((ch ^ (pl & ESW)) << 4));
-                    if (act && resid && inside[jj]) rr[jj] = *reinterpret_cast<const uint4*>(resid + mrow[jj] * p.ldr + ch * 8);
-                }
-                float ss[JG];
-#pragma unroll
-                for (int jj = 0; jj < JG; ++jj) {
-                    if (resid && act && inside[jj]) {           // conv output is T, then x + h rounded to T (:224)
-                        const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw[jj]);
-                        const bf16_t* b = reinterpret_cast<const bf16_t*>(&rr[jj]);
-                        bf16x8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)b[e]);
-                        raw[jj] = *reinterpret_cast<const uint4*>(&o);
-                    }
-                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw[jj]);
-                    float s_ = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s_ += (float)a[e] * (float)a[e];
-                    ss[jj] = s_;
-                }
-#define HL_ROR_ADD(N)                                                                                                   \
-                _Pragma("unroll") for (int jj = 0; jj < JG; ++jj)                                                      \
-                    ss[jj] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss[jj]), 0x120 + N, 0xf, 0xf, false))
-                HL_ROR_ADD(8); HL_ROR_ADD(4); HL_ROR_ADD(2); HL_ROR_ADD(1);
-#undef HL_ROR_ADD
-#pragma unroll
-                for (int jj = 0; jj < JG; ++jj) {
-                    if constexpr (!GAMMA_ONCE) {
-                        if (act) { pg0 = load4(p.post_gamma + ch * 8); pg1 = load4(p.post_gamma + ch * 8 + 4); }
-                    }
-                    const float sc = rms_scale_f(root_c, ss[jj]);
-                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw[jj]);
-                    bf16x8 y;
-#pragma unroll
-                    for (int e = 0; e < 8; e += 4) {
-                        const f32x4 g = e == 0 ? pg0 : pg1;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float u = (float)a[e + k] * sc * g[k];
-                            if (p.post_silu) u = silu_f(round_through<T>(u));
-                            y[e + k] = (bf16_t)u;
-                        }
-                    }
-                    if (act && inside[jj]) {
-                        if (p.out) *reinterpret_cast<uint4*>((T*)p.out + mrow[jj] * p.ldo + ch * 8) = raw[jj];
-                        *reinterpret_cast<bf16x8*>((T*)p.post_out + (int64_t)(ch >> 1) * p.post_plane + mrow[jj] * 16 + (ch & 1) * 8) = y;
-                    }
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < (32 * CPP + 63) / 64; ++j) {
-            const int q = j * 64 + lane;
-            const int pl = q / CPP, ch = q % CPP;
-            if (pl >= 32) continue;
-            const int row = TW == 32 ? row0 : row0 + pl / TW;
-            const int col = TW == 32 ? pl : pl % TW;
-            const int ho = h0 + row, wo = w0 + col;
-            const int nb = n0 + ch * 8;
-            uint4 raw = *reinterpret_cast<const uint4*>(blk + pl * EROW + ((ch ^ (pl & ESW)) << 4));
-            if (ho >= p.Ho || wo >= p.Wo || nb >= p.Cout) continue;
-            const int64_t m = ((int64_t)to * p.Ho + ho) * p.Wo + wo;
-            const bool wide = nb + 8 <= p.Cout && ((p.ldo | (resid ? p.ldr : 0)) & 7) == 0;      // else 4-channel halves (Cout % 4 == 0)
-            if (resid) {
-                bf16_t rr[8] = {};
-                if (rwide) *reinterpret_cast<uint4*>(rr) = rpre[j];
-                else if (wide) *reinterpret_cast<uint4*>(rr) = *reinterpret_cast<const uint4*>(resid + m * p.ldr + nb);
-                else {
-                    *reinterpret_cast<uint2*>(rr) = *reinterpret_cast<const uint2*>(resid + m * p.ldr + nb);
-                    if (nb + 8 <= p.Cout) *reinterpret_cast<uint2*>(rr + 4) = *reinterpret_cast<const uint2*>(resid + m * p.ldr + nb + 4);
-                }
-                const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw);
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)a[e] + (float)rr[e]);        // conv output is T, then x + h (:224)
-                raw = *reinterpret_cast<const uint4*>(&o);
-            }
-            if constexpr (NT == 4) {
-                if (p.gn_partial) {          // (16 chunks per pixel: ch = lane & 15 for every j, i.e. the same two groups)
-                    const bf16_t* a = reinterpret_cast<const bf16_t*>(&raw);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float v = (float)a[e]; gsum[e >> 2] += v; gsq[e >> 2] += v * v; }
-                }
-            }
-            T* dst = (T*)p.out + m * p.ldo + nb;
-            if (wide) *reinterpret_cast<uint4*>(dst) = raw;
-            else {
-                *reinterpret_cast<uint2*>(dst) = make_uint2(raw.x, raw.y);
-                if (nb + 8 <= p.Cout) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(raw.z, raw.w);
-            }
-        }
-    }
-    if (M4D_ABL(p) & 64) {          // tool build: entry / loop start / loop end / stores acknowledged, 100 MHz wall clock, hardware id
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ts[3] = __builtin_readcyclecounter();
-        if (t == 0 && p.dbg) {
-            unsigned hwid, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
-            d[0] = ts[0]; d[1] = ts[1]; d[2] = ts[2]; d[3] = ts[3]; d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
-            d[6] = ((unsigned long long)xcc << 32) | hwid; d[7] = 1;
-        }
-    }
-    if constexpr (NT == 4) {
-        // the next layer's GroupNorm(32 groups of 4 channels) statistics (trajectory_module.py:54-60): per-workgroup (sum, sum of squares)
-        // of the stored values, one row per patch in the order [frame][patch][group]; a finalize kernel adds them in that fixed order
-        if (p.gn_partial) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int o = 16; o < 64; o <<= 1) { gsum[h] += __shfl_xor(gsum[h], o, 64); gsq[h] += __shfl_xor(gsq[h], o, 64); }
-            __syncthreads();                                   // every wave is done with its staging block
-            float* red = reinterpret_cast<float*>(conv_dyn_smem);      // [wave][32 groups][2]
-            if (lane < 16) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) { red[(wave * 32 + lane * 2 + h) * 2] = gsum[h]; red[(wave * 32 + lane * 2 + h) * 2 + 1] = gsq[h]; }
-            }
-            __syncthreads();
-            if (t < 32) {
-                float a = 0.f, b = 0.f;
-#pragma unroll
-                for (int w = 0; w < NWAVE; ++w) { a += red[(w * 32 + t) * 2]; b += red[(w * 32 + t) * 2 + 1]; }
-                float* dst = p.gn_partial + (((int64_t)to * (tiles_h * tiles_w) + th * tiles_w + tw) * 32 + t) * 2;
-                dst[0] = a; dst[1] = b;
-            }
-        }
-    }
+#include "conv_halo_epi.inc"
 #endif
 }

@@ -62,7 +62,7 @@ class Packed:
 
 KERNEL_CLASSES = ("gemm_phased", "gemm_wide", "gemm_generic", "attn_phased", "attn_other", "conv_halo_mt3_12x32",
                   "conv_halo_mt3_24x16", "conv_halo", "conv_generic", "conv_fused_norm", "conv_fused_norm_resid", "conv_gnstats",
-                  "attn_bwd128", "attn_bwd_generic", "attn_xp", "attn_q64", "attn_bwd64")
+                  "attn_bwd128", "attn_bwd_generic", "attn_xp", "attn_q64", "attn_bwd64", "conv_halo64")
 
 
 def launch_counts(reset=False):

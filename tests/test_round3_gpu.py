@@ -78,10 +78,10 @@ def test_vae_chain_vs_reference_production_tiles(size, dtype):
         _check("chain", chain, z["rec_s"], z["rec_n"], (5e-3, 3e-3, 3e-3) if fp32 else tol("chain"), rep)
     print(size, dtype, {k: tuple(f"{x:.2e}" for x in v) for k, v in rep.items()}, {k: v for k, v in counts.items() if v})
     if fp32:
-        assert counts["conv_generic"] > 0 and counts["conv_halo"] + counts["conv_halo_mt3_12x32"] + counts["conv_halo_mt3_24x16"] == 0
+        assert counts["conv_generic"] > 0 and counts["conv_halo"] + counts["conv_halo_mt3_12x32"] + counts["conv_halo_mt3_24x16"] + counts["conv_halo64"] == 0
     else:
         mt3 = "conv_halo_mt3_24x16" if size == "120x208" else "conv_halo_mt3_12x32"
-        assert counts[mt3] > 0, counts                     # three pixel tiles per wave
+        assert counts[mt3] + counts["conv_halo64"] > 0, counts      # three pixel tiles per wave / (round 6) five per wave, one wave per SIMD
         assert counts["conv_halo"] > 0, counts             # the 8 x 32 / 16 x 16 patch kernels of the deeper levels
         assert counts["conv_fused_norm"] > 0 and counts["conv_fused_norm_resid"] > 0, counts
         assert counts["conv_gnstats"] > 0, counts

@@ -294,3 +294,33 @@ def test_tiny_dit_subject_ref_vs_reference():
     out.float().square().mean().backward()
     gpe = m.patch_embedding.weight.grad
     assert gpe is not None and bool(torch.isfinite(gpe).all()) and float(gpe.abs().sum()) > 0
+
+
+def test_conv_halo64_bit_identical_to_the_two_wave_kernel():
+    """conv_halo64_kernel (csrc/conv_halo64.h: the VAE's 3 x 3 x 3 conv of 96-channel tiles as one wave per SIMD, generated main loop)
+    against conv_halo_kernel<3, 3, 12, 32, 3, 3> on the same inputs in child processes (the switch is read once per process) — same
+    accumulation order, the SAME epilogue source: every output (raw, + shortcut, fused RMS_norm + SiLU into planar-16, 96 / 192 / 384
+    channels, ragged right edge, planar-16 and channels-last inputs) must agree bit for bit — and against 27 shifted fp32 GEMMs."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_conv64.py")], capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert out.count("bit-identical") == 7 and "DIFFERENT" not in out and "RESULT mode 2 PASS" in out, out[-3000:]
+    assert out.count("'conv_halo64': 1") == 7, out[-3000:]
+
+
+def test_vae_residual_block_runs_on_conv_halo64():
+    """the production path takes the new kernel: a 96-channel ResidualBlock at 120 x 416 (planar-16 staging) launches conv_halo64"""
+    from more4d_amd import ops
+    T, H, W, C = 4, 120, 416, 96
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(T * H * W, C, device=DEV, generator=g).to(BF)
+    w = (torch.randn(C, 27 * C, device=DEV, generator=g) * (27 * C) ** -0.5).to(BF)
+    xp = ops.Planar16(x.view(T, H * W, C // 16, 16).permute(2, 0, 1, 3).contiguous())
+    ops.launch_counts(reset=True)
+    ops.conv_cl_planar(xp, w, None, Tin=T, Hin=H, Win=W, kt=3)
+    cnt = ops.launch_counts()
+    assert cnt["conv_halo64"] == 1 and cnt["conv_halo_mt3_12x32"] == 0, cnt
+    ops.launch_counts(reset=True)
+    ops.conv_cl(x, w, None, Tin=T, Hin=H, Win=W, Cin=C, k=(3, 3, 3), pad=(0, 1, 1), out_thw=(T - 2, H, W))     # channels-last: the 12 x 32 kernel
+    cnt = ops.launch_counts()
+    assert cnt["conv_halo64"] == 0 and cnt["conv_halo_mt3_12x32"] == 1, cnt

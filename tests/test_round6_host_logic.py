@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("gen,inc", [("gen_attn_q64.py", "attention_q64_gen.inc"), ("gen_attn_bwd64.py", "attention_bwd64_dq_gen.inc"),
-                                     ("gen_attn_bwd64_kv.py", "attention_bwd64_kv_gen.inc")])
+                                     ("gen_attn_bwd64_kv.py", "attention_bwd64_kv_gen.inc"), ("gen_conv_halo64.py", "conv_halo64_gen.inc")])
 def test_generated_streams_match_their_generators(gen, inc):
     """the committed .inc files (hashed into the library) are what the generators emit (nothing checked that), and the
     generators' --help works"""

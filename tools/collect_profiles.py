@@ -42,6 +42,9 @@ cp(f"{src}/ab_q64_bench.log", "ab_q64_bench.log")
 cp(f"{src}/q64_check_time.log", "q64_check_time.log")
 cp(f"{src}/q64_stamps.log", "q64_stamps.log")
 cp(f"{src}/launch_check_8.log", "launch_check_8.log")
+cp(f"{src}/ab_bwd64_train.log", "ab_bwd64_train.log")
+cp(f"{src}/bwd64_check_time.log", "bwd64_check_time.log")
+cp(f"{src}/ab_gemm_refetch.log", "ab_gemm_refetch.log")
 for f in glob.glob(f"{src}/vae_train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "vae_train_kernel_stats.csv")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):

@@ -42,4 +42,28 @@ rep("attention 4 segments", lambda: ops.attention(q, segs, **kw))
 kc = torch.randn(2 * 512, C, generator=g, device=dev).to(bf)
 vc = torch.randn(C, 2 * 512, generator=g, device=dev).to(bf)
 rep("attention cross", lambda: ops.attention(q, [KV(kc, vc, 512 * C, C, 512, 1024, 512)], **kw))
+# the one-wave-per-SIMD attention backward (round 6) at the training shape: B = 1, scale = ln 2 (folded)
+import math  # noqa: E402
+LN2 = math.log(2.0)
+del q, k, vt, kc, vc
+qkv = torch.randn(L, 3 * C, generator=g, device=dev)
+qkv[:, :C] *= D ** -0.5 / LN2
+qkv = qkv.to(bf)
+q1, k1, v1 = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+d_o = torch.randn(L, C, generator=g, device=dev).to(bf)
+lse = torch.empty(1, H, L, device=dev)
+o1 = ops.attention(q1, [KV(k1, ops.transpose(v1.contiguous()), L * 3 * C, 3 * C, L, L, L)], B=1, Lq=L, heads=H, head_dim=D, q_bs=L * 3 * C,
+                   q_ls=3 * C, lse=lse, scale=LN2).view(L, C)
+
+
+def bwd():
+    g3 = torch.empty_like(qkv)
+    ops.attention_bwd(q1, k1, v1, o1, d_o, lse, B=1, Lq=L, Lk=L, Lk_rows=L, heads=H, head_dim=D, dq=g3[:, :C], dk=g3[:, C:2 * C],
+                      dv=g3[:, 2 * C:], scale=LN2)
+    return g3
+
+
+ops.launch_counts(reset=True)
+rep("attention backward (dq64 + kv64)", bwd)
+assert ops.launch_counts()["attn_bwd64"] == 2 * (N + 1), ops.launch_counts()
 print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad})")
