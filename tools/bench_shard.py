@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import CFG_14B, build_model, standin_group  # noqa: E402
+from bench import CFG_14B, ClockMonitor, build_model, standin_group  # noqa: E402
 
 
 def main():
@@ -48,13 +48,17 @@ def main():
         for _ in range(args.warmup):
             model(x=x, t=t, context=cc, seq_len=Lv, y=y, full_ref=full_ref)
         torch.cuda.synchronize()
+        mon = ClockMonitor(0).start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = model(x=x, t=t, context=cc, seq_len=Lv, y=y, full_ref=full_ref)
         t_host = (time.perf_counter() - t0) / args.steps       # host time to ENQUEUE a step (must stay below the GPU time)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    mon.stop()
+    ck = mon.region()
     print(json.dumps({"world": args.world, "mode": args.mode, "sp_world": spw, "batch_per_rank": B,
+                      "effective_clock_mhz": ck.get("effective_clock_mhz"), "socket_power_w": ck.get("socket_power_w", {}).get("mean"),
                       "rank_ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": t_host * 1e3, "finite": bool(torch.isfinite(out.float()).all())}))
 
 
