@@ -129,6 +129,14 @@ int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, void* out, 
                     const float* ln_w, const float* ln_b, float eps, const float* g_ss,
                     const float* g_gate, int64_t g_period, int64_t g_len, m4d_stream stream);
 
+/* m4d_ln_modulate with the guidance table indexed independently of the modulation: g_rows = rows per GUIDANCE sample (0: rows_per_sample).
+ * Per-token timesteps (wan_transformer4d.py:655-657: one modulation vector per row, rows_per_sample = 1) together with spatial
+ * guidance (:757-783: table row = token position inside its sample) need both. */
+int m4d_ln_modulate_g(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, void* out, int64_t rows, int C,
+                      int64_t rows_per_sample, const float* shift, const float* scale, int64_t mod_stride,
+                      const float* ln_w, const float* ln_b, float eps, const float* g_ss,
+                      const float* g_gate, int64_t g_period, int64_t g_len, int64_t g_rows, m4d_stream stream);
+
 /* In-place WanRMSNorm over the full channel dim (:386-394) followed by 3-axis RoPE on adjacent pairs
  * (:340-369) for up to two tensors (q and k) in one launch.
  *   x0/x1: T [rows, C] row stride ld (x1 may be NULL); w0/w1: float [C], both NULL => RoPE only (qk_norm=False, :431-432);
@@ -393,6 +401,11 @@ int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* dy, float* 
 int m4d_guidance_bwd(const float* x, m4d_dtype dz_dt, void* dz, int B, int64_t rows_per_sample, int C, const float* shift,
                      const float* scale, int64_t mod_stride, float eps, const float* g_ss, const float* g_gate,
                      int64_t g_period, int64_t g_len, float* ab, m4d_stream stream);
+
+/* m4d_guidance_bwd with mod_rows = rows that share one (shift, scale) vector (0: rows_per_sample; 1: per-token modulation, :655-657). */
+int m4d_guidance_bwd_m(const float* x, m4d_dtype dz_dt, void* dz, int B, int64_t rows_per_sample, int C, const float* shift,
+                       const float* scale, int64_t mod_stride, int64_t mod_rows, float eps, const float* g_ss, const float* g_gate,
+                       int64_t g_period, int64_t g_len, float* ab, m4d_stream stream);
 
 /* Backward of m4d_rmsnorm_rope, in place on the gradient: dy0/dy1 T [rows, C] (row stride ld_dy) hold dL/d(output) on
  * entry and dL/d(input) on return; x0/x1 are the PRE-norm inputs (row stride ld_x); dw0/dw1 float [C] accumulate the

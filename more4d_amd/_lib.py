@@ -49,6 +49,9 @@ SIGNATURES = {
     "m4d_ln_modulate": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                 c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int64,
                                 c_void_p]),
+    "m4d_ln_modulate_g": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                  c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                  c_void_p]),
     "m4d_rmsnorm_rope": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                  c_float, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "m4d_attention": (c_int, [c_int, c_void_p, c_int64, c_int64, POINTER(KvSegs), c_void_p, c_int64, c_int64,
@@ -69,6 +72,8 @@ SIGNATURES = {
                                c_int, c_int, c_void_p]),
     "m4d_guidance_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_float,
                                  c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "m4d_guidance_bwd_m": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int64, c_float,
+                                   c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "m4d_rmsnorm_rope_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_int64,
                                      c_int64, c_int64, c_void_p]),

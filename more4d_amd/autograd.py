@@ -214,13 +214,13 @@ STORE_KEYS = ("qkv_pre", "o", "lse1", "y1", "qc_pre", "yc", "pre", "y2")
 STORE_LITE = ("o", "lse1", "y2")     # best recompute time saved per stored byte: self-attention output + ffn_down output
 
 
-def _guidance_site_bwd(x, dz, shift, scale, st, Lp, eps, g, mod, gfeat2, G, prefix):
+def _guidance_site_bwd(x, dz, shift, scale, st, Lp, eps, g, mod, gfeat2, G, prefix, mod_rows=0):
     """Gradients of one SpatialGuidanceModule application (reference :757-783) given dz = dL/d(guided LN output):
     dz becomes dL/d(plain LN-modulate output) in place; fills G[prefix.gate / .spatial_guide.1.*]; returns the gradient
     w.r.t. the SiLU'd guidance features [B*P, 768] (T)."""
     B, C = x.shape[0], x.shape[-1]
     T = gfeat2.dtype
-    ab = ops.guidance_bwd_(x, dz, B=B, rows_per_sample=Lp, shift=shift, scale=scale, mod_stride=st, eps=eps, **g).view(-1, 2 * C)
+    ab = ops.guidance_bwd_(x, dz, B=B, rows_per_sample=Lp, shift=shift, scale=scale, mod_stride=st, eps=eps, mod_rows=mod_rows, **g).view(-1, 2 * C)
     dg = ops.colsum(ab, g["g_ss"].view(-1, 2 * C))[0]                # sum (A*S | Bm*H)
     G[prefix + ".gate"] = ops.add(dg[:C].contiguous(), dg[C:].contiguous())
     dss = ops.scale_cast(ab, T, gate=torch.cat([g["g_gate"], g["g_gate"]]), gate_stride=0, rows_per_sample=ab.shape[0])
@@ -262,8 +262,6 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     # come back per row (the reductions over a sample's rows degenerate) and are summed over ALL rows for the shared `modulation`
     per_token = e0.dim() == 4
     rps, nG = (1, R) if per_token else (Lp, B)
-    if per_token and guid is not None:
-        raise NotImplementedError("spatial guidance with per-token timesteps in training")
     e = ops.add_bcast(e0, f32(blk.modulation)).view(nG, 6, C)      # shift1 scale1 gate1 shift2 scale2 gate2
     de = zeros(nG, 6, C)
     g1, g2, gfeat2 = {}, {}, None
@@ -272,6 +270,8 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
         gfeat2 = gfeat.reshape(-1, gfeat.shape[-1])
         for gd, mod in ((g1, blk.spatial_guidance_self), (g2, blk.spatial_guidance_ffn)):
             gd.update(g_ss=mod.table(gfeat, c.f32cache), g_gate=f32(mod.gate), g_period=period, g_len=glen)
+            if per_token:      # modulation per row, guidance by the row's position inside its sample (m4d_ln_modulate_g / m4d_guidance_bwd_m)
+                gd.update(g_rows=Lp)
     dres2 = dres.view(R, C) if dres is not None else None
 
     # ================= recompute (reference :659-684) =================
@@ -363,7 +363,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     dgf = None
     if g2:
         dgf = _guidance_site_bwd(x2, dxn2, e[:, 3], e[:, 4], st, Lp, eps, g2, blk.spatial_guidance_ffn, gfeat2, G,
-                                 "spatial_guidance_ffn")
+                                 "spatial_guidance_ffn", mod_rows=rps)
     ops.ln_modulate_bwd(x2, dxn2, dres, B=nG, rows_per_sample=rps, scale=e[:, 4], mod_stride=st, eps=eps,
                         dshift=de[:, 3], dscale=de[:, 4], red_stride=st)
     # ---- cross attention: x2 = x1 + yc
@@ -423,7 +423,7 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
         G[f"self_attn.{nm}.bias"] = dbqkv[j * C:(j + 1) * C]
     if g1:
         dgf = ops.add(dgf, _guidance_site_bwd(x0, dxn1, e[:, 0], e[:, 1], st, Lp, eps, g1, blk.spatial_guidance_self, gfeat2,
-                                              G, "spatial_guidance_self"))
+                                              G, "spatial_guidance_self", mod_rows=rps))
     ops.ln_modulate_bwd(x0, dxn1, dres, B=nG, rows_per_sample=rps, scale=e[:, 1], mod_stride=st, eps=eps,
                         dshift=de[:, 0], dscale=de[:, 1], red_stride=st)
     G["modulation"] = ops.colsum(de.view(nG, 6 * C))[0].view(1, 6, C)

@@ -14,7 +14,7 @@ namespace {
 struct LnArgs {
     const void* x; void* out;
     const float *shift, *scale, *ln_w, *ln_b, *g_ss, *g_gate;
-    int64_t rows, rows_per_sample, mod_stride, g_period, g_len;
+    int64_t rows, rows_per_sample, mod_stride, g_period, g_len, g_rows;      // g_rows: rows per guidance sample (the modulation may be per row)
     int C; float eps;
 };
 
@@ -53,7 +53,11 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs p) {
     const float* sh = p.shift ? p.shift + sample * p.mod_stride : nullptr;
     const float* sc = p.scale ? p.scale + sample * p.mod_stride : nullptr;
     const float* gs = nullptr;
-    if (p.g_ss && l < p.g_len) gs = p.g_ss + (sample * p.g_period + l % p.g_period) * 2 * C;
+    if (p.g_ss) {      // guidance table row: by the row's position inside its GUIDANCE sample (g_rows rows; == rows_per_sample unless the
+        const int64_t gsample = row / p.g_rows, gl = row % p.g_rows;      // modulation is per token, wan_transformer4d.py:655-657 with :757-783)
+        if (gl < p.g_len) gs = p.g_ss + (gsample * p.g_period + gl % p.g_period) * 2 * C;
+    }
+    (void)l;
     TO* orow = (TO*)p.out + row * C;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -570,6 +574,14 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
                                int64_t rows_per_sample, const float* shift, const float* scale, int64_t mod_stride,
                                const float* ln_w, const float* ln_b, float eps, const float* g_ss,
                                const float* g_gate, int64_t g_period, int64_t g_len, m4d_stream stream) {
+    return m4d_ln_modulate_g(x_dt, x, out_dt, out, rows, C, rows_per_sample, shift, scale, mod_stride, ln_w, ln_b, eps, g_ss, g_gate, g_period,
+                             g_len, 0, stream);
+}
+
+extern "C" int m4d_ln_modulate_g(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, void* out, int64_t rows, int C,
+                                 int64_t rows_per_sample, const float* shift, const float* scale, int64_t mod_stride,
+                                 const float* ln_w, const float* ln_b, float eps, const float* g_ss,
+                                 const float* g_gate, int64_t g_period, int64_t g_len, int64_t g_rows, m4d_stream stream) {
     M4D_CHECK_ARG(x && out && rows > 0, "ln_modulate: null/empty");
     M4D_CHECK_ARG(C % 4 == 0 && C > 0 && C <= 8192, "ln_modulate: C=%d must be a multiple of 4 and <= 8192", C);
     M4D_CHECK_ARG((shift == nullptr) == (scale == nullptr), "ln_modulate: shift and scale must both be set or both NULL");
@@ -579,6 +591,7 @@ extern "C" int m4d_ln_modulate(m4d_dtype x_dt, const void* x, m4d_dtype out_dt, 
     p.x = x; p.out = out; p.shift = shift; p.scale = scale; p.ln_w = ln_w; p.ln_b = ln_b; p.g_ss = g_ss; p.g_gate = g_gate;
     p.rows = rows; p.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : rows; p.mod_stride = mod_stride;
     p.g_period = g_period > 0 ? g_period : 1; p.g_len = g_len; p.C = C; p.eps = eps;
+    p.g_rows = g_rows > 0 ? g_rows : p.rows_per_sample;
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256), grid((unsigned)((rows + 3) / 4));
     // LDS-staged, persistent form: exactly one of (scale, shift) / (ln_w, ln_b), no guidance terms, blocks of 4 rows inside one sample

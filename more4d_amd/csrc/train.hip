@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void ln_bwd_kernel(LnBwdArgs p) {
 // One workgroup per (position, sample): it owns every row of its position, so no atomics.
 struct GuidBwdArgs {
     const float* x; void* dz; const float *shift, *scale, *ss, *gate; float* ab;
-    int64_t rows_per_sample, mod_stride, period, glen;
+    int64_t rows_per_sample, mod_stride, period, glen, mod_rows;      // mod_rows: rows that share one (shift, scale) vector
     int C; float eps;
 };
 
@@ -352,8 +352,6 @@ __global__ __launch_bounds__(256) void guid_bwd_kernel(GuidBwdArgs p) {
     const int tid = threadIdx.x;
     const int64_t pos = blockIdx.x, sample = blockIdx.y;
     const int C = p.C, nv = C >> 2;
-    const float* sh = p.shift + sample * p.mod_stride;
-    const float* sc = p.scale + sample * p.mod_stride;
     const float* ssr = p.ss + (sample * p.period + pos) * 2 * C;
     f32x4 A[MAXV], Bm[MAXV], m[MAXV];
 #pragma unroll
@@ -364,6 +362,8 @@ __global__ __launch_bounds__(256) void guid_bwd_kernel(GuidBwdArgs p) {
     }
     for (int64_t l = pos; l < p.glen; l += p.period) {
         const int64_t row = sample * p.rows_per_sample + l;
+        const float* sh = p.shift + (row / p.mod_rows) * p.mod_stride;      // (per sample, or per token: mod_rows == 1)
+        const float* sc = p.scale + (row / p.mod_rows) * p.mod_stride;
         const float* xr = p.x + row * C;
         TD* dr = (TD*)p.dz + row * C;
         f32x4 v[MAXV], g[MAXV];
@@ -727,11 +727,17 @@ extern "C" int m4d_ln_modulate_bwd(const float* x, m4d_dtype dy_dt, const void* 
 extern "C" int m4d_guidance_bwd(const float* x, m4d_dtype dz_dt, void* dz, int B, int64_t rows_per_sample, int C,
                                 const float* shift, const float* scale, int64_t mod_stride, float eps, const float* g_ss,
                                 const float* g_gate, int64_t g_period, int64_t g_len, float* ab, m4d_stream stream) {
+    return m4d_guidance_bwd_m(x, dz_dt, dz, B, rows_per_sample, C, shift, scale, mod_stride, 0, eps, g_ss, g_gate, g_period, g_len, ab, stream);
+}
+
+extern "C" int m4d_guidance_bwd_m(const float* x, m4d_dtype dz_dt, void* dz, int B, int64_t rows_per_sample, int C,
+                                  const float* shift, const float* scale, int64_t mod_stride, int64_t mod_rows, float eps, const float* g_ss,
+                                  const float* g_gate, int64_t g_period, int64_t g_len, float* ab, m4d_stream stream) {
     M4D_CHECK_ARG(DT_OK(dz_dt), "guidance_bwd: bad dtype");
     M4D_CHECK_ARG(x && dz && shift && scale && g_ss && g_gate && ab && B > 0 && rows_per_sample > 0, "guidance_bwd: bad arguments");
     M4D_CHECK_ARG(C % 4 == 0 && C <= 8192, "guidance_bwd: C=%d must be a multiple of 4 and <= 8192", C);
     M4D_CHECK_ARG(g_period > 0 && g_len >= 0 && g_len <= rows_per_sample, "guidance_bwd: bad period / length");
-    GuidBwdArgs p{x, dz, shift, scale, g_ss, g_gate, ab, rows_per_sample, mod_stride, g_period, g_len, C, eps};
+    GuidBwdArgs p{x, dz, shift, scale, g_ss, g_gate, ab, rows_per_sample, mod_stride, g_period, g_len, mod_rows > 0 ? mod_rows : rows_per_sample, C, eps};
     dim3 grid((unsigned)g_period, (unsigned)B), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define GDB(TD, MV) hipLaunchKernelGGL((guid_bwd_kernel<TD, MV>), grid, block, 0, st, p)

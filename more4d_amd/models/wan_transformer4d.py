@@ -418,20 +418,6 @@ class SpatialGuidanceModule(nn.Module):
         return ops.gemm_bt(feats_silu.reshape(B * P, D), lin.weight, lin.bias, epilogue=EPI_STORE_F32).view(B, P, -1)
 
 
-def _fold_guidance(e, i_scale, i_shift, g, B, Lp, C):
-    """Per-token table e [B*Lp, 6, C] (in place): scale <- (1 + scale)(1 + gs gate) - 1, shift <- shift (1 + gs gate) + gh gate for
-    the guided tokens l < g_len, gs | gh = row (l % period) of the guidance table (SpatialGuidanceModule, reference :769-781)."""
-    period, glen = int(g["g_period"]), int(g["g_len"])
-    if glen <= 0:
-        return
-    idx = torch.arange(glen, device=e.device) % period
-    tab = g["g_ss"].view(B, -1, 2 * C)[:, idx] * g["g_gate"].repeat(2)                    # [B, glen, 2C]
-    ev = e.view(B, Lp, 6, C)
-    m = 1.0 + tab[..., :C]
-    ev[:, :glen, i_shift] = ev[:, :glen, i_shift] * m + tab[..., C:]
-    ev[:, :glen, i_scale] = (1.0 + ev[:, :glen, i_scale]) * m - 1.0
-
-
 class WanAttentionBlock(nn.Module):
     def __init__(self, cross_attn_type, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True,
                  cross_attn_norm=False, eps=1e-6, use_spatial_guidance=True):
@@ -473,13 +459,9 @@ class WanAttentionBlock(nn.Module):
             g2 = dict(g_ss=self.spatial_guidance_ffn.table(feats_silu, c.f32cache),
                       g_gate=_f32(self.spatial_guidance_ffn.gate, c.f32cache), g_period=period, g_len=glen)
             if per_token:
-                # guidance on top of a per-token modulation: the guided result (LN (1 + sc) + sh) (1 + gs g) + gh g (:781) is
-                # again ONE scale / shift pair per token — fold it into the table (the kernel's guidance index is
-                # row % rows_per_sample, which per-token calls use for the modulation)
-                e = e.clone()
-                _fold_guidance(e, 1, 0, g1, B, Lp, C)
-                _fold_guidance(e, 4, 3, g2, B, Lp, C)
-                g1, g2 = dict(g_ss=None), dict(g_ss=None)
+                # guidance on top of a per-token modulation: the modulation vectors are indexed per row (rows_per_sample = 1), the guidance
+                # table by the row's position inside its sample (g_rows = Lp) — m4d_ln_modulate_g
+                g1["g_rows"] = g2["g_rows"] = Lp
         # self-attention (:662-669)
         xn = ops.ln_modulate(xres, T, shift=e[:, 0], scale=e[:, 1], mod_stride=st, rows_per_sample=rps, eps=self.eps,
                              **g1)
@@ -966,8 +948,6 @@ class WanTransformer4DModel(nn.Module):
             raise NotImplementedError("TeaCache is an inference-time approximation")
         if isinstance(context, ContextCache):
             raise ValueError("training needs the raw text embeddings (the context projections are trainable)")
-        if t.dim() != 1 and self.use_omnimae_guidance and first_frame_features is not None:
-            raise NotImplementedError("spatial guidance with per-token timesteps in training")
         T, dev, C = self.dtype, self.device, self.dim
         f32 = torch.float32
         B = x.shape[0]

@@ -189,8 +189,9 @@ def _gemm_bt_packed(a, w, bias, *, out, epilogue, gate, gate_stride, rows_per_sa
 
 
 def ln_modulate(x, out_dtype, *, shift=None, scale=None, mod_stride=0, rows_per_sample=0, ln_w=None, ln_b=None,
-                eps=1e-6, g_ss=None, g_gate=None, g_period=0, g_len=0, out=None):
-    """LayerNorm over the last dim (+affine) (+modulate) (+spatial guidance) -> out_dtype, same shape."""
+                eps=1e-6, g_ss=None, g_gate=None, g_period=0, g_len=0, g_rows=0, out=None):
+    """LayerNorm over the last dim (+affine) (+modulate) (+spatial guidance) -> out_dtype, same shape.  g_rows: rows per guidance
+    sample when it differs from rows_per_sample (per-token modulation: rows_per_sample = 1, g_rows = tokens per sample)."""
     _dev(x, shift, scale, ln_w, ln_b, g_ss, g_gate, out)
     if not x.is_contiguous():
         raise ValueError("ln_modulate: x must be contiguous")
@@ -202,9 +203,9 @@ def ln_modulate(x, out_dtype, *, shift=None, scale=None, mod_stride=0, rows_per_
         if t is not None and t.dtype != torch.float32:
             raise TypeError("ln_modulate: modulation / affine / guidance tensors must be float32")
     lib = _lib.load()
-    check(lib.m4d_ln_modulate(dt_code(x.dtype), _ptr(x), dt_code(out.dtype), _ptr(out), rows, C, rows_per_sample,
-                              _ptr(shift), _ptr(scale), mod_stride, _ptr(ln_w), _ptr(ln_b), eps, _ptr(g_ss),
-                              _ptr(g_gate), g_period, g_len, _stream()), "m4d_ln_modulate")
+    check(lib.m4d_ln_modulate_g(dt_code(x.dtype), _ptr(x), dt_code(out.dtype), _ptr(out), rows, C, rows_per_sample,
+                                _ptr(shift), _ptr(scale), mod_stride, _ptr(ln_w), _ptr(ln_b), eps, _ptr(g_ss),
+                                _ptr(g_gate), g_period, g_len, g_rows, _stream()), "m4d_ln_modulate_g")
     return out
 
 
@@ -902,7 +903,7 @@ def act_bwd_(dy, pre, act):
     return dy
 
 
-def guidance_bwd_(x, dz, *, B, rows_per_sample, shift, scale, mod_stride, g_ss, g_gate, g_period, g_len, eps=1e-6):
+def guidance_bwd_(x, dz, *, B, rows_per_sample, shift, scale, mod_stride, g_ss, g_gate, g_period, g_len, eps=1e-6, mod_rows=0, g_rows=0):
     """Spatial-guidance tail of ln_modulate, backward: dz (T, in place) becomes the gradient w.r.t. the un-guided
     LN-modulate output; returns float32 [B, g_period, 2C] = (sum_f dz*u | sum_f dz) per spatial position."""
     _dev(x, dz, shift, scale, g_ss, g_gate)
@@ -910,9 +911,9 @@ def guidance_bwd_(x, dz, *, B, rows_per_sample, shift, scale, mod_stride, g_ss, 
     if not dz.is_contiguous() or not x.is_contiguous():
         raise ValueError("guidance_bwd_: contiguous tensors")
     ab = torch.empty((B, g_period, 2 * C), device=x.device, dtype=torch.float32)
-    check(_lib.load().m4d_guidance_bwd(_ptr(x), dt_code(dz.dtype), _ptr(dz), B, rows_per_sample, C, _ptr(shift), _ptr(scale),
-                                       mod_stride, eps, _ptr(g_ss), _ptr(g_gate), g_period, g_len, _ptr(ab), _stream()),
-          "m4d_guidance_bwd")
+    check(_lib.load().m4d_guidance_bwd_m(_ptr(x), dt_code(dz.dtype), _ptr(dz), B, rows_per_sample, C, _ptr(shift), _ptr(scale),
+                                         mod_stride, mod_rows, eps, _ptr(g_ss), _ptr(g_gate), g_period, g_len, _ptr(ab), _stream()),
+          "m4d_guidance_bwd_m")
     return ab
 
 

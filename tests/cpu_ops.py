@@ -69,7 +69,7 @@ def _strided_rows(t, B, stride, C):
 
 
 def ln_modulate(x, out_dtype, *, shift=None, scale=None, mod_stride=0, rows_per_sample=0, ln_w=None, ln_b=None,
-                eps=1e-6, g_ss=None, g_gate=None, g_period=0, g_len=0, out=None):
+                eps=1e-6, g_ss=None, g_gate=None, g_period=0, g_len=0, g_rows=0, out=None):
     C = x.shape[-1]
     rows = x.numel() // C
     rps = rows_per_sample or rows
@@ -81,10 +81,13 @@ def ln_modulate(x, out_dtype, *, shift=None, scale=None, mod_stride=0, rows_per_
         y = y * ln_w + ln_b
     if scale is not None:
         y = y * (1 + _strided_rows(scale, B, mod_stride, C)[:, None]) + _strided_rows(shift, B, mod_stride, C)[:, None]
-    if g_ss is not None:
-        sc = torch.zeros(B, rps, C)
-        sh = torch.zeros(B, rps, C)
-        n = min(g_len, rps)
+    if g_ss is not None:      # guidance samples of g_rows rows (default: the modulation's rows_per_sample)
+        gr = g_rows or rps
+        Bg = rows // gr
+        y = y.reshape(Bg, gr, C)
+        sc = torch.zeros(Bg, gr, C)
+        sh = torch.zeros(Bg, gr, C)
+        n = min(g_len, gr)
         idx = torch.arange(n) % g_period
         sc[:, :n] = g_ss[:, idx, :C]
         sh[:, :n] = g_ss[:, idx, C:]
@@ -493,13 +496,15 @@ def ln_modulate_bwd(x, dy, dx, *, B, rows_per_sample, scale=None, mod_stride=0, 
     return dx
 
 
-def guidance_bwd_(x, dz, *, B, rows_per_sample, shift, scale, mod_stride, g_ss, g_gate, g_period, g_len, eps=1e-6):
+def guidance_bwd_(x, dz, *, B, rows_per_sample, shift, scale, mod_stride, g_ss, g_gate, g_period, g_len, eps=1e-6, mod_rows=0, g_rows=0):
     C = x.shape[-1]
     rps = rows_per_sample
     xf = x.reshape(B, rps, C).float()
     mu = xf.mean(-1, keepdim=True)
     xh = (xf - mu) * torch.rsqrt((xf - mu).pow(2).mean(-1, keepdim=True) + eps)
-    u = xh * (1 + _strided_rows(scale, B, mod_stride, C)[:, None]) + _strided_rows(shift, B, mod_stride, C)[:, None]
+    mr = mod_rows or rps      # rows that share one (shift, scale) vector
+    nm = B * rps // mr
+    u = (xh.reshape(nm, mr, C) * (1 + _strided_rows(scale, nm, mod_stride, C)[:, None]) + _strided_rows(shift, nm, mod_stride, C)[:, None]).reshape(B, rps, C)
     g = dz.reshape(B, rps, C).float()
     n = min(g_len, rps)
     idx = torch.arange(n) % g_period

@@ -117,8 +117,9 @@ def make_dit_grads(ref):
     npz_save("dit_tiny_grads.npz", **out)
 
 
-def make_dit_guid_grads(ref):
-    """Guided training step (train_wan.sh: --use_omnimae_guidance; train_wan.py:1939-1951 passes first_frame): the reference
+def make_dit_guid_grads(ref, t_override=None, out_name="dit_tiny_guid_grads.npz"):
+    """(t_override / out_name: tests/golden/make_golden_r6.py re-runs this with PER-TOKEN timesteps)
+    Guided training step (train_wan.sh: --use_omnimae_guidance; train_wan.py:1939-1951 passes first_frame): the reference
     forward + backward with spatial guidance on.  The OmniMAE ViT-B (needs timm/hydra, frozen, train_wan.py:952) and
     torchvision's Normalize are absent here: a stand-in extractor returns the seeded synthetic patch / cls features stored in
     the fixture (the product takes exactly those through first_frame_features), Normalize is restated ((x-mean)/std).
@@ -172,8 +173,8 @@ def make_dit_guid_grads(ref):
             p_.requires_grad_("omnimae_extractor" not in n_)
         target = torch.randn(z["out_ref"].shape, generator=torch.Generator().manual_seed(22))
         first_frame = torch.rand(B, 3, 224, 224, generator=g)
-        pred = m(x=z["x"], t=z["t"], context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]), clip_fea=z["clip"],
-                 y=z["y"], full_ref=z["full_ref"], first_frame=first_frame)
+        pred = m(x=z["x"], t=z["t"] if t_override is None else t_override, context=[z["ctx0"], z["ctx1"]], seq_len=int(z["seq_len_pad"]),
+                 clip_fea=z["clip"], y=z["y"], full_ref=z["full_ref"], first_frame=first_frame)
         diff = pred.float() - target
         loss = (torch.nn.functional.mse_loss(pred.float(), target, reduction="none") * (diff.abs() <= 50).float()).mean()
         loss.backward()
@@ -187,7 +188,7 @@ def make_dit_guid_grads(ref):
     print("guided params with grad:", sum(1 for k in out if k.startswith("norm/")),
           "gate grad norm", float(out["norm/blocks.0.spatial_guidance_self.gate"]),
           "adapter grad norm", float(out["norm/feature_adapter.0.weight"]))
-    npz_save("dit_tiny_guid_grads.npz", **out)
+    npz_save(out_name, **out)
 
 
 def _load_reference_omnimae():

@@ -1,6 +1,6 @@
 """Round-6 fixtures, produced by RUNNING THE REFERENCE in the build container (needs /root/reference):
 
-    python tests/golden/make_golden_r6.py [subject_ref|all]
+    python tests/golden/make_golden_r6.py [subject_ref|guid_pertoken|all]
 
 * dit_tiny_subject_ref.npz — the `subject_ref` branch of WanTransformer4DModel.forward (wan_transformer4d.py:1092-1097, 1328-1331): extra
   frames that go through `patch_embedding`, are appended BEHIND the video tokens (RoPE frame index continues) and are cut off after the
@@ -8,6 +8,9 @@
   Reference quirk recorded by this fixture: `subject_ref_length = subject_ref[0].size(1)` (:1329) is the model WIDTH (subject_ref is
   [B, Ls, dim] there), so the reference cuts `dim` tokens; unpatchify then takes the first prod(grid) tokens, which makes the result right
   whenever at least `dim` tokens follow the video tokens — true here (128 subject tokens, dim = 128).
+* dit_tiny_guid_pertoken_grads.npz — spatial guidance (:757-783) TOGETHER with per-token timesteps (:655-657, t [B, seq_len]) in training:
+  make_golden.py:make_dit_guid_grads (the reference's forward + backward with the stand-in feature extractor) re-run with the t_tok of
+  dit_tiny_pertoken.npz; prediction, loss, norms + sampled values of every gradient.
 Data only; no reference source is stored."""
 import os
 import sys
@@ -41,8 +44,20 @@ def make_subject_ref(ref):
              out_noref=out_noref)
 
 
+def make_guid_pertoken(ref):
+    from make_golden import make_dit_guid_grads
+    t_tok = torch.from_numpy(np.load(os.path.join(HERE, "dit_tiny_pertoken.npz"))["t_tok"])
+    torch.set_grad_enabled(True)
+    try:
+        make_dit_guid_grads(ref, t_override=t_tok, out_name="dit_tiny_guid_pertoken_grads.npz")
+    finally:
+        torch.set_grad_enabled(False)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     ref = _ref_import.load_reference()
     if what in ("subject_ref", "all"):
         make_subject_ref(ref)
+    if what in ("guid_pertoken", "all"):
+        make_guid_pertoken(ref)

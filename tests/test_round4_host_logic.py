@@ -86,28 +86,6 @@ def test_block_without_qk_norm_host_logic(monkeypatch):
     assert rel_err(out, z["out"]) < 1e-4
 
 
-def test_per_token_modulation_with_guidance_folds_into_one_table():
-    """_fold_guidance: (LN (1 + sc) + sh)(1 + gs g) + gh g == LN (1 + sc') + sh' with the folded per-token table."""
-    from more4d_amd.models.wan_transformer4d import _fold_guidance
-    g = torch.Generator().manual_seed(0)
-    B, Lp, C, P = 2, 12, 8, 4
-    e = torch.randn(B * Lp, 6, C, generator=g)
-    gss = torch.randn(B, P, 2 * C, generator=g)
-    gate = torch.randn(C, generator=g)
-    ln = torch.randn(B, Lp, C, generator=g)
-    glen = 10
-    ev = e.view(B, Lp, 6, C)
-    want = ln * (1 + ev[:, :, 1]) + ev[:, :, 0]
-    idx = torch.arange(glen) % P
-    want[:, :glen] = want[:, :glen] * (1 + gss[:, idx, :C] * gate) + gss[:, idx, C:] * gate
-    e2 = e.clone()
-    _fold_guidance(e2, 1, 0, dict(g_ss=gss, g_gate=gate, g_period=P, g_len=glen), B, Lp, C)
-    e2v = e2.view(B, Lp, 6, C)
-    got = ln * (1 + e2v[:, :, 1]) + e2v[:, :, 0]
-    assert torch.allclose(got, want, atol=1e-5)
-    assert torch.equal(e2v[:, :, 2:], ev[:, :, 2:])
-
-
 def test_pipeline_preprocess_resizes_like_the_published_image_processor():
     """VaeImageProcessor.preprocess for tensors (diffusers, third-party: restated): target rounded down to a multiple of 8,
     F.interpolate's default (legacy nearest), [0, 1] -> [-1, 1] unless the tensor already holds negative values."""

@@ -90,6 +90,10 @@ def test_stack_of_forty_14b_blocks_vs_reference(dtype):
             assert g["delta_norm"] <= bf16_budget("stack40_14b", f"depth{d}", "delta_norm"), (d, g)
         for k in ("delta_max", "delta_rms", "out_rms"):
             assert got[40][k] <= bf16_budget("stack40_14b", "depth40", k), (k, got[40][k], bf16_budget("stack40_14b", "depth40", k))
+        # the number the north_star's "1e-3" cannot be asked of: how far the PRODUCTION bf16 kernels (gemm_bt256w,
+        # attn128q) sit from the reference's fp32 output after forty layers, next to the budget = 1.5 x the reference's own bf16-autocast error
+        print("depth40 distance of the production bf16 path from the reference fp32 output: " +
+              ", ".join(f"{k} {got[40][k]:.3e} (budget {bf16_budget('stack40_14b', 'depth40', k):.3e})" for k in ("delta_max", "delta_rms", "out_rms")))
 
 
 def _attn_case(B, n, Lq, Lk, spikes, seed=0):

@@ -45,6 +45,10 @@ cp(f"{src}/launch_check_8.log", "launch_check_8.log")
 cp(f"{src}/ab_bwd64_train.log", "ab_bwd64_train.log")
 cp(f"{src}/bwd64_check_time.log", "bwd64_check_time.log")
 cp(f"{src}/ab_gemm_refetch.log", "ab_gemm_refetch.log")
+cp(f"{src}/bwd64_pmc_summary.md", "bwd64_pmc_summary.md")
+cp(f"{src}/depth40_distance.log", "depth40_distance.log")
+cp(f"{src}/conv64_check_time.log", "conv64_check_time.log")
+cp(f"{src}/ab_gemm_tail.log", "ab_gemm_tail.log")
 for f in glob.glob(f"{src}/vae_train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "vae_train_kernel_stats.csv")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):

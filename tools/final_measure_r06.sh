@@ -19,7 +19,14 @@ bash tools/prof.sh > $O/prof.log 2>&1
 bash tools/prof_vae.sh > $O/prof_vae.log 2>&1
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_ks -o p -- python $R/tools/bench_train.py --layers 4 --steps 2 --warmup 1 > $O/train_ks.log 2>&1)
-find $O -name "*kernel_trace.csv" -size +5M -delete
+# MFMA-busy counters of the backward kernels (new and old) and of the VAE's conv kernels, each in its own PMC pass
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_bwd64 -o p -- python $R/tools/check_bwd64.py --child 3 time > $O/pmc_bwd64.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_bwd0 -o p -- python $R/tools/check_bwd64.py --child 0 time > $O/pmc_bwd0.log 2>&1)
+{ echo "# one-wave-per-SIMD backward (M4D_ATTN_BWD64=3)"; python tools/pmc_busy.py $(find $O/pmc_bwd64 -name "*counter_collection.csv") attn_bwd_kv64 attn_bwd_dq64 attn128q attn_delta; echo; echo "# two-waves-per-SIMD backward (M4D_ATTN_BWD64=0)"; python tools/pmc_busy.py $(find $O/pmc_bwd0 -name "*counter_collection.csv") attn_bwd_kvp attn_bwd_dqp attn128q; } > $O/bwd64_pmc_summary.md 2>&1; cat $O/bwd64_pmc_summary.md
+timeout 300 python -m pytest tests/test_round5_gpu.py -q -s -k "forty" 2>&1 | grep -E "stack40|depth40|passed|failed" > $O/depth40_distance.log; cat $O/depth40_distance.log
+timeout 600 python tools/check_conv64.py --time > $O/conv64_check_time.log 2>&1; grep "^mode\|RESULT\|bit-identical\|DIFFERENT" $O/conv64_check_time.log | tail -20
+timeout 600 python tools/ab_gemm_tail.py 2>&1 | grep -v amdgpu.ids > $O/ab_gemm_tail.log; tail -15 $O/ab_gemm_tail.log
+find $O -name "*kernel_trace.csv" -size +5M -delete; find $O -name "*counter_collection.csv" -size +5M -delete
 for m in cfg-sp sp; do for w in 2 4 8; do timeout 400 python tools/bench_shard.py --world $w --mode $m --steps 2 2>&1 | tail -1; done; done > $O/bench_shard.log 2>&1
 M4D_SP_MODE=ulysses timeout 400 python tools/bench_shard.py --world 8 --mode cfg-sp --steps 2 2>&1 | tail -1 >> $O/bench_shard.log; cat $O/bench_shard.log
 for p in cfg-sp sp; do timeout 300 python bench.py --gpus 8 --launch-check --parallelism $p 2>&1 | tail -1; done > $O/launch_check_8.log 2>&1; cat $O/launch_check_8.log | cut -c1-300
