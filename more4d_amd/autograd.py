@@ -434,6 +434,11 @@ def block_backward(blk, x0, e0, c, txt, txt_len, img, img_len, dres, saved=None,
     return de, dctx.get("txt"), dctx.get("img"), G
 
 
+def _folds_qscale(blk):
+    from .models.wan_transformer4d import _FOLD_QSCALE
+    return bool(_FOLD_QSCALE and blk.self_attn.qk_norm)
+
+
 class BlockFn(Function):
     """WanAttentionBlock on the tape.  apply(x, e0, txt, img, gfeat, blk, c, txt_len, img_len, store, gmeta, *params);
     gfeat = SiLU'd spatial-guidance features T [B, P, 768] (None without guidance), gmeta = (period, length).
@@ -457,6 +462,12 @@ class BlockFn(Function):
                                         guid=guid)
             if store == 1:
                 stash = {k: stash[k] for k in STORE_LITE}
+        elif blk.ffn[0].weight.dtype == torch.bfloat16 and not _folds_qscale(blk):
+            # bf16 without the folded softmax scale (qk_norm=False, or M4D_FOLD_QSCALE=0): blk.run's self-attention would take attn128q_kernel,
+            # which rounds Q * c to bf16 once more, while the backward's recompute (log-sum-exp requested) runs on attn128p_kernel — the loss
+            # would come from other bits than the ones the gradient is taken of.  Same code path as the recompute instead.
+            out, _ = block_backward(blk, x.detach(), e0.detach().contiguous(), c, txt.detach(), txt_len,
+                                    img.detach() if img is not None else None, img_len, None, forward_only=True, guid=guid)
         else:
             out = x.detach().clone()
             cc = ContextCache()

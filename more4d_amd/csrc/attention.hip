@@ -589,8 +589,10 @@ int launch(const AttnArgs& p, int D, hipStream_t st) {
         int q64_tiles = 0, q64_rag = 0;      // full 64-key tiles of all segments / segments with a ragged tail
         for (int i = 0; i < p.kv.nseg; ++i)
             if (p.kv.len[i] > 0) { q64_tiles += (int)(p.kv.len[i] / 64); q64_rag += (p.kv.len[i] % 64) != 0; }
-        if (w8 && q64_mode && same_strides && !p.kv.new_softmax && !p.accumulate && q64_tiles >= 4 && q64_rag <= 5 && (folded || !p.lse) &&
-            p.kv.k_ls[0] < (1 << 20) && p.kv.vt_ls[0] < (1 << 23) && p.q_ls < (1 << 20) && p.o_ls < (1 << 20)) {
+        // (the A/B switches of the older kernels keep their meaning: M4D_ATTN_LOCKSTEP=1 / M4D_ATTN_WIDE=1 select those kernels — ADVICE r5)
+        M4D_ENV_ONCE(wide_req, "M4D_ATTN_WIDE", 0);
+        if (w8 && q64_mode && !force_lockstep && !wide_req && same_strides && !p.kv.new_softmax && !p.accumulate && q64_tiles >= 4 && q64_rag <= 5 &&
+            (folded || !p.lse) && p.kv.k_ls[0] < (1 << 20) && p.kv.vt_ls[0] < (1 << 23) && p.q_ls < (1 << 20) && p.o_ls < (1 << 20)) {
             static PerDeviceOnce configured_q;
             if (configured_q.pending()) {
                 if (hipFuncSetAttribute((const void*)attn128q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768) != hipSuccess) return -3;

@@ -87,17 +87,21 @@ M4D_DEV float rms_scale_f(float root_c, float ss) { return root_c * __builtin_am
 // Environment switches are read ONCE per process (M4D_ENV_ONCE).  Timing ablations (M4D_*_ABL: kernels that skip work,
 // run faster and return WRONG results) exist only in tool builds: `python -m more4d_amd.build --ablations` compiles with
 // -DM4D_ABLATIONS into lib/libmore4d_hip_abl.so; in the shipping library M4D_ABL() is the constant 0, the branches fold
-// "Done once" state that HIP keeps PER DEVICE (hipFuncSetAttribute: the dynamic-LDS opt-in of a kernel): a process may drive several GPUs,
-// so the launchers' first-use blocks are keyed by the current device, not by a process-wide bool.
-struct PerDeviceOnce {
-    bool done[32] = {};
-    static int dev() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
-    bool pending() const { const int d = dev(); return d < 0 || d >= 32 || !done[d]; }
-    void mark() { const int d = dev(); if (d >= 0 && d < 32) done[d] = true; }
-};
-
 // away and the environment variables are never read.
 #include <stdlib.h>
+// "Done once" state that HIP keeps PER DEVICE (hipFuncSetAttribute: the dynamic-LDS opt-in of a kernel): a process may drive several GPUs,
+// so the launchers' first-use blocks are keyed by the current device, not by a process-wide bool.  Relaxed atomics: host
+// threads may launch concurrently (a flag seen late only repeats the idempotent hipFuncSetAttribute); devices beyond the table repeat it
+// on every launch (correct, slower).
+#include <atomic>
+struct PerDeviceOnce {
+    static constexpr int N = 64;
+    std::atomic<bool> done[N] = {};
+    static int dev() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
+    bool pending() const { const int d = dev(); return d < 0 || d >= N || !done[d].load(std::memory_order_relaxed); }
+    void mark() { const int d = dev(); if (d >= 0 && d < N) done[d].store(true, std::memory_order_relaxed); }
+};
+
 #define M4D_ENV_ONCE(var, name, dflt)                      \
     static int var = -0x7fffffff;                          \
     if (var == -0x7fffffff) {                              \
