@@ -93,6 +93,19 @@ _FOLD_QSCALE = os.environ.get("M4D_FOLD_QSCALE", "1") != "0"
 # T-sharded self-attention, A/B (tools/bench_shard.py): M4D_SP_PER_SEGMENT=1 = the gathered remote shards one call per shard + LSE merges
 # instead of one multi-segment call (attn128q_kernel takes up to 8 segments with up to 5 ragged tails itself, so this is off)
 _SP_PER_SEGMENT = os.environ.get("M4D_SP_PER_SEGMENT", "0") != "0"
+# M4D_SP_OVERLAP=1: the remote shards' attention calls beside the local call on a second stream (default: behind it; same-box A/B
+# profiles/r06_ab_sp_overlap.log: same bits, 1 % slower — the two launches' partial rounds do not fill each other)
+_SP_OVERLAP = os.environ.get("M4D_SP_OVERLAP", "0") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for the remote-shard attention calls of the T-sharded path."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _folded_norm_weight(p, head_dim, cache):
@@ -245,10 +258,22 @@ class WanSelfAttention(nn.Module):
                 n_loc = max(0, min(Lp, c.key_len - r * Lp))
                 kw = dict(B=B, Lq=Lp, heads=n, head_dim=d, q_bs=Lp * C, q_ls=C, **sm)
                 o = None
+                side, parts = None, []
+                if _SP_OVERLAP and q.is_cuda and n_loc > 0 and not (_SP_PER_SEGMENT and sm):
+                    # the gathered shards are attended on a second HIP stream: that stream (not this one) waits for the collectives,
+                    # and its calls overlap the local call below
+                    side = _side_stream(q.device)
+                    side.wait_stream(torch.cuda.current_stream())                      # q, k, V^T are ready
+                    with torch.cuda.stream(side):
+                        rem = [s for i, s in enumerate(c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)) if i != r and s.len > 0]
+                        for chunk in _ragged_chunks(rem, 5 if sm else len(rem)):
+                            lse_r = torch.empty((B, n, Lp), device=q.device, dtype=torch.float32)
+                            parts.append((ops.attention(q, chunk, lse=lse_r, **kw), lse_r))
                 if n_loc > 0:
                     lse = torch.empty((B, n, Lp), device=q.device, dtype=torch.float32)
                     o = ops.attention(q, [KV(k, vt, Lp * C, C, Lp, B * Lp, n_loc)], lse=lse, **kw)
-                rem = [s for i, s in enumerate(c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)) if i != r and s.len > 0]
+                if side is None:
+                    rem = [s for i, s in enumerate(c.sp.gather_finish(hk, hv, B, Lp, C, c.key_len)) if i != r and s.len > 0]
                 if o is None:           # this rank holds only padding rows: nothing local to attend
                     o = ops.attention(q, rem, **kw)
                 elif rem and _SP_PER_SEGMENT and sm and len(rem) <= 3:      # (every merge rounds the running output to bf16 once more)
@@ -257,6 +282,15 @@ class WanSelfAttention(nn.Module):
                     for seg in rem:
                         ops.attention(q, [seg], lse=lse_r, out=o_r, **kw)
                         ops.attn_merge_(o, lse, o_r, lse_r, B=B, L=Lp, heads=n, head_dim=d)
+                elif rem and side is not None:
+                    # the remote calls ran on the side stream beside the local call (a rank's call is 880 workgroups = 3.44 rounds of the
+                    # 256 CUs: two calls back to back leave two partial rounds, side by side they share the tail); the merges
+                    # follow on this stream in the order of the sequential path, so the bits are the same
+                    torch.cuda.current_stream().wait_stream(side)
+                    for o_r, lse_r in parts:
+                        ops.attn_merge_(o, lse, o_r, lse_r, B=B, L=Lp, heads=n, head_dim=d)
+                        o_r.record_stream(torch.cuda.current_stream())
+                        lse_r.record_stream(torch.cuda.current_stream())
                 elif rem:
                     # the remote shards in as few calls as attn128q_kernel allows (it stages at most five ragged tails per call: 7 remote
                     # shards of 2 730 keys at sp8 = two calls); every call's partial softmax is merged through the log-sum-exps

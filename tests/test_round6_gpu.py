@@ -390,3 +390,13 @@ def test_ln_modulate_per_row_modulation_with_guidance_kernel():
         A[:, l % P] += dz[:, l] * u[:, l]
         Bm[:, l % P] += dz[:, l]
     assert float((ab[..., :C] - A).abs().max()) < 1e-4 and float((ab[..., C:] - Bm).abs().max()) < 1e-4
+
+
+def test_sp_remote_calls_on_a_second_stream(monkeypatch):
+    """M4D_SP_OVERLAP=1 (remote-shard attention calls on a side stream beside the local call, merges in the sequential order) gives
+    every emulated rank the rows of the unsharded result (A/B with clocks: profiles/r06_ab_sp_overlap.log — same bits, no gain)."""
+    import more4d_amd.models.wan_transformer4d as wt
+    from test_dit_gpu import test_token_sharded_local_first_schedule_single_gpu as run
+    monkeypatch.setattr(wt, "_SP_OVERLAP", True)
+    run()
+    torch.cuda.synchronize()

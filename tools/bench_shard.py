@@ -57,9 +57,12 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     mon.stop()
     ck = mon.region()
+    import hashlib
+    digest = hashlib.sha1(out.float().cpu().numpy().tobytes()).hexdigest()[:12]
     print(json.dumps({"world": args.world, "mode": args.mode, "sp_world": spw, "batch_per_rank": B,
                       "effective_clock_mhz": ck.get("effective_clock_mhz"), "socket_power_w": ck.get("socket_power_w", {}).get("mean"),
-                      "rank_ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": t_host * 1e3, "finite": bool(torch.isfinite(out.float()).all())}))
+                      "rank_ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": t_host * 1e3, "finite": bool(torch.isfinite(out.float()).all()),
+                      "sp_overlap": os.environ.get("M4D_SP_OVERLAP", "1"), "digest": digest}))
 
 
 if __name__ == "__main__":
