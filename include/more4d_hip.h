@@ -231,6 +231,27 @@ int m4d_conv_cl_planar_norm(m4d_dtype dt, const void* x, int64_t x_plane_stride,
                             int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
                             const float* norm_gamma, void* norm_out, int64_t norm_out_plane_stride, int silu, m4d_stream stream);
 
+/* Tiled weights for the LDS-halo convolution kernels (3x3 / 3x3x3 taps, bf16, Cin % 16 == 0).  Those kernels stage one tap of a
+ * 32-output-channel x 16-input-channel weight tile per 1 KiB DMA request; from the plain [Cout, taps*Cin] order the 64 16-byte pieces of a
+ * request come from 32 different rows (32 cache lines per request).  m4d_conv_pack_weights writes the same values as
+ * [ceil(Cout/32)][Cin/16][taps] units of 1 KiB, each the image the kernels keep in LDS (row r of the unit = output channel 32*block + r,
+ * clamped to Cout-1; its two 16-byte halves = input channels [8c, 8c+8) of the chunk with c = half ^ ((r >> 3) & 1)), so that a request
+ * is one contiguous KiB.  The host does this once per weight, next to the (dt, dh, dw, c) repack m4d_conv_cl already asks for
+ * (reference weights: CausalConv3d / Conv2d of wan_vae.py:21-40, 81-100); m4d_conv_tiled_weight_bytes = size of the copy (0: not tileable).
+ * m4d_conv_cl_tw / m4d_conv_cl_planar_tw are m4d_conv_cl / m4d_conv_cl_planar{,_norm,_gnstats} taking BOTH orders: `w_tiled` may be NULL,
+ * kernels without a tiled form read `w`; results are bit-identical either way.  In m4d_conv_cl_planar_tw, norm_out != NULL selects the
+ * fused next-layer norm (m4d_conv_cl_planar_norm), gn_partial != NULL the GroupNorm statistics (m4d_conv_cl_planar_gnstats). */
+int64_t m4d_conv_tiled_weight_bytes(int Cin, int Cout, int taps);
+int m4d_conv_pack_weights(m4d_dtype dt, const void* w, void* w_tiled, int Cin, int Cout, int taps, m4d_stream stream);
+int m4d_conv_cl_tw(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* w_tiled, const void* bias,
+                   const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin,
+                   int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h, int pad_w, int To,
+                   int Ho, int Wo, int ups, int tsplit, m4d_stream stream);
+int m4d_conv_cl_planar_tw(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* w_tiled, const void* bias,
+                          const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout,
+                          int kt, int To, const float* norm_gamma, void* norm_out, int64_t norm_out_plane_stride, int silu,
+                          float* gn_partial, m4d_stream stream);
+
 /* RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:43-58) fused with the following SiLU
  * (:199-201, :319, :424).  x/out: T [P, C] with row strides; gamma float [C]. */
 int m4d_rmsnorm_silu_cl(m4d_dtype dt, const void* x, int64_t x_ld, const float* gamma, void* out, int64_t out_ld,

@@ -111,6 +111,12 @@ SIGNATURES = {
     "m4d_bilinear_cl": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "m4d_conv_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
                     [c_int] * 19 + [c_void_p]),
+    "m4d_conv_tiled_weight_bytes": (c_int64, [c_int, c_int, c_int]),
+    "m4d_conv_pack_weights": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "m4d_conv_cl_tw": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
+                       [c_int] * 19 + [c_void_p]),
+    "m4d_conv_cl_planar_tw": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +
+                              [c_int] * 7 + [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "m4d_rmsnorm_silu_cl": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "m4d_rmsnorm_silu_cl_planar": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "m4d_conv_cl_planar": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64] +

@@ -35,6 +35,7 @@ struct ConvArgs {
     const float* post_gamma; void* post_out; int64_t post_plane; int post_silu;      // fused RMS_norm(+SiLU) of the next layer (conv_halo.h)
     unsigned long long* dbg;   // tool builds only (M4D_CONV_ABL & 64): per-workgroup timestamps, 8 words each (tools/conv_timeline.py)
     float* gn_partial;     // per-patch GroupNorm(32 x 4 channels) statistics of the result, [To][patches][32][2] (Cout = 128)
+    const void* wt;        // the weights again in the tiled order of m4d_conv_pack_weights, or nullptr (LDS-halo kernels only)
 };
 
 constexpr int ROWB = 128, BM = 128, BN = 128;
@@ -458,7 +459,7 @@ int launch_halo_auto(ConvArgs& p, hipStream_t st) {
             M4D_ENV_ONCE(h64, "M4D_CONV_HALO64", 1);
             // (planar-16 inputs only — what the residual blocks' fused norms write: + 5 % there; on channels-last inputs, whose halo pieces
             //  are 32 bytes out of every Cin * 2, it measured 5 % SLOWER than the 12 x 32 kernel: tools/check_conv64.py --time.  h64 = 2: both)
-            if (h64 && (p.xplane || h64 == 2) && p.kt == 3 && wide && !p.ups && !p.tsplit && p.Cout % 96 == 0 &&
+            if (h64 && p.wt && (p.xplane || h64 == 2) && p.kt == 3 && wide && !p.ups && !p.tsplit && p.Cout % 96 == 0 &&
                 (((p.Ho + 9) / 10) * 10 - p.Ho) * 20 <= p.Ho)
                 return launch_halo64(p, st);
             if (p.kt == 3) return wide ? launch_halo<3, 3, 12, 32, 3, 3>(p, st) : launch_halo<3, 3, 24, 16, 3, 3>(p, st);
@@ -483,10 +484,10 @@ inline void conv_tool_switches(ConvArgs& p) {
 
 }  // namespace
 
-extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
-                           const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win,
-                           int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h,
-                           int pad_w, int To, int Ho, int Wo, int ups, int tsplit, m4d_stream stream) {
+static int conv_cl_impl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
+                        const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win,
+                        int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h,
+                        int pad_w, int To, int Ho, int Wo, int ups, int tsplit, const void* wt, m4d_stream stream) {
     const int es = dt == M4D_BF16 ? 2 : 4;
     M4D_CHECK_ARG(dt == M4D_BF16 || dt == M4D_F32, "conv_cl: bad dtype %d", (int)dt);
     M4D_CHECK_ARG(x && w && out, "conv_cl: null pointer");
@@ -498,7 +499,9 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
     M4D_CHECK_ARG(out_ld % 4 == 0 && out_ld >= Cout && (!resid || (resid_ld % 4 == 0 && resid_ld >= Cout)), "conv_cl: bad out/resid stride");
     M4D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0, "conv_cl: pointers must be 16-byte aligned");
     M4D_CHECK_ARG((ups == 0 || ups == 1) && (tsplit == 0 || tsplit == 1), "conv_cl: ups/tsplit are flags");
+    M4D_CHECK_ARG(!wt || (dt == M4D_BF16 && Cin % 16 == 0 && ((uintptr_t)wt % 16) == 0), "conv_cl: tiled weights are bf16, Cin %% 16, 16-byte aligned");
     ConvArgs p;
+    p.wt = wt;
     p.x = x; p.w = w; p.bias = bias; p.resid = resid; p.out = out;
     p.xs = x_pixel_stride; p.ldo = out_ld; p.ldr = resid_ld;
     p.Tin = Tin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout;
@@ -533,10 +536,10 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
         const int per = (int)std::max<int64_t>(1, (xlimit - 1) / frame_bytes);
         for (int f0 = 0; f0 < Tin; f0 += per) {
             const int nf = std::min(per, Tin - f0);
-            const int rc = m4d_conv_cl(dt, (const char*)x + (int64_t)f0 * frame_bytes, x_pixel_stride, w, bias,
-                                       resid ? (const char*)resid + (int64_t)f0 * Ho * Wo * resid_ld * 2 : nullptr, resid_ld,
-                                       (char*)out + (int64_t)f0 * Ho * Wo * out_ld * 2, out_ld, nf, Hin, Win, Cin, Cout, kt, kh, kw,
-                                       st, sh, sw, pad_t, pad_h, pad_w, nf, Ho, Wo, ups, tsplit, stream);
+            const int rc = conv_cl_impl(dt, (const char*)x + (int64_t)f0 * frame_bytes, x_pixel_stride, w, bias,
+                                        resid ? (const char*)resid + (int64_t)f0 * Ho * Wo * resid_ld * 2 : nullptr, resid_ld,
+                                        (char*)out + (int64_t)f0 * Ho * Wo * out_ld * 2, out_ld, nf, Hin, Win, Cin, Cout, kt, kh, kw,
+                                        st, sh, sw, pad_t, pad_h, pad_w, nf, Ho, Wo, ups, tsplit, wt, stream);
             if (rc) return rc;
         }
         return 0;
@@ -596,8 +599,10 @@ extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, 
  * of 32 bytes out of a Cin*2-byte pixel, so the halo DMA fetches whole lines it uses (fabric traffic / 4 at Cin = 96). */
 static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
                                int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
-                               const float* norm_gamma, void* norm_out, int64_t norm_plane, int norm_silu, float* gn_partial, m4d_stream stream) {
+                               const float* norm_gamma, void* norm_out, int64_t norm_plane, int norm_silu, float* gn_partial, const void* wt,
+                               m4d_stream stream) {
     M4D_CHECK_ARG(dt == M4D_BF16, "conv_cl_planar: bf16 only");
+    M4D_CHECK_ARG(!wt || ((uintptr_t)wt % 16) == 0, "conv_cl_planar: tiled weights must be 16-byte aligned");
     M4D_CHECK_ARG(!gn_partial || (Cout == 128 && out && !norm_out && out_ld % 8 == 0 && (!resid || resid_ld % 8 == 0)),
                   "conv_cl_planar_gnstats: Cout = 128 (GroupNorm of 32 groups x 4 channels), row strides %% 8");
     M4D_CHECK_ARG(x && w && (out || norm_out) && Tin > 0 && Hin > 0 && Win > 0 && Cout > 0 && To > 0, "conv_cl_planar: null/empty");
@@ -614,6 +619,7 @@ static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stri
     M4D_CHECK_ARG((!out || (out_ld % 4 == 0 && out_ld >= Cout)) && (!resid || (resid_ld % 4 == 0 && resid_ld >= Cout)), "conv_cl_planar: bad out/resid stride");
     M4D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0, "conv_cl_planar: pointers must be 16-byte aligned");
     ConvArgs p;
+    p.wt = wt;
     p.x = x; p.w = w; p.bias = bias; p.resid = resid; p.out = out;
     p.xs = Cin; p.ldo = out_ld; p.ldr = resid_ld;
     p.Tin = Tin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Cout = Cout;
@@ -634,12 +640,28 @@ static int conv_cl_planar_impl(m4d_dtype dt, const void* x, int64_t x_plane_stri
     return 0;
 }
 
+extern "C" int m4d_conv_cl(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* bias,
+                           const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win,
+                           int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h,
+                           int pad_w, int To, int Ho, int Wo, int ups, int tsplit, m4d_stream stream) {
+    return conv_cl_impl(dt, x, x_pixel_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, kh, kw, st, sh, sw, pad_t, pad_h,
+                        pad_w, To, Ho, Wo, ups, tsplit, nullptr, stream);
+}
+
+extern "C" int m4d_conv_cl_tw(m4d_dtype dt, const void* x, int64_t x_pixel_stride, const void* w, const void* w_tiled, const void* bias,
+                              const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win,
+                              int Cin, int Cout, int kt, int kh, int kw, int st, int sh, int sw, int pad_t, int pad_h,
+                              int pad_w, int To, int Ho, int Wo, int ups, int tsplit, m4d_stream stream) {
+    return conv_cl_impl(dt, x, x_pixel_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, kh, kw, st, sh, sw, pad_t, pad_h,
+                        pad_w, To, Ho, Wo, ups, tsplit, w_tiled, stream);
+}
+
 extern "C" int m4d_conv_cl_planar(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
                                   int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin, int Cout, int kt, int To,
                                   m4d_stream stream) {
     M4D_CHECK_ARG(out, "conv_cl_planar: null output");
     return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, nullptr, nullptr, 0, 0,
-                               nullptr, stream);
+                               nullptr, nullptr, stream);
 }
 
 extern "C" int m4d_conv_cl_planar_gnstats_blocks(int Hin, int Win) {
@@ -652,7 +674,7 @@ extern "C" int m4d_conv_cl_planar_gnstats(m4d_dtype dt, const void* x, int64_t x
                                           int To, float* gn_partial, m4d_stream stream) {
     M4D_CHECK_ARG(out && gn_partial, "conv_cl_planar_gnstats: null output / statistics");
     return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, nullptr, nullptr, 0, 0,
-                               gn_partial, stream);
+                               gn_partial, nullptr, stream);
 }
 
 extern "C" int m4d_conv_cl_planar_norm(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* bias, const void* resid,
@@ -661,5 +683,54 @@ extern "C" int m4d_conv_cl_planar_norm(m4d_dtype dt, const void* x, int64_t x_pl
                                        m4d_stream stream) {
     M4D_CHECK_ARG(norm_out, "conv_cl_planar_norm: null normalised output");
     return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, norm_gamma, norm_out,
-                               norm_out_plane_stride, silu, nullptr, stream);
+                               norm_out_plane_stride, silu, nullptr, nullptr, stream);
+}
+
+// one entry for the three planar forms with tiled weights: norm_out / gn_partial select the fused epilogues as in the entries above
+extern "C" int m4d_conv_cl_planar_tw(m4d_dtype dt, const void* x, int64_t x_plane_stride, const void* w, const void* w_tiled, const void* bias,
+                                     const void* resid, int64_t resid_ld, void* out, int64_t out_ld, int Tin, int Hin, int Win, int Cin,
+                                     int Cout, int kt, int To, const float* norm_gamma, void* norm_out, int64_t norm_out_plane_stride,
+                                     int silu, float* gn_partial, m4d_stream stream) {
+    M4D_CHECK_ARG(out || norm_out, "conv_cl_planar_tw: null output");
+    M4D_CHECK_ARG(!(norm_out && gn_partial), "conv_cl_planar_tw: fused norm and GroupNorm statistics exclude each other");
+    return conv_cl_planar_impl(dt, x, x_plane_stride, w, bias, resid, resid_ld, out, out_ld, Tin, Hin, Win, Cin, Cout, kt, To, norm_gamma, norm_out,
+                               norm_out_plane_stride, silu, gn_partial, w_tiled, stream);
+}
+
+// ---- tiled weights ----
+namespace {
+// slot i of the tiled copy: unit u = i / 64 = (row block * chunks + chunk) * taps + tap, slot s = i % 64 -> row s / 2 of the block, physical
+// 16-byte half s & 1 holding channels [8 c, 8 c + 8) of the chunk with c = (s & 1) ^ ((row >> 3) & 1) — the LDS image the halo kernels read
+__global__ __launch_bounds__(256) void conv_pack_w_kernel(const bf16_t* w, bf16_t* out, int Cout, int Cin, int taps, int64_t nslots) {
+    const int nch = Cin / 16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(i & 63);
+        int64_t u = i >> 6;
+        const int tap = (int)(u % taps); u /= taps;
+        const int chunk = (int)(u % nch);
+        const int rb = (int)(u / nch);
+        const int r = s >> 1;
+        const int row = min(rb * 32 + r, Cout - 1);
+        const int c = (s & 1) ^ ((r >> 3) & 1);
+        const uint4 v = *reinterpret_cast<const uint4*>(w + ((int64_t)row * taps + tap) * Cin + chunk * 16 + c * 8);
+        *reinterpret_cast<uint4*>(out + i * 8) = v;
+    }
+}
+}  // namespace
+
+extern "C" int64_t m4d_conv_tiled_weight_bytes(int Cin, int Cout, int taps) {
+    if (Cin <= 0 || Cout <= 0 || taps <= 0 || Cin % 16) return 0;
+    return (int64_t)((Cout + 31) / 32) * (Cin / 16) * taps * 1024;
+}
+
+extern "C" int m4d_conv_pack_weights(m4d_dtype dt, const void* w, void* w_tiled, int Cin, int Cout, int taps, m4d_stream stream) {
+    M4D_CHECK_ARG(dt == M4D_BF16, "conv_pack_weights: bf16 only");
+    M4D_CHECK_ARG(w && w_tiled && Cin > 0 && Cout > 0 && taps > 0 && Cin % 16 == 0, "conv_pack_weights: null / empty / Cin %% 16");
+    M4D_CHECK_ARG(((uintptr_t)w % 16) == 0 && ((uintptr_t)w_tiled % 16) == 0, "conv_pack_weights: pointers must be 16-byte aligned");
+    const int64_t nslots = m4d_conv_tiled_weight_bytes(Cin, Cout, taps) / 16;
+    M4D_CHECK_ARG(nslots * 16 < (1ll << 31), "conv_pack_weights: the tiled copy must stay below 2 GiB");
+    const unsigned grid = (unsigned)std::min<int64_t>((nslots + 255) / 256, 4096);
+    hipLaunchKernelGGL(conv_pack_w_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, (bf16_t*)w_tiled, Cout, Cin, taps, nslots);
+    M4D_CHECK_LAUNCH("conv_pack_weights");
+    return 0;
 }

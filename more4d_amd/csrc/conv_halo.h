@@ -104,7 +104,14 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         const_cast<void*>(p.x), (short)0,
         (int)(p.xplane ? (int64_t)(p.Cin / 16 - 1) * p.xplane * 2 + (int64_t)p.Tin * p.Hin * p.Win * 32 : (int64_t)p.Tin * p.Hin * p.Win * p.xs * 2),
         0x00027000);                                       // (physical extent, < 2 GiB)
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
+    // weights: the plain [Cout][taps][Cin] order (every 16-byte piece of a DMA request from another 2 K-byte row: 32 cache lines per
+    // request) or, when the caller passes them, the TILED order of m4d_conv_pack_weights — [Cout / 32][Cin / 16][taps] units of 1 KiB,
+    // each the LDS image (32 rows x 32 bytes, swizzled) of one tap's 32-channel tile, so that a request is one contiguous KiB
+    const bool tiled = p.wt != nullptr;
+    const int ntaps = KT * KH * KW, nchunk_w = p.Cin / CK;
+    const __amdgpu_buffer_rsrc_t rw = tiled
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), (short)0, (int)(((p.Cout + 31) / 32) * nchunk_w * ntaps * 1024), 0x00027000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), (short)0, (int)(p.Cout * p.K * 2), 0x00027000);
     const int plane_bytes = (int)(p.xplane * 2);            // planar-16 input: [Cin/16][rows >= Tin*Hin*Win][16], p.xplane elements between planes
     int hoff[HPW];
 #pragma unroll
@@ -135,6 +142,8 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
         const int c = physc ^ ((n >> 3) & 1);
         const int64_t row = min(n0 + n, p.Cout - 1);
         woff[i] = (int)((row * p.K + tig * p.Cin + c * 8) * 2);
+        // (tiled: the request is the unit of (row block tn * NT + n / 32, chunk 0, tap tig) — a block past the last one reads zeros)
+        if (tiled) woff[i] = (((tn * NT + (n >> 5)) * nchunk_w) * ntaps + tig) * 1024 + lane * 16;
     }
     auto issue_halo = [&](int ck0) {
         char* dst = conv_dyn_smem;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__((MT == 3 ? 256 : 512 / MT), (MT == 1 ? 4 : 2)) void
     auto issue_w = [&](int buf, int ck0, int g) {
         if (M4D_ABL(p) & 4) return;
         char* dst = conv_dyn_smem + HALO_BYTES + buf * WG_BYTES;
-        const int koff = (g * KW * p.Cin + ck0) * 2;
+        const int koff = tiled ? ((ck0 >> 4) * ntaps + g * KW) * 1024 : (g * KW * p.Cin + ck0) * 2;
 #pragma unroll
         for (int i = 0; i < WPW; ++i)
             if (i * NWAVE + wave < WINSTR)

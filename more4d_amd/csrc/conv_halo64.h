@@ -52,10 +52,16 @@ __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
     // raw buffer resources as in conv_halo_kernel (base, stride 0, extent in bytes, flags 0x00027000): a request past the end of the
     // buffer writes ZEROS — halo pixels outside the image are just offset -1.  Built word by word: the stream takes them in SGPRs.
     const int pixb = p.xplane ? 32 : (int)(p.xs * 2);
-    const unsigned long long xb = (unsigned long long)p.x, wbp = (unsigned long long)p.w;
+    const unsigned long long xb = (unsigned long long)p.x;
     const unsigned rx2 = (unsigned)(p.xplane ? (int64_t)(p.Cin / 16 - 1) * p.xplane * 2 + (int64_t)p.Tin * p.Hin * p.Win * 32
                                               : (int64_t)p.Tin * p.Hin * p.Win * p.xs * 2);
+#ifdef M4D_CV64_GATHER
+    const unsigned long long wbp = (unsigned long long)p.w;
     const unsigned rw2 = (unsigned)(p.Cout * p.K * 2);
+#else
+    const unsigned long long wbp = (unsigned long long)p.wt;
+    const unsigned rw2 = (unsigned)((p.Cout / 32) * (p.Cin / CK) * 27 * 1024);
+#endif
 
     // ---- lane table (LDS offset 0, 32 dwords per work item): AB[5][3], WF, HO[8], WO[5] ----
     {
@@ -85,10 +91,14 @@ __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
             int piece = i * NWAVE + wave;
             if (piece > 8) piece = 8;
             const int q = piece * 64 + lane;
-            const int tig = q / (NB * 2), n = (q % (NB * 2)) >> 1, physc = q & 1;
-            const int c = physc ^ ((n >> 3) & 1);
+            const int tig = q / (NB * 2), n = (q % (NB * 2)) >> 1;
+#ifdef M4D_CV64_GATHER          // (tool builds of the first version: plain [Cout][27][Cin] weights, conv_halo64 --gather stream)
+            const int c = (q & 1) ^ ((n >> 3) & 1);
             const int64_t row = min(n0 + n, p.Cout - 1);
             tab[24 + i] = (unsigned)((row * p.K + tig * p.Cin + c * 8) * 2);
+#else                           // tiled weights (m4d_conv_pack_weights): the piece is the KiB of (row block tn * 3 + n / 32, chunk 0, tap tig)
+            tab[24 + i] = (unsigned)((((tn * NT + (n >> 5)) * (p.Cin / CK)) * 27 + tig) * 1024 + lane * 16);
+#endif
         }
         tab[29] = tab[30] = tab[31] = 0;
     }

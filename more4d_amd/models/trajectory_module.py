@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .wan_vae import CIN_PAD, _round
+from .wan_vae import CIN_PAD, _TILED_WEIGHTS, _round
 
 
 def zero_module(module):
@@ -72,6 +72,18 @@ class _AdaptorBase(nn.Module):
             self._pack_cache[id(conv)] = hit
         return hit[1:]
 
+    def _tiled(self, conv):
+        """the 3x3 conv's weights in the tiled order of the LDS-halo kernels (ops.conv_pack_weights), cached like _packed()"""
+        if not _TILED_WEIGHTS or self.dtype != torch.bfloat16:
+            return None
+        key = (conv.weight._version, conv.weight.data_ptr(), self.dtype)
+        hit = self._pack_cache.get(("tiled", id(conv)))
+        if hit is None or hit[0] != key:
+            w, _, cip, _ = self._packed(conv)
+            hit = (key, ops.conv_pack_weights(w, cip) if w.is_cuda else None)
+            self._pack_cache[("tiled", id(conv))] = hit
+        return hit[1]
+
     def _f32(self, p):
         key = (p._version, p.data_ptr())
         hit = self._pack_cache.get(id(p))
@@ -84,7 +96,7 @@ class _AdaptorBase(nn.Module):
         w, b, cip, cop = self._packed(conv)
         assert cip == cin
         return ops.conv_cl(x, w, b, Tin=F, Hin=H, Win=W, Cin=cin, k=(1, 3, 3), pad=(0, 1, 1), out_thw=(F, H, W),
-                           resid=resid), cop
+                           resid=resid, w_tiled=self._tiled(conv)), cop
 
     def _gn_swish(self, x, norm, F, HW):
         return ops.groupnorm_cl(x.view(F, HW, -1), self._f32(norm.weight), self._f32(norm.bias), F=F, HW=HW,
@@ -105,13 +117,14 @@ class _AdaptorBase(nn.Module):
         """3x3 conv over planar-16 frame groups -> ([F*H*W, cop], cop, stats or None); stats = per-patch GroupNorm sums of the result."""
         w, b, cip, cop = self._packed(conv)
         out = torch.empty((F * H * W, cop), device=w.device, dtype=w.dtype)
+        wt = self._tiled(conv)
         st = self._stats_buf(conv.weight.shape[0], F, H, W) if stats else None
         f0 = 0
         for g in groups:
             n = g.t.shape[1]
             rows = slice(f0 * H * W, (f0 + n) * H * W)
             ops.conv_cl_planar(g, w, b, Tin=n, Hin=H, Win=W, kt=1, resid=None if resid is None else resid[rows], out=out[rows],
-                               gn_stats=None if st is None else st[f0:f0 + n])
+                               gn_stats=None if st is None else st[f0:f0 + n], w_tiled=wt)
             f0 += n
         return out, cop, st
 

@@ -23,6 +23,10 @@ import torch.nn as nn
 
 from .. import ops
 
+# M4D_CONV_TILED=0: the LDS-halo conv kernels stage their weights from the plain [Cout, taps*Cin] order (A/B; default: from the tiled copies
+# of ops.conv_pack_weights — one contiguous KiB per DMA request instead of 32 cache lines)
+_TILED_WEIGHTS = os.environ.get("M4D_CONV_TILED", "1") != "0"
+
 CACHE_T = 2
 
 
@@ -323,6 +327,19 @@ class _Runner:
             cache[id(conv)] = hit
         return hit[1:]
 
+    def tiled(self, conv):
+        """The conv's weights once more in the tiled order of the LDS-halo kernels (ops.conv_pack_weights), or None; cached like packed()."""
+        if not _TILED_WEIGHTS or self.T != torch.bfloat16 or conv.weight.shape[-1] != 3 or conv.weight.shape[-2] != 3:
+            return None
+        cache = self.vae._pack_cache
+        key = (id(conv), self.T, conv.weight._version, conv.weight.data_ptr())
+        hit = cache.get(("tiled", id(conv)))
+        if hit is None or hit[0] != key:
+            w, _, _, cip, _ = self.packed(conv)
+            hit = (key, ops.conv_pack_weights(w, cip) if w.is_cuda else None)
+            cache[("tiled", id(conv))] = hit
+        return hit[1]
+
     def gamma(self, norm):
         cache = self.vae._pack_cache
         key = (id(norm), norm.gamma._version, norm.gamma.data_ptr())
@@ -352,7 +369,7 @@ class _Runner:
             ho, wo, pad = hl, wl, kh // 2
         y = ops.conv_cl(x.data, w, b, Tin=x.t, Hin=x.h, Win=x.w, Cin=x.c, k=(1, kh, kw), stride=(1, stride_hw, stride_hw),
                         pad=(0, pad, pad), out_thw=(t, ho, wo), resid=_data(resid), out=out, ups=ups, tsplit=tsplit,
-                        x_pixel_stride=x_pixel_stride)
+                        x_pixel_stride=x_pixel_stride, w_tiled=self.tiled(conv))
         return _Act(y, t, ho, wo, cop)
 
     def conv_causal(self, key, conv, t, h, w, fill, resid=None, out=None, then=None, keep_raw=True):
@@ -380,10 +397,10 @@ class _Runner:
                     if isinstance(dst2, ops.Planar16):
                         norm, fused_for = (self.gamma(nxt_norm), dst2, True), nxt_key
             y = ops.conv_cl_planar(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, kt=kt, resid=_data(resid), out=out, norm=norm,
-                                   keep_raw=keep_raw or fused_for is None)
+                                   keep_raw=keep_raw or fused_for is None, w_tiled=self.tiled(conv))
         else:
             y = ops.conv_cl(st.window(t), wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=(kt, kh, kw), pad=(0, kh // 2, kw // 2),
-                            out_thw=(t, h, w), resid=_data(resid), out=out)
+                            out_thw=(t, h, w), resid=_data(resid), out=out, w_tiled=self.tiled(conv))
         st.roll(t)
         a = _Act(y, t, h, w, cop)
         a.prefilled_for = fused_for

@@ -376,11 +376,38 @@ def add_bcast(a, bias):
 
 # ------------------------------------------------------------------ Motion-Sensitive 3D-VAE (channels-last)
 
+def conv_pack_weights(w, Cin):
+    """The weights w [Cout, taps*Cin] (bf16, Cin % 16 == 0) once more in the tiled order the LDS-halo conv kernels stage from with
+    contiguous 1 KiB requests (m4d_conv_pack_weights); pass the result as `w_tiled` to conv_cl / conv_cl_planar.  None if not tileable."""
+    _dev(w)
+    Cout, K = w.shape
+    lib = _lib.load()
+    if w.dtype != torch.bfloat16 or not w.is_contiguous() or Cin % 16 or K % Cin:
+        return None
+    n = lib.m4d_conv_tiled_weight_bytes(Cin, Cout, K // Cin)
+    if n <= 0 or n >= 1 << 31:
+        return None
+    out = torch.empty(n // 2, device=w.device, dtype=w.dtype)
+    check(lib.m4d_conv_pack_weights(dt_code(w.dtype), _ptr(w), _ptr(out), Cin, Cout, K // Cin, _stream()), "m4d_conv_pack_weights")
+    return out
+
+
+def _check_tiled(w_tiled, w, Cin):
+    if w_tiled is None:
+        return
+    _dev(w_tiled)
+    Cout, K = w.shape
+    if w_tiled.dtype != w.dtype or not w_tiled.is_contiguous() or \
+            w_tiled.numel() * 2 != _lib.load().m4d_conv_tiled_weight_bytes(Cin, Cout, K // Cin):
+        raise ValueError("conv: w_tiled is not conv_pack_weights(w, Cin)")
+
+
 def conv_cl(x, w, bias, *, Tin, Hin, Win, Cin, k, stride=(1, 1, 1), pad=(0, 0, 0), out_thw, x_pixel_stride=None,
-            resid=None, out=None, ups=False, tsplit=False):
-    """Implicit-GEMM conv on channels-last x (flat or [T,H,W,C]); w [Cout, kt*kh*kw*Cin] packed (dt,dh,dw,c).
-    Returns out [To*Ho*Wo, Cout] (or writes `out`, a row-strided 2-D view)."""
+            resid=None, out=None, ups=False, tsplit=False, w_tiled=None):
+    """Implicit-GEMM conv on channels-last x (flat or [T,H,W,C]); w [Cout, kt*kh*kw*Cin] packed (dt,dh,dw,c); w_tiled: optionally
+    conv_pack_weights(w, Cin) as well.  Returns out [To*Ho*Wo, Cout] (or writes `out`, a row-strided 2-D view)."""
     _dev(x, w, bias, resid, out)
+    _check_tiled(w_tiled, w, Cin)
     Cout = w.shape[0]
     kt, kh, kw = k
     if w.shape[1] != kt * kh * kw * Cin:
@@ -402,6 +429,11 @@ def conv_cl(x, w, bias, *, Tin, Hin, Win, Cin, k, stride=(1, 1, 1), pad=(0, 0, 0
         if rm != M or resid.shape[-1] != Cout:
             raise ValueError("conv_cl: resid shape mismatch")
     lib = _lib.load()
+    if w_tiled is not None:
+        check(lib.m4d_conv_cl_tw(dt_code(x.dtype), _ptr(x), x_pixel_stride, _ptr(w), _ptr(w_tiled), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
+                                 Tin, Hin, Win, Cin, Cout, kt, kh, kw, stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
+                                 To, Ho, Wo, int(ups), int(tsplit), _stream()), "m4d_conv_cl_tw")
+        return out
     check(lib.m4d_conv_cl(dt_code(x.dtype), _ptr(x), x_pixel_stride, _ptr(w), _ptr(bias), _ptr(resid), ldr, _ptr(out), ldo,
                           Tin, Hin, Win, Cin, Cout, kt, kh, kw, stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
                           To, Ho, Wo, int(ups), int(tsplit), _stream()), "m4d_conv_cl")
@@ -435,7 +467,7 @@ def gnstats_blocks(Hin, Win):
     return _lib.load().m4d_conv_cl_planar_gnstats_blocks(Hin, Win)
 
 
-def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True, gn_stats=None):
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True, gn_stats=None, w_tiled=None):
     """3x3(x3) stride-1 conv (pad (0,1,1), valid in T) of a Planar16 input; w / bias / resid / out as conv_cl.
     norm = (gamma float32 [Cout], dst Planar16, silu): the next layer's RMS_norm(+SiLU) fused into the epilogue, written to `dst`
     (rows == To*Hin*Win); with keep_raw=False the un-normalised result is not stored and None is returned."""
@@ -460,6 +492,26 @@ def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=
         if rm != M or resid.shape[-1] != Cout:
             raise ValueError("conv_cl_planar: resid shape mismatch")
     lib = _lib.load()
+    if w_tiled is not None:
+        _check_tiled(w_tiled, w, Cin)
+        g_ptr = d_ptr = st_ptr = None
+        d_plane = silu = 0
+        if gn_stats is not None:
+            _dev(gn_stats)
+            if norm is not None or gn_stats.dtype != torch.float32 or not gn_stats.is_contiguous() or \
+                    gn_stats.numel() != To * gnstats_blocks(Hin, Win) * 64:
+                raise ValueError("conv_cl_planar: gn_stats must be contiguous float32 [To, blocks, 32, 2] (and excludes norm=)")
+            st_ptr = _ptr(gn_stats)
+        if norm is not None:
+            gamma, dst, silu = norm
+            _dev(gamma, dst.t)
+            if gamma.dtype != torch.float32 or gamma.numel() != Cout or dst.rows != M or dst.channels != Cout or dst.t.dtype != w.dtype:
+                raise ValueError("conv_cl_planar: norm = (gamma float32 [Cout], Planar16 of To*Hin*Win rows x Cout channels, silu)")
+            g_ptr, d_ptr, d_plane = _ptr(gamma), _ptr(dst.t), dst.plane_stride
+        check(lib.m4d_conv_cl_planar_tw(dt_code(w.dtype), _ptr(x.t), x.plane_stride, _ptr(w), _ptr(w_tiled), _ptr(bias), _ptr(resid), ldr,
+                                        _ptr(out), ldo, Tin, Hin, Win, Cin, Cout, kt, To, g_ptr, d_ptr, d_plane, int(silu), st_ptr, _stream()),
+              "m4d_conv_cl_planar_tw")
+        return out
     if gn_stats is not None:
         # gn_stats: float32 [To, gnstats_blocks(Hin, Win), 32, 2] view: per-patch GroupNorm(32 x 4 channels) sums of the result (Cout = 128)
         _dev(gn_stats)

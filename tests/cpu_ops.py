@@ -229,7 +229,7 @@ NAMES += ["conv_cl", "rmsnorm_silu_cl", "groupnorm_cl", "softmax_rows", "ncthw_t
 
 
 def conv_cl(x, w, bias, *, Tin, Hin, Win, Cin, k, stride=(1, 1, 1), pad=(0, 0, 0), out_thw, x_pixel_stride=None,
-            resid=None, out=None, ups=False, tsplit=False):
+            resid=None, out=None, ups=False, tsplit=False, w_tiled=None):
     kt, kh, kw = k
     Cout = w.shape[0]
     xs = x_pixel_stride or Cin * (2 if tsplit else 1)
@@ -282,7 +282,7 @@ def gnstats_blocks(Hin, Win):
     return 1
 
 
-def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True, gn_stats=None):
+def conv_cl_planar(x, w, bias, *, Tin, Hin, Win, kt, resid=None, out=None, norm=None, keep_raw=True, gn_stats=None, w_tiled=None):
     if gn_stats is not None:      # one block per frame: (sum, sum of squares) of every group of 4 channels
         y = conv_cl_planar(x, w, bias, Tin=Tin, Hin=Hin, Win=Win, kt=kt, resid=resid, out=out)
         v = y.float().view(Tin - kt + 1, Hin * Win, -1, 4)

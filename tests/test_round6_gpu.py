@@ -297,33 +297,109 @@ def test_tiny_dit_subject_ref_vs_reference():
 
 
 def test_conv_halo64_bit_identical_to_the_two_wave_kernel():
-    """conv_halo64_kernel (csrc/conv_halo64.h: the VAE's 3 x 3 x 3 conv of 96-channel tiles as one wave per SIMD, generated main loop)
-    against conv_halo_kernel<3, 3, 12, 32, 3, 3> on the same inputs in child processes (the switch is read once per process) — same
-    accumulation order, the SAME epilogue source: every output (raw, + shortcut, fused RMS_norm + SiLU into planar-16, 96 / 192 / 384
-    channels, ragged right edge, planar-16 and channels-last inputs) must agree bit for bit — and against 27 shifted fp32 GEMMs."""
+    """conv_halo64_kernel (csrc/conv_halo64.h: the VAE's 3 x 3 x 3 conv of 96-channel tiles as one wave per SIMD, generated main loop,
+    tiled weights) against conv_halo_kernel<3, 3, 12, 32, 3, 3> on plain AND on tiled weights, same inputs, in child processes (the
+    switch is read once per process) — same accumulation order, the SAME epilogue source: every output (raw, + shortcut, fused RMS_norm +
+    SiLU into planar-16, 96 / 192 / 384 channels, ragged right edge, planar-16 and channels-last inputs) must agree bit for bit — and
+    against 27 shifted fp32 GEMMs; m4d_conv_pack_weights against a torch restatement of the tiled order."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_conv64.py")], capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
-    assert out.count("bit-identical") == 7 and "DIFFERENT" not in out and "RESULT mode 2 PASS" in out, out[-3000:]
+    assert out.count("bit-identical") == 14 and "DIFFERENT" not in out and "differs from" not in out, out[-3000:]
+    assert "RESULT halo64 2 tiled 1 PASS" in out and "RESULT halo64 0 tiled 1 PASS" in out and "RESULT halo64 0 tiled 0 PASS" in out, out[-3000:]
     assert out.count("'conv_halo64': 1") == 7, out[-3000:]
 
 
 def test_vae_residual_block_runs_on_conv_halo64():
-    """the production path takes the new kernel: a 96-channel ResidualBlock at 120 x 416 (planar-16 staging) launches conv_halo64"""
+    """the production path takes the new kernel: a 96-channel conv at 120 x 416 with tiled weights launches conv_halo64 (planar-16 input
+    by default); without tiled weights (the kernel has no gather form) and on channels-last inputs the 12 x 32 kernel runs"""
     from more4d_amd import ops
     T, H, W, C = 4, 120, 416, 96
     g = torch.Generator(device=DEV).manual_seed(0)
     x = torch.randn(T * H * W, C, device=DEV, generator=g).to(BF)
     w = (torch.randn(C, 27 * C, device=DEV, generator=g) * (27 * C) ** -0.5).to(BF)
+    wt = ops.conv_pack_weights(w, C)
     xp = ops.Planar16(x.view(T, H * W, C // 16, 16).permute(2, 0, 1, 3).contiguous())
     ops.launch_counts(reset=True)
-    ops.conv_cl_planar(xp, w, None, Tin=T, Hin=H, Win=W, kt=3)
+    a = ops.conv_cl_planar(xp, w, None, Tin=T, Hin=H, Win=W, kt=3, w_tiled=wt)
     cnt = ops.launch_counts()
     assert cnt["conv_halo64"] == 1 and cnt["conv_halo_mt3_12x32"] == 0, cnt
     ops.launch_counts(reset=True)
-    ops.conv_cl(x, w, None, Tin=T, Hin=H, Win=W, Cin=C, k=(3, 3, 3), pad=(0, 1, 1), out_thw=(T - 2, H, W))     # channels-last: the 12 x 32 kernel
+    b = ops.conv_cl_planar(xp, w, None, Tin=T, Hin=H, Win=W, kt=3)
     cnt = ops.launch_counts()
     assert cnt["conv_halo64"] == 0 and cnt["conv_halo_mt3_12x32"] == 1, cnt
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    with pytest.raises(ValueError):
+        ops.conv_cl_planar(xp, w, None, Tin=T, Hin=H, Win=W, kt=3, w_tiled=wt[:-8])
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("3x3x3 96->32 (NT=1)", dict(T=3, H=64, W=64, Cin=96, Cout=32, kt=3)),
+    ("3x3x3 32->64 (NT=2)", dict(T=3, H=64, W=96, Cin=32, Cout=64, kt=3)),
+    ("3x3x3 192->128 (NT=4), narrow map", dict(T=3, H=60, W=104, Cin=192, Cout=128, kt=3)),
+    ("3x3x3 384->384 small map", dict(T=3, H=30, W=52, Cin=384, Cout=384, kt=3)),
+    ("3x3 192->96 up-sampled view", dict(T=2, H=60, W=104, Cin=192, Cout=96, kt=1, ups=True)),
+    ("3x3 96->12 (head, Cout padded to 32)", dict(T=2, H=64, W=64, Cin=96, Cout=12, kt=1)),
+    ("3x3 stride 2 96->96", dict(T=2, H=120, W=208, Cin=96, Cout=96, kt=1, stride=2)),
+    ("3x3 128->128 adaptor shape", dict(T=2, H=120, W=208, Cin=128, Cout=128, kt=1)),
+])
+def test_tiled_weights_same_bits_on_every_halo_kernel(name, kw):
+    """m4d_conv_cl_tw / m4d_conv_cl_planar_tw (weights in the tiled order of m4d_conv_pack_weights: one contiguous KiB per DMA request)
+    against the plain-weight entries on the LDS-halo kernel's other instantiations — channel tiles of 32 / 64 / 96 / 128, 16 x 16 and
+    8 x 32 patches, up-sampled input view, stride 2, Cout below a row block: bit-identical, and an LDS-halo kernel actually ran."""
+    from more4d_amd import ops
+    T, H, W, Cin, Cout, kt = (kw[k] for k in ("T", "H", "W", "Cin", "Cout", "kt"))
+    ups, stride = kw.get("ups", False), kw.get("stride", 1)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(T * H * W, Cin, device=DEV, generator=g).to(BF)
+    w = (torch.randn(Cout, kt * 9 * Cin, device=DEV, generator=g) * (kt * 9 * Cin) ** -0.5).to(BF)
+    b = torch.randn(Cout, device=DEV, generator=g).to(BF)
+    wt = ops.conv_pack_weights(w, Cin)
+    assert wt is not None and wt.numel() == -(-Cout // 32) * 32 * kt * 9 * Cin
+    To = T - kt + 1
+    Hl, Wl = H * (2 if ups else 1), W * (2 if ups else 1)
+    if stride == 2:
+        args = dict(Tin=T, Hin=H, Win=W, Cin=Cin, k=(1, 3, 3), stride=(1, 2, 2), pad=(0, 0, 0), out_thw=(T, H // 2, W // 2))
+    else:
+        args = dict(Tin=T, Hin=H, Win=W, Cin=Cin, k=(kt, 3, 3), pad=(0, 1, 1), out_thw=(To, Hl, Wl), ups=ups)
+    ops.launch_counts(reset=True)
+    a = ops.conv_cl(x, w, b, **args)
+    c = ops.conv_cl(x, w, b, w_tiled=wt, **args)
+    cnt = ops.launch_counts()
+    assert sum(v for k, v in cnt.items() if k.startswith("conv_halo")) == 2, cnt
+    assert torch.equal(a.view(torch.int16), c.view(torch.int16)), name
+    if stride == 1 and not ups:
+        xp = ops.Planar16(x.view(T, H * W, Cin // 16, 16).permute(2, 0, 1, 3).contiguous())
+        d = ops.conv_cl_planar(xp, w, b, Tin=T, Hin=H, Win=W, kt=kt, w_tiled=wt)
+        assert torch.equal(a.view(torch.int16), d.view(torch.int16)), name
+
+
+def test_vae_decode_uses_tiled_weights_and_keeps_its_bits(monkeypatch):
+    """the VAE's decode with the tiled copies (default) and without them (WanVAE views' tiled() -> None): same bits, and the tiled run
+    launches conv_halo64"""
+    import more4d_amd.models.wan_vae as wv
+    from more4d_amd import ops
+    from more4d_amd.models.wan_vae import AutoencoderKLWan
+    from util import load_keys
+    from weights import fill
+    vae = AutoencoderKLWan().eval()
+    vae.load_state_dict(fill(load_keys("vae_keys.json"), 2024))
+    vae = vae.to(DEV, BF)
+    z = torch.randn(1, 16, 2, 60, 104, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(BF)
+    ops.launch_counts(reset=True)
+    with torch.no_grad():
+        a = vae.decode(z)
+    a = a.sample if hasattr(a, "sample") else a
+    cnt = ops.launch_counts()
+    assert cnt["conv_halo64"] > 0, cnt
+    cls = next(c for c in vars(wv).values() if isinstance(c, type) and hasattr(c, "tiled") and hasattr(c, "packed"))
+    monkeypatch.setattr(cls, "tiled", lambda self, conv: None)
+    ops.launch_counts(reset=True)
+    with torch.no_grad():
+        b = vae.decode(z)
+    b = b.sample if hasattr(b, "sample") else b
+    assert ops.launch_counts()["conv_halo64"] == 0
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
 
 def test_guided_dit_per_token_timesteps_gradients_vs_reference():

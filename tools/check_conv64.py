@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""conv_halo64_kernel (M4D_CONV_HALO64=2: planar-16 AND channels-last inputs; the default 1 takes planar-16 only) against conv_halo_kernel<3,3,12,32,3,3> (=0) on the same inputs — the two share the
-accumulation order and the epilogue source, so every output must agree BIT FOR BIT — and against an fp32 torch conv3d; then timing at
-the VAE's dominant shape (96 -> 96 channels, 480 x 832, 4 output frames).
+"""conv_halo64_kernel (M4D_CONV_HALO64=2: planar-16 AND channels-last inputs; tiled weights) against conv_halo_kernel<3,3,12,32,3,3> (=0)
+with plain and with tiled weights (ops.conv_pack_weights) on the same inputs — the kernels share the accumulation order and the epilogue
+source, so every output must agree BIT FOR BIT — and against an fp32 reference; the pack kernel against a torch restatement of the tiled
+order; then timing at the VAE's dominant shape (96 -> 96 channels, 480 x 832, 4 output frames).
     python tools/check_conv64.py [--time]"""
 import os
 import subprocess
@@ -23,6 +24,21 @@ def planar(x_cl, T, H, W, C):
     return ops.Planar16(t)
 
 
+def tiled_ref(w, Cin):
+    """torch restatement of m4d_conv_pack_weights: [Cout, taps * Cin] -> [ceil(Cout / 32)][Cin / 16][taps][32 rows][2 halves][8], rows past
+    Cout - 1 repeat the last row, half h of row r holds channels 8 * (h ^ ((r >> 3) & 1)) + [0, 8) of the chunk"""
+    Cout, K = w.shape
+    taps, nrb = K // Cin, (Cout + 31) // 32
+    rows = torch.arange(nrb * 32, device=w.device).clamp(max=Cout - 1)
+    wv = w[rows].view(nrb, 32, taps, Cin // 16, 2, 8).clone()
+    sw = ((torch.arange(32, device=w.device) >> 3) & 1).bool()
+    wv[:, sw] = wv[:, sw].flip(-2)
+    return wv.permute(0, 3, 2, 1, 4, 5).contiguous().view(-1)
+
+
+TILED = False
+
+
 def case(name, T, H, W, Cin, Cout, layout, bias=True, resid=False, norm=False, keep_raw=True, seed=0):
     from more4d_amd import ops
     g = torch.Generator(device=DEV).manual_seed(seed)
@@ -34,8 +50,15 @@ def case(name, T, H, W, Cin, Cout, layout, bias=True, resid=False, norm=False, k
     r = torch.randn(M, Cout, device=DEV, generator=g).to(BF) if resid else None
     ops.launch_counts(reset=True)
     outs = []
+    w_ref = w
+    wt = None
+    if TILED:
+        wt = ops.conv_pack_weights(w, Cin)
+        if not torch.equal(wt.view(torch.int16), tiled_ref(w, Cin).view(torch.int16)):
+            print(f"{name}: conv_pack_weights differs from the torch restatement", flush=True)
+            return True, []
     if layout == "cl":
-        out = ops.conv_cl(x, w, b, Tin=T, Hin=H, Win=W, Cin=Cin, k=(3, 3, 3), pad=(0, 1, 1), out_thw=(To, H, W), resid=r)
+        out = ops.conv_cl(x, w, b, Tin=T, Hin=H, Win=W, Cin=Cin, k=(3, 3, 3), pad=(0, 1, 1), out_thw=(To, H, W), resid=r, w_tiled=wt)
         outs.append(out)
     else:
         xp = planar(x, T, H, W, Cin)
@@ -44,7 +67,7 @@ def case(name, T, H, W, Cin, Cout, layout, bias=True, resid=False, norm=False, k
             gamma = torch.rand(Cout, device=DEV, generator=g) + 0.5
             dst = ops.Planar16(torch.full((Cout // 16, To, H * W, 16), float("nan"), device=DEV, dtype=BF))
             nrm = (gamma, dst, True)
-        out = ops.conv_cl_planar(xp, w, b, Tin=T, Hin=H, Win=W, kt=3, resid=r, norm=nrm, keep_raw=keep_raw)
+        out = ops.conv_cl_planar(xp, w, b, Tin=T, Hin=H, Win=W, kt=3, resid=r, norm=nrm, keep_raw=keep_raw, w_tiled=wt)
         if out is not None:
             outs.append(out)
         if norm:
@@ -55,7 +78,7 @@ def case(name, T, H, W, Cin, Cout, layout, bias=True, resid=False, norm=False, k
     # (27 shifted fp32 GEMMs instead of torch's conv3d: no MIOpen search on a fresh box)
     xf = torch.zeros(T, H + 2, W + 2, Cin, device=DEV)
     xf[:, 1:-1, 1:-1] = x.float().view(T, H, W, Cin)
-    wf = w.float().view(Cout, 3, 3, 3, Cin)
+    wf = w_ref.float().view(Cout, 3, 3, 3, Cin)
     ref = torch.zeros(To, H, W, Cout, device=DEV)
     for dt in range(3):
         for dh in range(3):
@@ -105,8 +128,10 @@ CASES = (
 
 
 def main():
+    global TILED
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        mode, what = sys.argv[2], sys.argv[3]
+        mode, tiled, what = sys.argv[2], sys.argv[3] == "1", sys.argv[4]
+        TILED = tiled
         os.environ["M4D_CONV_HALO64"] = mode
         from more4d_amd import ops
         if what == "time":
@@ -115,17 +140,19 @@ def main():
             x = torch.randn(T * H * W, C, device=DEV, generator=g).to(BF)
             w = (torch.randn(C, 27 * C, device=DEV, generator=g) * (27 * C) ** -0.5).to(BF)
             b = torch.randn(C, device=DEV, generator=g).to(BF)
+            wt = ops.conv_pack_weights(w, C) if tiled else None
             xp = planar(x, T, H, W, C)
             out = torch.empty((T - 2) * H * W, C, device=DEV, dtype=BF)
             for lay in ("planar", "cl"):
                 def run():
                     if lay == "planar":
-                        ops.conv_cl_planar(xp, w, b, Tin=T, Hin=H, Win=W, kt=3, out=out)
+                        ops.conv_cl_planar(xp, w, b, Tin=T, Hin=H, Win=W, kt=3, out=out, w_tiled=wt)
                     else:
-                        ops.conv_cl(x, w, b, Tin=T, Hin=H, Win=W, Cin=C, k=(3, 3, 3), pad=(0, 1, 1), out_thw=(T - 2, H, W), out=out)
+                        ops.conv_cl(x, w, b, Tin=T, Hin=H, Win=W, Cin=C, k=(3, 3, 3), pad=(0, 1, 1), out_thw=(T - 2, H, W), out=out, w_tiled=wt)
                 for _ in range(5):
                     run()
                 torch.cuda.synchronize()
+                ops.launch_counts(reset=True)
                 t0 = time.perf_counter()
                 n = 40
                 for _ in range(n):
@@ -133,7 +160,9 @@ def main():
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / n * 1e3
                 fl = 2.0 * (T - 2) * H * W * C * 27 * C
-                print(f"mode {mode} {lay}: {ms:.4f} ms  {fl / ms / 1e9:.0f} TF  frac {fl / ms / 1e9 / 2500:.3f}  digest {float(out.float().abs().double().sum()):.10e}", flush=True)
+                kern = "+".join(k for k, v in ops.launch_counts().items() if v and k.startswith("conv_halo"))
+                print(f"halo64={mode} tiled={int(tiled)} {lay} [{kern}]: {ms:.4f} ms  {fl / ms / 1e9:.0f} TF  frac {fl / ms / 1e9 / 2500:.3f}  "
+                      f"digest {float(out.float().abs().double().sum()):.10e}", flush=True)
             return
         bad = False
         outs = []
@@ -141,32 +170,35 @@ def main():
             b_, o = case(*c)
             bad |= b_
             outs.append(o)
-        torch.save(outs, f"/tmp/conv64_mode{mode}.pt")
-        print("RESULT mode", mode, "FAIL" if bad else "PASS", flush=True)
+        torch.save(outs, f"/tmp/conv64_mode{mode}{int(tiled)}.pt")
+        print("RESULT halo64", mode, "tiled", int(tiled), "FAIL" if bad else "PASS", flush=True)
         sys.exit(1 if bad else 0)
     rc = 0
-    for mode in ("0", "2"):
+    runs = (("0", "0"), ("0", "1"), ("2", "1"))       # (M4D_CONV_HALO64, tiled weights)
+    for mode, tiled in runs:
         try:
-            rc |= subprocess.run([sys.executable, __file__, "--child", mode, "check"], timeout=180).returncode
+            rc |= subprocess.run([sys.executable, __file__, "--child", mode, tiled, "check"], timeout=180).returncode
         except subprocess.TimeoutExpired:
-            print("mode", mode, "TIMED OUT", flush=True)
+            print("halo64", mode, "tiled", tiled, "TIMED OUT", flush=True)
             rc |= 1
     try:
-        a, b = torch.load("/tmp/conv64_mode0.pt"), torch.load("/tmp/conv64_mode2.pt")
-        for (nm, *_), x, y in zip(CASES, a, b):
-            same = len(x) == len(y) and all(torch.equal(p.view(torch.int16), q.view(torch.int16)) for p, q in zip(x, y))
-            print(f"{nm}: new vs old kernel", "bit-identical" if same else "DIFFERENT")
-            rc |= int(not same)
+        a = torch.load("/tmp/conv64_mode00.pt")
+        for mode, tiled in runs[1:]:
+            b = torch.load(f"/tmp/conv64_mode{mode}{tiled}.pt")
+            for (nm, *_), x, y in zip(CASES, a, b):
+                same = len(x) == len(y) and len(x) > 0 and all(torch.equal(p.view(torch.int16), q.view(torch.int16)) for p, q in zip(x, y))
+                print(f"{nm}: halo64={mode} tiled={tiled} vs the two-wave kernel on plain weights:", "bit-identical" if same else "DIFFERENT")
+                rc |= int(not same)
     except Exception as ex:      # noqa: BLE001
         print("compare failed:", ex)
         rc |= 1
     if "--time" in sys.argv:
         for rnd in range(2):
-            for mode in ("0", "2"):
+            for mode, tiled in runs:
                 try:
-                    subprocess.run([sys.executable, __file__, "--child", mode, "time"], timeout=120)
+                    subprocess.run([sys.executable, __file__, "--child", mode, tiled, "time"], timeout=120)
                 except subprocess.TimeoutExpired:
-                    print("mode", mode, "time TIMED OUT", flush=True)
+                    print("halo64", mode, "tiled", tiled, "time TIMED OUT", flush=True)
     sys.exit(rc)
 
 

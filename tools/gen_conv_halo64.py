@@ -25,12 +25,15 @@ import sys
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--abl", default="", help="timing ablations (results wrong): w = no weight requests, s = no slab requests, r = no fragment reads")
+ap.add_argument("--gather", action="store_true", help="weights in the plain [Cout][27][Cin] order (the first version: every 16-byte piece of a request from another row); "
+                "default: the tiled order of m4d_conv_pack_weights, every request one contiguous KiB")
 ap.add_argument("-o", default="more4d_amd/csrc/conv_halo64_gen.inc")
 args = ap.parse_args()
 
 MT, NT = 5, 3
 WG_BYTES, WTAP = 9216, 3072
 SLAB = 16384
+CKSTEP = 32 if args.gather else 27 * 1024        # weight soffset step per 16-channel chunk
 W_OFF, S_OFF = 0, 3 * WG_BYTES                 # weight ring, slab ring (bytes from the workgroup's LDS base)
 PITCHB = 40 * 32                               # bytes of one halo row
 
@@ -120,9 +123,11 @@ def dma_slab(slot, soff_reg):
 
 def w_soff(g, chunk_ahead, dst):
     """soffset of weight group g of the chunk `chunk_ahead` chunks after the current one: g * GS + CKB + 32 * chunk_ahead"""
+    if not args.gather:      # tiled: unit (row block, chunk, tap) = 1 KiB, taps of a chunk consecutive
+        return [f"s_add_u32 s{dst}, s{CKB}, 0x{g * 3 * 1024 + chunk_ahead * CKSTEP:x}"]
     ins = [f"s_mul_i32 s{dst}, s{GS}, {g}", f"s_add_u32 s{dst}, s{dst}, s{CKB}"]
     if chunk_ahead:
-        ins.append(f"s_add_u32 s{dst}, s{dst}, {32 * chunk_ahead}")
+        ins.append(f"s_add_u32 s{dst}, s{dst}, {CKSTEP * chunk_ahead}")
     return ins
 
 
@@ -224,7 +229,7 @@ def swapped(line):
     return re.sub(r"v\[(\d+):(\d+)\]", rep, line)
 
 
-tail_check = [f"s_add_u32 s{CKB}, s{CKB}, 32", f"s_add_u32 s{CHO}, s{CHO}, s{CHB}", f"s_sub_u32 s{NCH}, s{NCH}, 1", f"s_cmp_eq_u32 s{NCH}, 0"]
+tail_check = [f"s_add_u32 s{CKB}, s{CKB}, 0x{CKSTEP:x}", f"s_add_u32 s{CHO}, s{CHO}, s{CHB}", f"s_sub_u32 s{NCH}, s{NCH}, 1", f"s_cmp_eq_u32 s{NCH}, 0"]
 emit(tail_check)
 emit(f"s_cbranch_scc1 {label('done')}")
 emit([swapped(l) for l in first])
