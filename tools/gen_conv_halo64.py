@@ -27,6 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--abl", default="", help="timing ablations (results wrong): w = no weight requests, s = no slab requests, r = no fragment reads")
 ap.add_argument("--gather", action="store_true", help="weights in the plain [Cout][27][Cin] order (the first version: every 16-byte piece of a request from another row); "
                 "default: the tiled order of m4d_conv_pack_weights, every request one contiguous KiB")
+ap.add_argument("--ahead", type=int, default=1, help="fragments are read this many taps ahead of their MFMAs (1: two register sets; 2: three sets — built and measured: bit-identical, same time, the reads cost LDS throughput, not latency)")
 ap.add_argument("-o", default="more4d_amd/csrc/conv_halo64_gen.inc")
 args = ap.parse_args()
 
@@ -45,12 +46,15 @@ WO = [28 + i for i in range(5)]                                       # weight D
 TMP = [34, 35]
 
 
+NBUF = args.ahead + 1              # fragment register sets
+
+
 def FA(buf, mi):
     return 64 + (buf * MT + mi) * 4
 
 
 def FW(buf, ni):
-    return 104 + (buf * NT + ni) * 4
+    return 64 + NBUF * MT * 4 + (buf * NT + ni) * 4
 
 
 def ACC(mi, ni):
@@ -172,69 +176,51 @@ for r in range(MT * NT * 16):
     emit(f"v_accvgpr_write_b32 a{r}, v{TMP[1]}")
 emit("s_waitcnt vmcnt(0)")
 emit("s_barrier")
-emit(frag_reads(0, 0, 0, 0, 0))                                # tap 0 of step 0
+def tap_coords(T):
+    """(slab slot, dh, weight slot, dw) of tap T of a chunk (T >= 27: of the next chunk — same slots: three slabs, nine weight groups per chunk)"""
+    T %= 27
+    return (T // 9) % 3, (T // 3) % 3, (T // 3) % 3, T % 3
+
+
+UNROLL = {2: 2, 3: 1}[NBUF]        # chunks per loop body: 27 taps per chunk must line up with the register sets
+for T in range(args.ahead):        # taps 0 .. ahead - 1 of chunk 0
+    emit(frag_reads(T % NBUF, *tap_coords(T)))
 emit(label("chunk") + ":")
-buf = 0
-for dt in range(3):
-    for dh in range(3):
-        g = dt * 3 + dh
-        # ---- step boundary: weight group g + 1 (and the slab of step g + 1) have landed; weight slot (g + 2) % 3 and, when dh == 0,
-        # slab slot (dt + 2) % 3 are free.  In flight and allowed to stay: the slab requested in the previous step (8 pieces, issued
-        # behind that step's weight pieces).  (The very first boundary has nothing to wait for: same code, the counters are zero.)
-        emit([f"s_waitcnt vmcnt({8 if dh == 1 and 's' not in args.abl else 0})", "s_barrier"])
-        g2, c2 = (g + 2) % 9, (g + 2) // 9
-        groups = [w_soff(g2, c2, ST[1]) + dma_w((g + 2) % 3, ST[1])[0]] + dma_w((g + 2) % 3, ST[1])[1:]
-        if "w" in args.abl:
-            groups = []
-        if dh == 0 and "s" not in args.abl:
-            j2 = dt + 2
-            sl = dma_slab(j2 % 3, ST[0])
-            groups += [s_soff(j2 % 3, j2 // 3, ST[0]) + sl[0]] + sl[1:]
-        for dw in range(3):
-            mf = tap_mfmas(buf)
-            # fragments of the next tap: (dh, dw + 1) of this step, or tap 0 of the next step (slab of (dt', dh'), weight slot (g + 1) % 3)
-            if dw < 2:
-                nxt = frag_reads(buf ^ 1, dt, dh, g % 3, dw + 1)
-            else:
-                ndt, ndh = ((dt, dh + 1) if dh < 2 else ((dt + 1) % 3, 0))
-                nxt = frag_reads(buf ^ 1, ndt, ndh, (g + 1) % 3, 0)
-            emit("s_waitcnt lgkmcnt(0)")
-            for i, m in enumerate(mf):
-                emit(m)
-                if 1 <= i <= 8:
-                    if "r" not in args.abl:
-                        emit(nxt[i - 1])                 # one fragment read behind each of MFMAs 1..8
-                elif i >= 9 and groups:
-                    emit(groups.pop(0))              # one DMA piece (m0, nop, request) behind each of MFMAs 9..14: weights first
-            buf ^= 1
-        assert not groups
-assert buf == 1          # nine taps-of-three = 27 taps: the buffers swap roles every chunk -> emit the loop body twice
-body_start = out.index(label("chunk") + ":")
-# (27 taps per chunk is odd: unroll two chunks so that the fragment buffers line up at the loop edge)
-first = out[body_start + 1:]
-swap = {}
-for b_ in range(2):
-    for mi in range(MT):
-        swap[FA(b_, mi)] = FA(b_ ^ 1, mi)
-    for ni in range(NT):
-        swap[FW(b_, ni)] = FW(b_ ^ 1, ni)
-
-
-def swapped(line):
-    import re
-
-    def rep(m):
-        a, b = int(m.group(1)), int(m.group(2))
-        return f"v[{swap[a]}:{swap[a] + b - a}]" if a in swap else m.group(0)
-    return re.sub(r"v\[(\d+):(\d+)\]", rep, line)
-
-
 tail_check = [f"s_add_u32 s{CKB}, s{CKB}, 0x{CKSTEP:x}", f"s_add_u32 s{CHO}, s{CHO}, s{CHB}", f"s_sub_u32 s{NCH}, s{NCH}, 1", f"s_cmp_eq_u32 s{NCH}, 0"]
-emit(tail_check)
-emit(f"s_cbranch_scc1 {label('done')}")
-emit([swapped(l) for l in first])
-emit(tail_check)
-emit(f"s_cbranch_scc0 {label('chunk')}")
+for u in range(UNROLL):
+    for dt in range(3):
+        for dh in range(3):
+            g = dt * 3 + dh
+            # ---- step boundary: weight group g + 1 (and the slab of step g + 1) have landed; weight slot (g + 2) % 3 and, when dh == 0,
+            # slab slot (dt + 2) % 3 are free.  In flight and allowed to stay: the slab requested in the previous step (8 pieces, issued
+            # behind that step's weight pieces).  (The very first boundary has nothing to wait for: same code, the counters are zero.)
+            emit([f"s_waitcnt vmcnt({8 if dh == 1 and 's' not in args.abl else 0})", "s_barrier"])
+            g2, c2 = (g + 2) % 9, (g + 2) // 9
+            groups = [w_soff(g2, c2, ST[1]) + dma_w((g + 2) % 3, ST[1])[0]] + dma_w((g + 2) % 3, ST[1])[1:]
+            if "w" in args.abl:
+                groups = []
+            if dh == 0 and "s" not in args.abl:
+                j2 = dt + 2
+                sl = dma_slab(j2 % 3, ST[0])
+                groups += [s_soff(j2 % 3, j2 // 3, ST[0]) + sl[0]] + sl[1:]
+            for dw in range(3):
+                T = u * 27 + g * 3 + dw                  # tap counter over the loop body
+                buf = T % NBUF
+                mf = tap_mfmas(buf)
+                # the fragments of tap T + ahead go into the register set tap T - 1 has just released
+                nxt = frag_reads((T + args.ahead) % NBUF, *tap_coords(g * 3 + dw + args.ahead))
+                # the reads of the taps in between (issued behind the previous taps' MFMAs, LDS returns in order) may stay in flight
+                emit(f"s_waitcnt lgkmcnt({0 if 'r' in args.abl else min(15, (args.ahead - 1) * (MT + NT))})")
+                for i, m in enumerate(mf):
+                    emit(m)
+                    if 1 <= i <= 8:
+                        if "r" not in args.abl:
+                            emit(nxt[i - 1])                 # one fragment read behind each of MFMAs 1..8
+                    elif i >= 9 and groups:
+                        emit(groups.pop(0))              # one DMA piece (m0, nop, request) behind each of MFMAs 9..14: weights first
+            assert not groups
+    emit(tail_check)
+    emit(f"s_cbranch_scc1 {label('done')}" if u < UNROLL - 1 else f"s_cbranch_scc0 {label('chunk')}")
 emit(label("done") + ":")
 # drain: the last prefetched fragments and the over-requested DMA pieces must not land in the epilogue's staging blocks
 emit("s_waitcnt lgkmcnt(0)")
