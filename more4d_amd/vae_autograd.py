@@ -45,20 +45,22 @@ def conv_dgrad(dy, wp, cop, cip, k, t, h, w, stride=(1, 1, 1)):
     kt, kh, kw = k
     wd, cop8 = _flipped(wp, cop, k, cip)
     T, dev = dy.dtype, dy.device
+    # (the data-gradient conv stages its flipped weights from a tiled copy like the forward, ops.conv_pack_weights)
+    wt = ops.conv_pack_weights(wd, cop8) if (wd.is_cuda and wd.dtype == torch.bfloat16 and kh == 3 and kw == 3 and cop8 % 16 == 0) else None
     if stride == (1, 1, 1):
         buf = torch.zeros((t + kt - 1, h * w, cop8), device=dev, dtype=T)
         buf[:t, :, :cop] = dy.view(t, h * w, cop)
-        return ops.conv_cl(buf, wd, None, Tin=t + kt - 1, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, kh // 2, kw // 2), out_thw=(t, h, w))
+        return ops.conv_cl(buf, wd, None, Tin=t + kt - 1, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, kh // 2, kw // 2), out_thw=(t, h, w), w_tiled=wt)
     if stride == (1, 2, 2):
         ho, wo = h // 2, w // 2
         buf = torch.zeros((t, h, w, cop8), device=dev, dtype=T)
         buf[:, 0:2 * ho:2, 0:2 * wo:2, :cop] = dy.view(t, ho, wo, cop)           # zero insertion: D[2i, 2j] = dy[i, j]
-        return ops.conv_cl(buf, wd, None, Tin=t, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, kh - 1, kw - 1), out_thw=(t, h, w))
+        return ops.conv_cl(buf, wd, None, Tin=t, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, kh - 1, kw - 1), out_thw=(t, h, w), w_tiled=wt)
     if stride == (2, 1, 1):
         to = dy.shape[0] // (h * w)
         buf = torch.zeros((t + 2, h * w, cop8), device=dev, dtype=T)             # frame 0 = D[-1] = 0, frame 1 + 2j = dy[j]
         buf[1:1 + 2 * to:2, :, :cop] = dy.view(to, h * w, cop)
-        return ops.conv_cl(buf, wd, None, Tin=t + 2, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, 0, 0), out_thw=(t, h, w))
+        return ops.conv_cl(buf, wd, None, Tin=t + 2, Hin=h, Win=w, Cin=cop8, k=k, pad=(0, 0, 0), out_thw=(t, h, w), w_tiled=wt)
     raise NotImplementedError(stride)
 
 
@@ -227,7 +229,7 @@ class _TrainRunner(_Runner):
         fill(st.chunk(t))
         xin = st.window(t)
         y = ops.conv_cl(xin, wgt, b, Tin=st.n_tail + t, Hin=h, Win=w, Cin=cip, k=k, pad=(0, kh // 2, kw // 2),
-                        out_thw=(t, h, w), resid=None if resid is None else resid.data, out=out)
+                        out_thw=(t, h, w), resid=None if resid is None else resid.data, out=out, w_tiled=self.tiled(conv))
         ya = _Act(y, t, h, w, cop)                         # (no roll: the tails of the NEXT chunk come from its own snapshot)
         self.last_act = ya
 
@@ -258,7 +260,8 @@ class _TrainRunner(_Runner):
             ho, wo, pad = hl, wl, kh // 2
         xps = src.data.stride(0)
         y = ops.conv_cl(src.data, wgt, b, Tin=t, Hin=hl, Win=wl, Cin=cip, k=k, stride=(1, stride_hw, stride_hw), pad=(0, pad, pad),
-                        out_thw=(t, ho, wo), resid=None if resid is None else resid.data, out=out, x_pixel_stride=xps)
+                        out_thw=(t, ho, wo), resid=None if resid is None else resid.data, out=out, x_pixel_stride=xps,
+                        w_tiled=self.tiled(conv))
         ya = _Act(y, t, ho, wo, cop)
         self.last_act = ya
 
