@@ -247,7 +247,7 @@ def secondary_figures(model, cfg, dev):
         px = 480 * 832
         fl = px * (6.657e6 + 48 * 5.003e6) + px * (10.748e6 + 48 * 8.445e6)
         tf = fl / ((r["ms"]["encode"] + r["ms"]["decode"]) / 1e3) / 1e12
-        out["roofline_vae"] = {"kernel": "conv_halo_kernel (78 % of VAE kernel time) inside vae.encode + vae.decode, whole-call FLOPs / wall time",
+        out["roofline_vae"] = {"kernel": "conv_halo64_kernel + conv_halo_kernel (80 % of VAE kernel time; weights staged from the tiled copies of m4d_conv_pack_weights) inside vae.encode + vae.decode, whole-call FLOPs / wall time",
                                "bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
                                "algorithmic_tflop": fl / 1e12}
     except Exception as ex:

@@ -49,6 +49,8 @@ cp(f"{src}/bwd64_pmc_summary.md", "bwd64_pmc_summary.md")
 cp(f"{src}/depth40_distance.log", "depth40_distance.log")
 cp(f"{src}/conv64_check_time.log", "conv64_check_time.log")
 cp(f"{src}/ab_gemm_tail.log", "ab_gemm_tail.log")
+cp(f"{src}/ab_conv_tiled.log", "ab_conv_tiled.log")
+cp(f"{src}/ab_sp_overlap.log", "ab_sp_overlap.log")
 for f in glob.glob(f"{src}/vae_train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "vae_train_kernel_stats.csv")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):
