@@ -153,15 +153,23 @@ def main():
                     run()
                 torch.cuda.synchronize()
                 ops.launch_counts(reset=True)
-                t0 = time.perf_counter()
+                from bench import ClockMonitor
                 n = 40
-                for _ in range(n):
+                for _ in range(10 * n):          # (long enough for the clock samples: the board settles on its power limit)
                     run()
                 torch.cuda.synchronize()
-                ms = (time.perf_counter() - t0) / n * 1e3
+                mon = ClockMonitor(0).start()
+                t0 = time.perf_counter()
+                for _ in range(50 * n):
+                    run()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / (50 * n) * 1e3
+                mon.stop()
+                ck = mon.region()
                 fl = 2.0 * (T - 2) * H * W * C * 27 * C
                 kern = "+".join(k for k, v in ops.launch_counts().items() if v and k.startswith("conv_halo"))
                 print(f"halo64={mode} tiled={int(tiled)} {lay} [{kern}]: {ms:.4f} ms  {fl / ms / 1e9:.0f} TF  frac {fl / ms / 1e9 / 2500:.3f}  "
+                      f"clock {ck.get('effective_clock_mhz') or 0:.0f} MHz power {(ck.get('socket_power_w') or {}).get('mean') or 0:.0f} W  "
                       f"digest {float(out.float().abs().double().sum()):.10e}", flush=True)
             return
         bad = False

@@ -24,9 +24,12 @@ import argparse
 import sys
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--abl", default="", help="timing ablations (results wrong): w = no weight requests, s = no slab requests, r = no fragment reads")
+ap.add_argument("--abl", default="", help="timing ablations (results wrong): w = no weight requests, s = no slab requests, r = no fragment reads, "
+                "p = no pixel-fragment reads, q = no weight-fragment reads")
 ap.add_argument("--gather", action="store_true", help="weights in the plain [Cout][27][Cin] order (the first version: every 16-byte piece of a request from another row); "
                 "default: the tiled order of m4d_conv_pack_weights, every request one contiguous KiB")
+ap.add_argument("--window", action="store_true", help="pixel fragments as a sliding window of image rows per (dt, dw): the five rows of tap (dh, dw) are rows dh .. dh + 4 of "
+                "seven, every row fragment is read ONCE per frame (21 reads per 9 taps instead of 45); same MFMA order, same bits")
 ap.add_argument("--ahead", type=int, default=1, help="fragments are read this many taps ahead of their MFMAs (1: two register sets; 2: three sets — built and measured: bit-identical, same time, the reads cost LDS throughput, not latency)")
 ap.add_argument("-o", default="more4d_amd/csrc/conv_halo64_gen.inc")
 args = ap.parse_args()
@@ -101,9 +104,11 @@ def frag_reads(buf, slab_slot, dh, w_slot, dw):
     """the 5 pixel + 3 weight fragments of tap (dh, dw) of the step that reads slab slot / weight slot"""
     ins = []
     for mi in range(MT):
-        ins.append(f"ds_read_b128 {vr(FA(buf, mi), 4)}, v{AB[mi][dw]} offset:{slab_slot * SLAB + dh * PITCHB}")
+        if "p" not in args.abl:
+            ins.append(f"ds_read_b128 {vr(FA(buf, mi), 4)}, v{AB[mi][dw]} offset:{slab_slot * SLAB + dh * PITCHB}")
     for ni in range(NT):
-        ins.append(f"ds_read_b128 {vr(FW(buf, ni), 4)}, v{WF} offset:{w_slot * WG_BYTES + dw * WTAP + ni * 1024}")
+        if "q" not in args.abl:
+            ins.append(f"ds_read_b128 {vr(FW(buf, ni), 4)}, v{WF} offset:{w_slot * WG_BYTES + dw * WTAP + ni * 1024}")
     return ins
 
 
@@ -182,45 +187,102 @@ def tap_coords(T):
     return (T // 9) % 3, (T // 3) % 3, (T // 3) % 3, T % 3
 
 
-UNROLL = {2: 2, 3: 1}[NBUF]        # chunks per loop body: 27 taps per chunk must line up with the register sets
-for T in range(args.ahead):        # taps 0 .. ahead - 1 of chunk 0
-    emit(frag_reads(T % NBUF, *tap_coords(T)))
-emit(label("chunk") + ":")
-tail_check = [f"s_add_u32 s{CKB}, s{CKB}, 0x{CKSTEP:x}", f"s_add_u32 s{CHO}, s{CHO}, s{CHB}", f"s_sub_u32 s{NCH}, s{NCH}, 1", f"s_cmp_eq_u32 s{NCH}, 0"]
-for u in range(UNROLL):
-    for dt in range(3):
-        for dh in range(3):
-            g = dt * 3 + dh
-            # ---- step boundary: weight group g + 1 (and the slab of step g + 1) have landed; weight slot (g + 2) % 3 and, when dh == 0,
-            # slab slot (dt + 2) % 3 are free.  In flight and allowed to stay: the slab requested in the previous step (8 pieces, issued
-            # behind that step's weight pieces).  (The very first boundary has nothing to wait for: same code, the counters are zero.)
-            emit([f"s_waitcnt vmcnt({8 if dh == 1 and 's' not in args.abl else 0})", "s_barrier"])
-            g2, c2 = (g + 2) % 9, (g + 2) // 9
-            groups = [w_soff(g2, c2, ST[1]) + dma_w((g + 2) % 3, ST[1])[0]] + dma_w((g + 2) % 3, ST[1])[1:]
-            if "w" in args.abl:
-                groups = []
-            if dh == 0 and "s" not in args.abl:
-                j2 = dt + 2
-                sl = dma_slab(j2 % 3, ST[0])
-                groups += [s_soff(j2 % 3, j2 // 3, ST[0]) + sl[0]] + sl[1:]
-            for dw in range(3):
-                T = u * 27 + g * 3 + dw                  # tap counter over the loop body
-                buf = T % NBUF
-                mf = tap_mfmas(buf)
-                # the fragments of tap T + ahead go into the register set tap T - 1 has just released
-                nxt = frag_reads((T + args.ahead) % NBUF, *tap_coords(g * 3 + dw + args.ahead))
-                # the reads of the taps in between (issued behind the previous taps' MFMAs, LDS returns in order) may stay in flight
-                emit(f"s_waitcnt lgkmcnt({0 if 'r' in args.abl else min(15, (args.ahead - 1) * (MT + NT))})")
-                for i, m in enumerate(mf):
-                    emit(m)
-                    if 1 <= i <= 8:
-                        if "r" not in args.abl:
-                            emit(nxt[i - 1])                 # one fragment read behind each of MFMAs 1..8
-                    elif i >= 9 and groups:
-                        emit(groups.pop(0))              # one DMA piece (m0, nop, request) behind each of MFMAs 9..14: weights first
-            assert not groups
-    emit(tail_check)
-    emit(f"s_cbranch_scc1 {label('done')}" if u < UNROLL - 1 else f"s_cbranch_scc0 {label('chunk')}")
+if args.window:
+    # ---- sliding window: register slot (R % 5, dw) holds row R of the wave's seven halo rows (R = mi + dh) at column shift dw.  Row 5
+    # takes over row 0's registers once tap (dh 0, dw) is done, row 6 row 1's; the next frame's rows 0..4 follow two taps after the
+    # last use of what they replace.  Reads issued in tap t (relative to the frame's nine taps), each one tap or more before its
+    # first use and one tap or more after the last use of the registers' previous content:
+    WSCHED = {0: [(0, 2, 1), (0, 3, 1), (0, 4, 1), (0, 0, 2)], 1: [(0, 1, 2), (0, 2, 2), (0, 3, 2), (0, 4, 2)], 2: [(0, 5, 0), (0, 5, 1)],
+              3: [(0, 5, 2)], 4: [(0, 6, 0)], 5: [(0, 6, 1)], 6: [(0, 6, 2)], 7: [(1, 0, 0), (1, 1, 0), (1, 2, 0)],
+              8: [(1, 3, 0), (1, 4, 0), (1, 0, 1), (1, 1, 1)]}          # (frame ahead, row, dw)
+    assert args.ahead == 1 and sum(len(v) for v in WSCHED.values()) == 21
+
+    def PS(slot, dw):
+        return 64 + (slot * 3 + dw) * 4
+
+    def FWW(buf, ni):
+        return 64 + 60 + (buf * NT + ni) * 4
+
+    def row_read(dt, R, dw):
+        return f"ds_read_b128 {vr(PS(R % 5, dw), 4)}, v{AB[0][dw]} offset:{(dt % 3) * SLAB + R * PITCHB}"
+
+    def w_reads(buf, T):
+        _, _, w_slot, dw = tap_coords(T)
+        return [f"ds_read_b128 {vr(FWW(buf, ni), 4)}, v{WF} offset:{w_slot * WG_BYTES + dw * WTAP + ni * 1024}" for ni in range(NT)]
+
+    for t in (7, 8):               # what the two taps in front of frame 0 would have read
+        emit([row_read(0, R, dw) for (_, R, dw) in WSCHED[t]])
+    emit(w_reads(0, 0))
+    emit(label("chunk") + ":")
+    tail_check = [f"s_add_u32 s{CKB}, s{CKB}, 0x{CKSTEP:x}", f"s_add_u32 s{CHO}, s{CHO}, s{CHB}", f"s_sub_u32 s{NCH}, s{NCH}, 1", f"s_cmp_eq_u32 s{NCH}, 0"]
+    for u in range(2):
+        for dt in range(3):
+            for dh in range(3):
+                g = dt * 3 + dh
+                emit([f"s_waitcnt vmcnt({8 if dh == 1 and 's' not in args.abl else 0})", "s_barrier"])
+                g2, c2 = (g + 2) % 9, (g + 2) // 9
+                groups = [w_soff(g2, c2, ST[1]) + dma_w((g + 2) % 3, ST[1])[0]] + dma_w((g + 2) % 3, ST[1])[1:]
+                if dh == 0:
+                    j2 = dt + 2
+                    sl = dma_slab(j2 % 3, ST[0])
+                    groups += [s_soff(j2 % 3, j2 // 3, ST[0]) + sl[0]] + sl[1:]
+                for dw in range(3):
+                    T = u * 27 + g * 3 + dw
+                    buf = T % 2
+                    mf = [f"v_mfma_f32_32x32x16_bf16 {ar(ACC(mi, ni), 16)}, {vr(FWW(buf, ni), 4)}, {vr(PS((mi + dh) % 5, dw), 4)}, {ar(ACC(mi, ni), 16)}"
+                          for mi in range(MT) for ni in range(NT)]
+                    nxt = w_reads(buf ^ 1, g * 3 + dw + 1) + [row_read(dt + ahead_f, R, dw_) for (ahead_f, R, dw_) in WSCHED[dh * 3 + dw]]
+                    assert len(nxt) <= 8
+                    emit("s_waitcnt lgkmcnt(0)")
+                    for i, m in enumerate(mf):
+                        emit(m)
+                        if 1 <= i <= 8 and i - 1 < len(nxt):
+                            emit(nxt[i - 1])
+                        elif i >= 9 and groups:
+                            emit(groups.pop(0))
+                assert not groups
+        emit(tail_check)
+        emit(f"s_cbranch_scc1 {label('done')}" if u == 0 else f"s_cbranch_scc0 {label('chunk')}")
+else:
+    UNROLL = {2: 2, 3: 1}[NBUF]        # chunks per loop body: 27 taps per chunk must line up with the register sets
+    for T in range(args.ahead):        # taps 0 .. ahead - 1 of chunk 0
+        emit(frag_reads(T % NBUF, *tap_coords(T)))
+    emit(label("chunk") + ":")
+    tail_check = [f"s_add_u32 s{CKB}, s{CKB}, 0x{CKSTEP:x}", f"s_add_u32 s{CHO}, s{CHO}, s{CHB}", f"s_sub_u32 s{NCH}, s{NCH}, 1", f"s_cmp_eq_u32 s{NCH}, 0"]
+    for u in range(UNROLL):
+        for dt in range(3):
+            for dh in range(3):
+                g = dt * 3 + dh
+                # ---- step boundary: weight group g + 1 (and the slab of step g + 1) have landed; weight slot (g + 2) % 3 and, when dh == 0,
+                # slab slot (dt + 2) % 3 are free.  In flight and allowed to stay: the slab requested in the previous step (8 pieces, issued
+                # behind that step's weight pieces).  (The very first boundary has nothing to wait for: same code, the counters are zero.)
+                emit([f"s_waitcnt vmcnt({8 if dh == 1 and 's' not in args.abl else 0})", "s_barrier"])
+                g2, c2 = (g + 2) % 9, (g + 2) // 9
+                groups = [w_soff(g2, c2, ST[1]) + dma_w((g + 2) % 3, ST[1])[0]] + dma_w((g + 2) % 3, ST[1])[1:]
+                if "w" in args.abl:
+                    groups = []
+                if dh == 0 and "s" not in args.abl:
+                    j2 = dt + 2
+                    sl = dma_slab(j2 % 3, ST[0])
+                    groups += [s_soff(j2 % 3, j2 // 3, ST[0]) + sl[0]] + sl[1:]
+                for dw in range(3):
+                    T = u * 27 + g * 3 + dw                  # tap counter over the loop body
+                    buf = T % NBUF
+                    mf = tap_mfmas(buf)
+                    # the fragments of tap T + ahead go into the register set tap T - 1 has just released
+                    nxt = frag_reads((T + args.ahead) % NBUF, *tap_coords(g * 3 + dw + args.ahead))
+                    # the reads of the taps in between (issued behind the previous taps' MFMAs, LDS returns in order) may stay in flight
+                    emit(f"s_waitcnt lgkmcnt({0 if 'r' in args.abl else min(15, (args.ahead - 1) * (MT + NT))})")
+                    for i, m in enumerate(mf):
+                        emit(m)
+                        if 1 <= i <= 8:
+                            if "r" not in args.abl and i - 1 < len(nxt):
+                                emit(nxt[i - 1])                 # one fragment read behind each of MFMAs 1..8
+                        elif i >= 9 and groups:
+                            emit(groups.pop(0))              # one DMA piece (m0, nop, request) behind each of MFMAs 9..14: weights first
+                assert not groups
+        emit(tail_check)
+        emit(f"s_cbranch_scc1 {label('done')}" if u < UNROLL - 1 else f"s_cbranch_scc0 {label('chunk')}")
 emit(label("done") + ":")
 # drain: the last prefetched fragments and the over-requested DMA pieces must not land in the epilogue's staging blocks
 emit("s_waitcnt lgkmcnt(0)")
