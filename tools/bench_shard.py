@@ -14,6 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import CFG_14B, ClockMonitor, build_model, standin_group  # noqa: E402
+import more4d_amd.models.wan_transformer4d as _wt  # noqa: E402
 
 
 def main():
@@ -62,7 +63,7 @@ def main():
     print(json.dumps({"world": args.world, "mode": args.mode, "sp_world": spw, "batch_per_rank": B,
                       "effective_clock_mhz": ck.get("effective_clock_mhz"), "socket_power_w": ck.get("socket_power_w", {}).get("mean"),
                       "rank_ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": t_host * 1e3, "finite": bool(torch.isfinite(out.float()).all()),
-                      "sp_overlap": os.environ.get("M4D_SP_OVERLAP", "1"), "digest": digest}))
+                      "sp_overlap": int(_wt._SP_OVERLAP), "digest": digest}))
 
 
 if __name__ == "__main__":

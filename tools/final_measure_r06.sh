@@ -29,7 +29,7 @@ bash tools/ab_conv_tiled.sh > $O/ab_conv_tiled.log 2>&1; grep "^==\|roundtrip" $
 bash tools/ab_sp_overlap.sh > $O/ab_sp_overlap.log 2>&1; cut -c1-200 $O/ab_sp_overlap.log
 timeout 600 python tools/ab_gemm_tail.py 2>&1 | grep -v amdgpu.ids > $O/ab_gemm_tail.log; tail -15 $O/ab_gemm_tail.log
 find $O -name "*kernel_trace.csv" -size +5M -delete; find $O -name "*counter_collection.csv" -size +5M -delete
-for m in cfg-sp sp; do for w in 2 4 8; do timeout 400 python tools/bench_shard.py --world $w --mode $m --steps 2 2>&1 | tail -1; done; done > $O/bench_shard.log 2>&1
+{ timeout 400 python tools/bench_shard.py --world 1 --mode sp --steps 2 2>&1 | tail -1; for m in cfg-sp sp; do for w in 2 4 8; do timeout 400 python tools/bench_shard.py --world $w --mode $m --steps 2 2>&1 | tail -1; done; done; } > $O/bench_shard.log 2>&1
 M4D_SP_MODE=ulysses timeout 400 python tools/bench_shard.py --world 8 --mode cfg-sp --steps 2 2>&1 | tail -1 >> $O/bench_shard.log; cat $O/bench_shard.log
 for p in cfg-sp sp; do timeout 300 python bench.py --gpus 8 --launch-check --parallelism $p 2>&1 | tail -1; done > $O/launch_check_8.log 2>&1; cat $O/launch_check_8.log | cut -c1-300
 timeout 300 python tools/bench_vae_train.py 2>&1 | tail -1 > $O/vae_train_bench.json

@@ -19,7 +19,7 @@ for line in open(os.path.join(src, "trace.log")):
 
 import re
 
-FIXED = ("conv_cl256_kernel", "conv_cl_kernel", "rmsnorm_silu_cl_kernel", "groupnorm_apply_kernel", "groupnorm_stats_kernel")
+FIXED = ("conv_halo64_kernel", "conv_cl256_kernel", "conv_cl_kernel", "rmsnorm_silu_cl_kernel", "groupnorm_apply_kernel", "groupnorm_stats_kernel")
 KEYS = []
 
 
