@@ -401,21 +401,24 @@ int launch_halo(ConvArgs& p, hipStream_t st) {
     return 0;
 }
 
-// one wave per SIMD, 10 x 32 patches, 96-channel tiles (conv_halo64.h)
+// one wave per SIMD (conv_halo64.h): KT = 3: 10 x 32 patches, 96-channel tiles; KT = 1: 8 x 32 patches, 128-channel tiles
+template <int KT, int MT, int NT>
 int launch_halo64(ConvArgs& p, hipStream_t st) {
+    using C64 = Halo64Cfg<KT, MT, NT>;
     static PerDeviceOnce configured;
     if (configured.pending()) {
-        if (hipFuncSetAttribute((const void*)conv_halo64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, halo64::LDS_BYTES) != hipSuccess) {
-            m4d_set_error("conv_cl: cannot enable %d bytes of LDS", halo64::LDS_BYTES);
+        if (hipFuncSetAttribute((const void*)conv_halo64_kernel<KT, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, C64::LDS_BYTES) != hipSuccess) {
+            m4d_set_error("conv_cl: cannot enable %d bytes of LDS", C64::LDS_BYTES);
             return -3;
         }
         configured.mark();
     }
-    p.tiles_m = p.To * ((p.Ho + halo64::TH - 1) / halo64::TH) * ((p.Wo + 31) / 32);
-    p.tiles_n = p.Cout / 96;
+    p.tiles_m = p.To * ((p.Ho + C64::TH - 1) / C64::TH) * ((p.Wo + 31) / 32);
+    p.tiles_n = p.Cout / (NT * 32);
     m4d_count_launch(M4D_KC_CONV_HALO64);
     if (p.post_out) m4d_count_launch(p.resid ? M4D_KC_CONV_FUSED_NORM_RESID : M4D_KC_CONV_FUSED_NORM);
-    hipLaunchKernelGGL(conv_halo64_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(128), halo64::LDS_BYTES, st, p);
+    if (p.gn_partial) m4d_count_launch(M4D_KC_CONV_GNSTATS);
+    hipLaunchKernelGGL((conv_halo64_kernel<KT, MT, NT>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(128), C64::LDS_BYTES, st, p);
     return 0;
 }
 
@@ -423,6 +426,15 @@ int launch_halo64(ConvArgs& p, hipStream_t st) {
 // 32 / 64, everything else tiles of 128
 template <int KT, int KH, int TH, int TW>
 int launch_halo_nt(ConvArgs& p, hipStream_t st) {
+    if constexpr (KT == 1 && KH == 3 && TH == 8 && TW == 32) {
+        // the 3 x 3 conv on 128-channel tiles (the adaptors' convs, trajectory_module.py:54-71) as one wave per SIMD: the same 8 x 32 patches
+        // (GroupNorm-statistics blocks, fused norm) and the same accumulation order as conv_halo_kernel<1, 3, 8, 32, 4, 2> — bit-identical
+        // Built, bit-identical, and NOT faster (tools/check_conv64k1.py --time, same box: 1.488 vs 1.481 ms at 128 -> 128 channels, 480 x 832, 12 frames:
+        // nine taps per chunk make a 72-tap main loop, the per-workgroup prologue and epilogue dominate both kernels) — off unless M4D_CONV_HALO64K1=1
+        M4D_ENV_ONCE(h64k1, "M4D_CONV_HALO64K1", 0);
+        if (h64k1 && p.wt && p.Cout % 128 == 0 && !p.ups && !p.tsplit && p.Cin % 16 == 0 && (int64_t)p.To * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32) * (p.Cout / 128) > 256)
+            return launch_halo64<1, 4, 4>(p, st);
+    }
     if (p.gn_partial) return launch_halo<KT, KH, TH, TW, 4, 2>(p, st);       // (Cout = 128: one 128-channel tile per patch)
     if (p.post_out) {        // fused next-layer norm: one workgroup must own all channels of a pixel
         switch (p.Cout) {
@@ -461,7 +473,7 @@ int launch_halo_auto(ConvArgs& p, hipStream_t st) {
             //  are 32 bytes out of every Cin * 2, it measured 5 % SLOWER than the 12 x 32 kernel: tools/check_conv64.py --time.  h64 = 2: both)
             if (h64 && p.wt && (p.xplane || h64 == 2) && p.kt == 3 && wide && !p.ups && !p.tsplit && p.Cout % 96 == 0 &&
                 (((p.Ho + 9) / 10) * 10 - p.Ho) * 20 <= p.Ho)
-                return launch_halo64(p, st);
+                return launch_halo64<3, 5, 3>(p, st);
             if (p.kt == 3) return wide ? launch_halo<3, 3, 12, 32, 3, 3>(p, st) : launch_halo<3, 3, 24, 16, 3, 3>(p, st);
             return wide ? launch_halo<1, 3, 12, 32, 3, 3>(p, st) : launch_halo<1, 3, 24, 16, 3, 3>(p, st);
         }

@@ -17,18 +17,32 @@
 #define M4D_CV64_ACLOB "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 #define M4D_CV64_SCLOB "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
 
-namespace halo64 {
-constexpr int MT = 5, NT = 3, NWAVE = 2, TH = NWAVE * MT, TW = 32;
-constexpr int PITCH = 40, HH = TH + 2, SLAB = 16384, WG_BYTES = 3 * 96 * 32, W_RING = 3 * WG_BYTES, LDS_BYTES = W_RING + 3 * SLAB;
-static_assert(HH * PITCH * 32 <= SLAB && NWAVE * 32 * NT * 64 <= LDS_BYTES, "slab / epilogue staging must fit");
-}  // namespace halo64
+#ifndef M4D_CV64K1_INC
+#define M4D_CV64K1_INC "conv_halo64k1_gen.inc"
+#endif
 
+// LDS geometry of one instantiation (KT = 3: MT = 5, NT = 3, the 3 x 3 x 3 conv on 10 x 32 patches of 96-channel tiles; KT = 1: MT = 4, NT = 4, the
+// 3 x 3 conv on 8 x 32 patches of 128-channel tiles — the adaptors' convs, same patch as conv_halo_kernel<1, 3, 8, 32, 4, 2> so that the
+// per-patch GroupNorm statistics land in the same blocks)
+template <int KT, int MT, int NT>
+struct Halo64Cfg {
+    static constexpr int NWAVE = 2, TH = NWAVE * MT, TW = 32, PITCH = 40, HH = TH + 2;
+    static constexpr int SLAB = MT == 5 ? 16384 : 14336;          // one frame of one chunk, a whole number of KiB pieces per wave
+    static constexpr int WG_BYTES = 3 * NT * 1024, W_RING = 3 * WG_BYTES, LDS_BYTES = W_RING + 3 * SLAB;
+    static_assert(HH * PITCH * 32 <= SLAB && NWAVE * 32 * NT * 64 <= LDS_BYTES && LDS_BYTES <= 80 * 1024, "slab / epilogue staging must fit half a CU");
+    static_assert((KT == 3 && MT == 5 && NT == 3) || (KT == 1 && MT == 4 && NT == 4), "generated streams: tools/gen_conv_halo64.py --shape");
+};
+namespace halo64 { constexpr int TH = 10, LDS_BYTES = Halo64Cfg<3, 5, 3>::LDS_BYTES; }
+
+template <int KT, int MT, int NT>
 __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace halo;
     typedef bf16_t T;
-    constexpr int MT = halo64::MT, NT = halo64::NT, NWAVE = halo64::NWAVE, TH = halo64::TH, TW = halo64::TW, PITCH = halo64::PITCH, HH = halo64::HH;
-    constexpr int NB = NT * 32, EROW = NT * 64, ESW = 3, ROWS_PER_MT = 1;
+    using C64 = Halo64Cfg<KT, MT, NT>;
+    constexpr int NWAVE = C64::NWAVE, TH = C64::TH, TW = C64::TW, PITCH = C64::PITCH, HH = C64::HH;
+    constexpr int NB = NT * 32, EROW = NT * 64, ESW = NT % 2 == 0 ? 7 : 3, ROWS_PER_MT = 1, NTAPS = KT * 9;
+    constexpr int NSP = C64::SLAB / 2048, NWP = (C64::WG_BYTES / 1024 + 1) / 2;       // DMA pieces per wave: slab / weight group
     unsigned long long ts[4] = {0, 0, 0, 0}, rt0 = 0;
     (void)ts; (void)rt0;
     const int tiles_w = (p.Wo + TW - 1) / TW, tiles_h = (p.Ho + TH - 1) / TH;
@@ -60,7 +74,7 @@ __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
     const unsigned rw2 = (unsigned)(p.Cout * p.K * 2);
 #else
     const unsigned long long wbp = (unsigned long long)p.wt;
-    const unsigned rw2 = (unsigned)((p.Cout / 32) * (p.Cin / CK) * 27 * 1024);
+    const unsigned rw2 = (unsigned)((p.Cout / 32) * (p.Cin / CK) * NTAPS * 1024);
 #endif
 
     // ---- lane table (LDS offset 0, 32 dwords per work item): AB[5][3], WF, HO[8], WO[5] ----
@@ -72,12 +86,14 @@ __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
 #pragma unroll
             for (int dw = 0; dw < KW; ++dw) {
                 const int cc = li + dw;
-                tab[mi * 3 + dw] = lds0 + halo64::W_RING + (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
+                tab[mi * 3 + dw] = lds0 + C64::W_RING + (unsigned)((row * PITCH + cc) * PXB + ((hi ^ ((cc >> 3) & 1)) << 4));
             }
         }
         tab[15] = lds0 + (unsigned)(li * PXB + ((hi ^ ((li >> 3) & 1)) << 4));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {        // slab piece 2 i + wave: 64 x 16-byte slots; slot q = pixel q >> 1, physical chunk q & 1
+        for (int i = 0; i < 8; ++i) tab[16 + i] = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) {      // slab piece 2 i + wave: 64 x 16-byte slots; slot q = pixel q >> 1, physical chunk q & 1
             const int q = (i * NWAVE + wave) * 64 + lane;
             const int px = q >> 1, physc = q & 1;
             const int hh = px / PITCH, ww = px % PITCH;
@@ -87,9 +103,9 @@ __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
             tab[16 + i] = ok ? (unsigned)(((int64_t)hi_ * p.Win + wi) * pixb) + (unsigned)(c * 16) : 0xffffffffu;
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {        // weight piece 2 i + wave of a (dt, dh) group (9 pieces; wave 1's fifth repeats piece 8)
+        for (int i = 0; i < NWP; ++i) {      // weight piece 2 i + wave of a (dt, dh) group (nine pieces: wave 1's fifth repeats piece 8)
             int piece = i * NWAVE + wave;
-            if (piece > 8) piece = 8;
+            if (piece > C64::WG_BYTES / 1024 - 1) piece = C64::WG_BYTES / 1024 - 1;
             const int q = piece * 64 + lane;
             const int tig = q / (NB * 2), n = (q % (NB * 2)) >> 1;
 #ifdef M4D_CV64_GATHER          // (tool builds of the first version: plain [Cout][27][Cin] weights, conv_halo64 --gather stream)
@@ -97,10 +113,11 @@ __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
             const int64_t row = min(n0 + n, p.Cout - 1);
             tab[24 + i] = (unsigned)((row * p.K + tig * p.Cin + c * 8) * 2);
 #else                           // tiled weights (m4d_conv_pack_weights): the piece is the KiB of (row block tn * 3 + n / 32, chunk 0, tap tig)
-            tab[24 + i] = (unsigned)((((tn * NT + (n >> 5)) * (p.Cin / CK)) * 27 + tig) * 1024 + lane * 16);
+            tab[24 + i] = (unsigned)((((tn * NT + (n >> 5)) * (p.Cin / CK)) * NTAPS + tig) * 1024 + lane * 16);
 #endif
         }
-        tab[29] = tab[30] = tab[31] = 0;
+#pragma unroll
+        for (int i = 24 + NWP; i < 32; ++i) tab[i] = 0;
     }
     __syncthreads();
 
@@ -111,13 +128,23 @@ __global__ __launch_bounds__(128, 1) void conv_halo64_kernel(ConvArgs p) {
     const unsigned nch = (unsigned)(p.Cin / CK);
     f32x16 acc[MT][NT];
 #define M4D_U(x) __builtin_amdgcn_readfirstlane((unsigned)(x))
-    asm volatile(
+    if constexpr (KT == 3) {
+        asm volatile(
 #include M4D_CV64_INC
-        : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[1][0]), "={a[64:79]}"(acc[1][1]), "={a[80:95]}"(acc[1][2]), "={a[96:111]}"(acc[2][0]), "={a[112:127]}"(acc[2][1]), "={a[128:143]}"(acc[2][2]), "={a[144:159]}"(acc[3][0]), "={a[160:175]}"(acc[3][1]), "={a[176:191]}"(acc[3][2]), "={a[192:207]}"(acc[4][0]), "={a[208:223]}"(acc[4][1]), "={a[224:239]}"(acc[4][2])
-        : [tid] "v"(threadIdx.x), [rx0] "s"(M4D_U(xb)), [rx1] "s"(M4D_U((xb >> 32) & 0xffff)), [rx2] "s"(M4D_U(rx2)), [rx3] "s"(M4D_U(0x00027000u)),
-          [rw0] "s"(M4D_U(wbp)), [rw1] "s"(M4D_U((wbp >> 32) & 0xffff)), [rw2] "s"(M4D_U(rw2)), [rw3] "s"(M4D_U(0x00027000u)),
-          [cho] "s"(M4D_U(cho)), [frb] "s"(M4D_U(frb)), [chb] "s"(M4D_U(chb)), [gs] "s"(M4D_U(gs)), [nch] "s"(M4D_U(nch)), [lds0] "s"(M4D_U(lds0))
-        : "memory", "vcc", "scc", "m0", M4D_CV64_SCLOB, M4D_CV64_VCLOB, M4D_CV64_ACLOB);
+            : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[1][0]), "={a[64:79]}"(acc[1][1]), "={a[80:95]}"(acc[1][2]), "={a[96:111]}"(acc[2][0]), "={a[112:127]}"(acc[2][1]), "={a[128:143]}"(acc[2][2]), "={a[144:159]}"(acc[3][0]), "={a[160:175]}"(acc[3][1]), "={a[176:191]}"(acc[3][2]), "={a[192:207]}"(acc[4][0]), "={a[208:223]}"(acc[4][1]), "={a[224:239]}"(acc[4][2])
+          : [tid] "v"(threadIdx.x), [rx0] "s"(M4D_U(xb)), [rx1] "s"(M4D_U((xb >> 32) & 0xffff)), [rx2] "s"(M4D_U(rx2)), [rx3] "s"(M4D_U(0x00027000u)),
+            [rw0] "s"(M4D_U(wbp)), [rw1] "s"(M4D_U((wbp >> 32) & 0xffff)), [rw2] "s"(M4D_U(rw2)), [rw3] "s"(M4D_U(0x00027000u)),
+            [cho] "s"(M4D_U(cho)), [frb] "s"(M4D_U(frb)), [chb] "s"(M4D_U(chb)), [gs] "s"(M4D_U(gs)), [nch] "s"(M4D_U(nch)), [lds0] "s"(M4D_U(lds0))
+            : "memory", "vcc", "scc", "m0", M4D_CV64_SCLOB, M4D_CV64_VCLOB, M4D_CV64_ACLOB);
+    } else {
+        asm volatile(
+#include M4D_CV64K1_INC
+            : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), "={a[64:79]}"(acc[1][0]), "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]), "={a[128:143]}"(acc[2][0]), "={a[144:159]}"(acc[2][1]), "={a[160:175]}"(acc[2][2]), "={a[176:191]}"(acc[2][3]), "={a[192:207]}"(acc[3][0]), "={a[208:223]}"(acc[3][1]), "={a[224:239]}"(acc[3][2]), "={a[240:255]}"(acc[3][3])
+          : [tid] "v"(threadIdx.x), [rx0] "s"(M4D_U(xb)), [rx1] "s"(M4D_U((xb >> 32) & 0xffff)), [rx2] "s"(M4D_U(rx2)), [rx3] "s"(M4D_U(0x00027000u)),
+            [rw0] "s"(M4D_U(wbp)), [rw1] "s"(M4D_U((wbp >> 32) & 0xffff)), [rw2] "s"(M4D_U(rw2)), [rw3] "s"(M4D_U(0x00027000u)),
+            [cho] "s"(M4D_U(cho)), [frb] "s"(M4D_U(frb)), [chb] "s"(M4D_U(chb)), [gs] "s"(M4D_U(gs)), [nch] "s"(M4D_U(nch)), [lds0] "s"(M4D_U(lds0))
+            : "memory", "vcc", "scc", "m0", M4D_CV64_SCLOB, M4D_CV64_VCLOB);
+    }
 #undef M4D_U
 
 #include "conv_halo_epi.inc"

@@ -476,3 +476,14 @@ def test_sp_remote_calls_on_a_second_stream(monkeypatch):
     monkeypatch.setattr(wt, "_SP_OVERLAP", True)
     run()
     torch.cuda.synchronize()
+
+
+def test_conv_halo64_k1_bit_identical_to_the_two_wave_kernel():
+    """conv_halo64_kernel<1, 4, 4> (the adaptors' 3 x 3 convs on 128-channel tiles as one wave per SIMD, generated with
+    tools/gen_conv_halo64.py --shape 1x4x4; measured no faster and therefore off by default, M4D_CONV_HALO64K1=1) against
+    conv_halo_kernel<1, 3, 8, 32, 4, 2>: raw, shortcut, ragged patches, fused norm bit for bit, GroupNorm sums to 1e-5."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_conv64k1.py")], capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert out.count("bit-identical") == 6 and "DIFFERENT" not in out and "RESULT k1 1 PASS" in out and "RESULT k1 0 PASS" in out, out[-3000:]
+    assert out.count("'conv_halo64': 1") >= 5, out[-3000:]

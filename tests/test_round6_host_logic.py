@@ -10,13 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("gen,inc", [("gen_attn_q64.py", "attention_q64_gen.inc"), ("gen_attn_bwd64.py", "attention_bwd64_dq_gen.inc"),
-                                     ("gen_attn_bwd64_kv.py", "attention_bwd64_kv_gen.inc"), ("gen_conv_halo64.py", "conv_halo64_gen.inc")])
+                                     ("gen_attn_bwd64_kv.py", "attention_bwd64_kv_gen.inc"), ("gen_conv_halo64.py", "conv_halo64_gen.inc"),
+                                     ("gen_conv_halo64.py --shape 1x4x4", "conv_halo64k1_gen.inc")])
 def test_generated_streams_match_their_generators(gen, inc):
     """the committed .inc files (hashed into the library) are what the generators emit (nothing checked that), and the
     generators' --help works"""
     with tempfile.TemporaryDirectory() as td:
         outp = os.path.join(td, "x.inc")
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "-o", outp], check=True, capture_output=True)
+        gen, *flags = gen.split()
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen), "-o", outp] + flags, check=True, capture_output=True)
         a = [l for l in open(outp) if not l.startswith("//")]
         b = [l for l in open(os.path.join(ROOT, "more4d_amd", "csrc", inc)) if not l.startswith("//")]
         assert a == b, inc

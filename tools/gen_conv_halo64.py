@@ -31,13 +31,22 @@ ap.add_argument("--gather", action="store_true", help="weights in the plain [Cou
 ap.add_argument("--window", action="store_true", help="pixel fragments as a sliding window of image rows per (dt, dw): the five rows of tap (dh, dw) are rows dh .. dh + 4 of "
                 "seven, every row fragment is read ONCE per frame (21 reads per 9 taps instead of 45); same MFMA order, same bits")
 ap.add_argument("--ahead", type=int, default=1, help="fragments are read this many taps ahead of their MFMAs (1: two register sets; 2: three sets — built and measured: bit-identical, same time, the reads cost LDS throughput, not latency)")
-ap.add_argument("-o", default="more4d_amd/csrc/conv_halo64_gen.inc")
+ap.add_argument("--shape", default="3x5x3", help="KT x MT x NT: 3x5x3 = the 3x3x3 conv, 10 x 32 patches, 96-channel tiles (conv_halo64_kernel); "
+                "1x4x4 = the 3x3 conv, 8 x 32 patches, 128-channel tiles (conv_halo64k1_kernel: the adaptors' convs)")
+ap.add_argument("-o", default=None)
 args = ap.parse_args()
 
-MT, NT = 5, 3
-WG_BYTES, WTAP = 9216, 3072
-SLAB = 16384
-CKSTEP = 32 if args.gather else 27 * 1024        # weight soffset step per 16-channel chunk
+KT, MT, NT = (int(v) for v in args.shape.split("x"))
+assert (KT, MT, NT) in ((3, 5, 3), (1, 4, 4))
+if args.o is None:
+    args.o = "more4d_amd/csrc/conv_halo64_gen.inc" if KT == 3 else "more4d_amd/csrc/conv_halo64k1_gen.inc"
+NG = 3 * KT                                      # (dt, dh) groups of three taps per chunk
+WTAP = NT * 1024
+WG_BYTES = 3 * WTAP
+SLAB = 16384 if MT == 5 else 14336               # one frame of one chunk: (2 MT + 2) halo rows x 40 pixels x 32 B, in whole KiB pieces per wave
+NSP, NWP = SLAB // 2048, (WG_BYTES // 1024 + 1) // 2      # DMA pieces per wave: slab / weight group
+CKSTEP = 32 if args.gather else 9 * KT * 1024    # weight soffset step per 16-channel chunk
+assert not (args.gather or args.window or args.ahead != 1) or KT == 3
 W_OFF, S_OFF = 0, 3 * WG_BYTES                 # weight ring, slab ring (bytes from the workgroup's LDS base)
 PITCHB = 40 * 32                               # bytes of one halo row
 
@@ -45,7 +54,7 @@ PITCHB = 40 * 32                               # bytes of one halo row
 AB = [[4 + mi * 3 + dw for dw in range(3)] for mi in range(MT)]       # pixel-fragment addresses (slab ring base included)
 WF = 19                                                               # weight-fragment address (row li of a tap's tile)
 HO = [20 + i for i in range(8)]                                       # slab DMA lane offsets (piece i of this wave)
-WO = [28 + i for i in range(5)]                                       # weight DMA lane offsets
+WO = [28 + i for i in range(6)]                                       # weight DMA lane offsets
 TMP = [34, 35]
 
 
@@ -118,16 +127,17 @@ def tap_mfmas(buf):
 
 
 def dma_w(slot, soff_reg):
-    """this wave's five pieces of a weight group (pieces 2 i + wave; wave 1's fifth repeats piece 8: same bytes, same place) as a list
-    of instruction GROUPS (one per MFMA gap)"""
-    # (piece 8 is the group's last KiB: both waves write it to the same place — wave-independent base)
-    return [[(f"s_add_u32 m0, s{WBW}, 0x{slot * WG_BYTES + i * 2048:x}" if i < 4 else f"s_add_u32 m0, s{LDS0}, 0x{slot * WG_BYTES + 8192:x}"), "s_nop 0",
-             f"buffer_load_dwordx4 v{WO[i]}, {sr(RW)}, s{soff_reg} offen lds"] for i in range(5)]
+    """this wave's pieces of a weight group (pieces 2 i + wave; nine pieces: wave 1's fifth repeats piece 8: same bytes, same place) as a
+    list of instruction GROUPS (one per MFMA gap)"""
+    # (piece 8 of nine is the group's last KiB: both waves write it to the same place — wave-independent base)
+    odd = (WG_BYTES // 1024) % 2 == 1
+    return [[(f"s_add_u32 m0, s{LDS0}, 0x{slot * WG_BYTES + WG_BYTES - 1024:x}" if odd and i == NWP - 1 else f"s_add_u32 m0, s{WBW}, 0x{slot * WG_BYTES + i * 2048:x}"), "s_nop 0",
+             f"buffer_load_dwordx4 v{WO[i]}, {sr(RW)}, s{soff_reg} offen lds"] for i in range(NWP)]
 
 
 def dma_slab(slot, soff_reg):
     return [[f"s_add_u32 m0, s{WBS}, 0x{slot * SLAB + i * 2048:x}", "s_nop 0",
-             f"buffer_load_dwordx4 v{HO[i]}, {sr(RX)}, s{soff_reg} offen lds"] for i in range(8)]
+             f"buffer_load_dwordx4 v{HO[i]}, {sr(RX)}, s{soff_reg} offen lds"] for i in range(NSP)]
 
 
 def w_soff(g, chunk_ahead, dst):
@@ -172,7 +182,7 @@ emit(s_soff(0, 0, ST[0]))
 emit(dma_slab(0, ST[0]))
 emit(w_soff(0, 0, ST[1]))
 emit(dma_w(0, ST[1]))
-emit(s_soff(1, 0, ST[0]))
+emit(s_soff(1, 0, ST[0]) if KT == 3 else s_soff(0, 1, ST[0]))       # (KT = 1: a chunk has one slab — the second request is chunk 1's)
 emit(dma_slab(1, ST[0]))
 emit(w_soff(1, 0, ST[1]))
 emit(dma_w(1, ST[1]))
@@ -182,7 +192,8 @@ for r in range(MT * NT * 16):
 emit("s_waitcnt vmcnt(0)")
 emit("s_barrier")
 def tap_coords(T):
-    """(slab slot, dh, weight slot, dw) of tap T of a chunk (T >= 27: of the next chunk — same slots: three slabs, nine weight groups per chunk)"""
+    """(slab slot, dh, weight slot, dw) of tap T of the loop body.  Slabs and weight groups go through rings of three: a slab serves nine taps
+    (KT = 3: frame dt of the chunk; KT = 1: the chunk), a weight group three — the slots repeat every 27 taps"""
     T %= 27
     return (T // 9) % 3, (T // 3) % 3, (T // 3) % 3, T % 3
 
@@ -244,42 +255,49 @@ if args.window:
         emit(tail_check)
         emit(f"s_cbranch_scc1 {label('done')}" if u == 0 else f"s_cbranch_scc0 {label('chunk')}")
 else:
-    UNROLL = {2: 2, 3: 1}[NBUF]        # chunks per loop body: 27 taps per chunk must line up with the register sets
+    TPC = 9 * KT                       # taps per chunk
+    # chunks per loop body: the taps must line up with the register sets, and (KT = 1: one slab per chunk, ring of three) with the slab slots
+    UNROLL = {(3, 2): 2, (3, 3): 1, (1, 2): 6}[(KT, NBUF)]
+    RD = MT + NT                       # fragment reads per tap: behind MFMAs 1 .. RD, DMA pieces behind the MFMAs after them
     for T in range(args.ahead):        # taps 0 .. ahead - 1 of chunk 0
         emit(frag_reads(T % NBUF, *tap_coords(T)))
     emit(label("chunk") + ":")
     tail_check = [f"s_add_u32 s{CKB}, s{CKB}, 0x{CKSTEP:x}", f"s_add_u32 s{CHO}, s{CHO}, s{CHB}", f"s_sub_u32 s{NCH}, s{NCH}, 1", f"s_cmp_eq_u32 s{NCH}, 0"]
     for u in range(UNROLL):
-        for dt in range(3):
+        for dt in range(KT):
             for dh in range(3):
                 g = dt * 3 + dh
                 # ---- step boundary: weight group g + 1 (and the slab of step g + 1) have landed; weight slot (g + 2) % 3 and, when dh == 0,
-                # slab slot (dt + 2) % 3 are free.  In flight and allowed to stay: the slab requested in the previous step (8 pieces, issued
-                # behind that step's weight pieces).  (The very first boundary has nothing to wait for: same code, the counters are zero.)
-                emit([f"s_waitcnt vmcnt({8 if dh == 1 and 's' not in args.abl else 0})", "s_barrier"])
-                g2, c2 = (g + 2) % 9, (g + 2) // 9
+                # the slab slot two slabs on are free.  In flight and allowed to stay: the slab requested in the previous step (NSP pieces,
+                # issued behind that step's weight pieces).  (The very first boundary has nothing to wait for: same code, the counters are zero.)
+                emit([f"s_waitcnt vmcnt({NSP if dh == 1 and 's' not in args.abl else 0})", "s_barrier"])
+                g2, c2 = (g + 2) % NG, (g + 2) // NG
                 groups = [w_soff(g2, c2, ST[1]) + dma_w((g + 2) % 3, ST[1])[0]] + dma_w((g + 2) % 3, ST[1])[1:]
                 if "w" in args.abl:
                     groups = []
                 if dh == 0 and "s" not in args.abl:
-                    j2 = dt + 2
-                    sl = dma_slab(j2 % 3, ST[0])
-                    groups += [s_soff(j2 % 3, j2 // 3, ST[0]) + sl[0]] + sl[1:]
+                    if KT == 3:      # slab j = 3 c + dt: frame dt + 2 (of this or the next chunk) into slot (dt + 2) % 3
+                        j2 = dt + 2
+                        sl = dma_slab(j2 % 3, ST[0])
+                        groups += [s_soff(j2 % 3, j2 // 3, ST[0]) + sl[0]] + sl[1:]
+                    else:            # slab j = c: the slab of chunk c + 2 into slot (c + 2) % 3 (the loop body starts at a chunk c = 0 mod 3)
+                        sl = dma_slab((u + 2) % 3, ST[0])
+                        groups += [s_soff(0, 2, ST[0]) + sl[0]] + sl[1:]
                 for dw in range(3):
-                    T = u * 27 + g * 3 + dw                  # tap counter over the loop body
+                    T = u * TPC + g * 3 + dw                 # tap counter over the loop body
                     buf = T % NBUF
                     mf = tap_mfmas(buf)
                     # the fragments of tap T + ahead go into the register set tap T - 1 has just released
-                    nxt = frag_reads((T + args.ahead) % NBUF, *tap_coords(g * 3 + dw + args.ahead))
+                    nxt = frag_reads((T + args.ahead) % NBUF, *tap_coords(T + args.ahead))
                     # the reads of the taps in between (issued behind the previous taps' MFMAs, LDS returns in order) may stay in flight
-                    emit(f"s_waitcnt lgkmcnt({0 if 'r' in args.abl else min(15, (args.ahead - 1) * (MT + NT))})")
+                    emit(f"s_waitcnt lgkmcnt({0 if 'r' in args.abl else min(15, (args.ahead - 1) * RD)})")
                     for i, m in enumerate(mf):
                         emit(m)
-                        if 1 <= i <= 8:
+                        if 1 <= i <= RD:
                             if "r" not in args.abl and i - 1 < len(nxt):
-                                emit(nxt[i - 1])                 # one fragment read behind each of MFMAs 1..8
-                        elif i >= 9 and groups:
-                            emit(groups.pop(0))              # one DMA piece (m0, nop, request) behind each of MFMAs 9..14: weights first
+                                emit(nxt[i - 1])                 # one fragment read behind each of MFMAs 1..RD
+                        elif i > RD and groups:
+                            emit(groups.pop(0))              # one DMA piece (m0, nop, request) behind each of the last MFMAs: weights first
                 assert not groups
         emit(tail_check)
         emit(f"s_cbranch_scc1 {label('done')}" if u < UNROLL - 1 else f"s_cbranch_scc0 {label('chunk')}")
