@@ -471,7 +471,11 @@ int launch_halo_auto(ConvArgs& p, hipStream_t st) {
             M4D_ENV_ONCE(h64, "M4D_CONV_HALO64", 1);
             // (planar-16 inputs only — what the residual blocks' fused norms write: + 5 % there; on channels-last inputs, whose halo pieces
             //  are 32 bytes out of every Cin * 2, it measured 5 % SLOWER than the 12 x 32 kernel: tools/check_conv64.py --time.  h64 = 2: both)
-            if (h64 && p.wt && (p.xplane || h64 == 2) && p.kt == 3 && wide && !p.ups && !p.tsplit && p.Cout % 96 == 0 &&
+            // (M4D_CONV_HALO64_NARROW: maps that are no multiple of 32 columns wide but lose at most 1 / 13 of a 32-column patch row to
+            //  padding — the 208-column maps — take it as well instead of the 24 x 16 kernel)
+            M4D_ENV_ONCE(narrow64, "M4D_CONV_HALO64_NARROW", 1);
+            const bool wide64 = wide || (narrow64 && (((p.Wo + 31) / 32) * 32 - p.Wo) * 12 <= p.Wo);
+            if (h64 && p.wt && (p.xplane || h64 == 2) && p.kt == 3 && wide64 && !p.ups && !p.tsplit && p.Cout % 96 == 0 &&
                 (((p.Ho + 9) / 10) * 10 - p.Ho) * 20 <= p.Ho)
                 return launch_halo64<3, 5, 3>(p, st);
             if (p.kt == 3) return wide ? launch_halo<3, 3, 12, 32, 3, 3>(p, st) : launch_halo<3, 3, 24, 16, 3, 3>(p, st);

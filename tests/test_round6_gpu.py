@@ -300,14 +300,14 @@ def test_conv_halo64_bit_identical_to_the_two_wave_kernel():
     """conv_halo64_kernel (csrc/conv_halo64.h: the VAE's 3 x 3 x 3 conv of 96-channel tiles as one wave per SIMD, generated main loop,
     tiled weights) against conv_halo_kernel<3, 3, 12, 32, 3, 3> on plain AND on tiled weights, same inputs, in child processes (the
     switch is read once per process) — same accumulation order, the SAME epilogue source: every output (raw, + shortcut, fused RMS_norm +
-    SiLU into planar-16, 96 / 192 / 384 channels, ragged right edge, planar-16 and channels-last inputs) must agree bit for bit — and
+    SiLU into planar-16, 96 / 192 / 384 channels, ragged right edge, a 208-column map, planar-16 and channels-last inputs) must agree bit for bit — and
     against 27 shifted fp32 GEMMs; m4d_conv_pack_weights against a torch restatement of the tiled order."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_conv64.py")], capture_output=True, text=True, timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
-    assert out.count("bit-identical") == 14 and "DIFFERENT" not in out and "differs from" not in out, out[-3000:]
+    assert out.count("bit-identical") == 16 and "DIFFERENT" not in out and "differs from" not in out, out[-3000:]
     assert "RESULT halo64 2 tiled 1 PASS" in out and "RESULT halo64 0 tiled 1 PASS" in out and "RESULT halo64 0 tiled 0 PASS" in out, out[-3000:]
-    assert out.count("'conv_halo64': 1") == 7, out[-3000:]
+    assert out.count("'conv_halo64': 1") == 8, out[-3000:]
 
 
 def test_vae_residual_block_runs_on_conv_halo64():

@@ -124,6 +124,7 @@ CASES = (
     ("planar_norm_raw", 4, 60, 64, 96, 96, "planar", True, False, True, True),
     ("planar_norm_resid_noraw", 3, 60, 32, 192, 96, "planar", True, True, True, False),
     ("planar_384_384", 3, 120, 224, 384, 384, "planar", True, True),
+    ("planar_384_384_208_columns", 3, 120, 208, 384, 384, "planar", True, True),   # 6.5 patches wide: the 24 x 16 kernel's map (M4D_CONV_HALO64_NARROW)
 )
 
 

@@ -51,6 +51,7 @@ cp(f"{src}/conv64_check_time.log", "conv64_check_time.log")
 cp(f"{src}/ab_gemm_tail.log", "ab_gemm_tail.log")
 cp(f"{src}/ab_conv_tiled.log", "ab_conv_tiled.log")
 cp(f"{src}/ab_sp_overlap.log", "ab_sp_overlap.log")
+cp(f"{src}/ab_conv_narrow.log", "ab_conv_narrow.log")
 for f in glob.glob(f"{src}/vae_train_ks/**/p_kernel_stats.csv", recursive=True):
     cp(f, "vae_train_kernel_stats.csv")
 for f in glob.glob(f"{src}/train_ks/**/p_kernel_stats.csv", recursive=True):

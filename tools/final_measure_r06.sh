@@ -24,7 +24,7 @@ export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_bwd0 -o p -- python $R/tools/check_bwd64.py --child 0 time > $O/pmc_bwd0.log 2>&1)
 { echo "# one-wave-per-SIMD backward (M4D_ATTN_BWD64=3)"; python tools/pmc_busy.py $(find $O/pmc_bwd64 -name "*counter_collection.csv") attn_bwd_kv64 attn_bwd_dq64 attn128q attn_delta; echo; echo "# two-waves-per-SIMD backward (M4D_ATTN_BWD64=0)"; python tools/pmc_busy.py $(find $O/pmc_bwd0 -name "*counter_collection.csv") attn_bwd_kvp attn_bwd_dqp attn128q; } > $O/bwd64_pmc_summary.md 2>&1; cat $O/bwd64_pmc_summary.md
 timeout 300 python -m pytest tests/test_round5_gpu.py -q -s -k "forty" 2>&1 | grep -E "stack40|depth40|passed|failed" > $O/depth40_distance.log; cat $O/depth40_distance.log
-timeout 900 python tools/check_conv64.py --time > $O/conv64_check_time.log 2>&1; grep "^halo64=\|RESULT\|DIFFERENT\|differs" $O/conv64_check_time.log | tail -20; grep -c "bit-identical" $O/conv64_check_time.log
+timeout 900 python tools/check_conv64.py --time > $O/conv64_check_time.log 2>&1; grep "^halo64=\|RESULT\|DIFFERENT\|differs" $O/conv64_check_time.log | tail -20; grep -c "bit-identical" $O/conv64_check_time.log; bash tools/ab_conv_narrow.sh > $O/ab_conv_narrow.log 2>&1; cut -c1-150 $O/ab_conv_narrow.log
 bash tools/ab_conv_tiled.sh > $O/ab_conv_tiled.log 2>&1; grep "^==\|roundtrip" $O/ab_conv_tiled.log | cut -c1-200
 bash tools/ab_sp_overlap.sh > $O/ab_sp_overlap.log 2>&1; cut -c1-200 $O/ab_sp_overlap.log
 timeout 600 python tools/ab_gemm_tail.py 2>&1 | grep -v amdgpu.ids > $O/ab_gemm_tail.log; tail -15 $O/ab_gemm_tail.log
