@@ -468,9 +468,11 @@ int launch_halo_auto(ConvArgs& p, hipStream_t st) {
         const bool fits = (nh * th - p.Ho) * 20 <= p.Ho;      // at most 5 % of the rows are padding
         if (fits && (p.post_out || patches * ((p.Cout + 95) / 96) > 256)) {      // (small maps: launch_halo_nt's 32-channel tiles)
             // M4D_CONV_HALO64=1 (default): the one-wave-per-SIMD kernel (conv_halo64.h) on 32-column maps whose rows divide into 10-row patches
-            M4D_ENV_ONCE(h64, "M4D_CONV_HALO64", 1);
-            // (planar-16 inputs only — what the residual blocks' fused norms write: + 5 % there; on channels-last inputs, whose halo pieces
-            //  are 32 bytes out of every Cin * 2, it measured 5 % SLOWER than the 12 x 32 kernel: tools/check_conv64.py --time.  h64 = 2: both)
+            M4D_ENV_ONCE(h64, "M4D_CONV_HALO64", 2);
+            // (2, default: planar-16 and channels-last inputs; 1: planar-16 only — what the residual blocks' fused norms write; 0: off.  On
+            //  channels-last inputs, whose halo pieces are 32 bytes out of every Cin * 2, the first version (plain weights) was 5 % SLOWER than
+            //  the 12 x 32 kernel; on tiled weights it is 8 % faster there too: tools/check_conv64.py --time.  The inference path has few such
+            //  launches, the training path — channels-last staging — many.)
             // (M4D_CONV_HALO64_NARROW: maps that are no multiple of 32 columns wide but lose at most 1 / 13 of a 32-column patch row to
             //  padding — the 208-column maps — take it as well instead of the 24 x 16 kernel)
             M4D_ENV_ONCE(narrow64, "M4D_CONV_HALO64_NARROW", 1);
